@@ -1,0 +1,198 @@
+/*
+ * icd_amd.h - C ABI of the MI355X-native iCD U-Net hot path (libicd_amd.so).
+ *
+ * This is the drop-in boundary for the ONE path of yandex-research/invertible-cd that this project accelerates:
+ * the few-step consistency U-Net loop.  In the reference the operator boundary is a Python callable
+ *     model.unet(latents, t, timestep_cond=w_emb, encoder_hidden_states=ctx)["sample"]     utils/generation.py:241-244
+ *     pipe.unet(latents, t, encoder_hidden_states=..., timestep_cond=..., added_cond_kwargs=...)[0]
+ *                                                                                           utils/generation_sdxl.py:445-453,288-295
+ * plus the per-Attention-module plugin callback controller(attention_probs, is_cross, place)  utils/p2p.py:336
+ * and the boundary step predicted_origin(...)                                                utils/generation.py:136-155.
+ * All arithmetic below that callable is third-party (diffusers/torch/cuDNN) in the reference; here it is
+ * hand-written HIP for gfx950.  Python (ctypes) binds exactly these entry points - see INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain C, no torch types; every pointer is a DEVICE pointer unless named host_*;
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream);
+ *   - no allocation inside: outputs and workspace are caller-owned;
+ *   - return 0 on success, negative icd_status on failure; icd_last_error() gives the message
+ *     (the Python host raises RuntimeError, keeping the reference's exception convention);
+ *   - activations are fp16 "NHWC" ([B, H*W, C] tokens) inside the path; latents cross the boundary as the
+ *     reference's contiguous NCHW [B,4,H,W];  accumulation is fp32 everywhere.
+ */
+#ifndef ICD_AMD_H
+#define ICD_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    ICD_OK = 0,
+    ICD_ERR_INVALID_ARG = -1,
+    ICD_ERR_UNSUPPORTED = -2,
+    ICD_ERR_HIP = -3,
+    ICD_ERR_MISSING_TENSOR = -4,
+    ICD_ERR_WORKSPACE = -5,
+    ICD_ERR_HOOK = -6
+} icd_status;
+
+const char* icd_last_error(void);
+int icd_version(void);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Block-level operators (diffusers semantics, SURVEY.md section 8a row "a12/13-ops").
+ * ---------------------------------------------------------------------------------------------------------- */
+
+/* flags of icd_gemm_desc */
+#define ICD_GEMM_GEGLU      1   /* out[m, j] = h * gelu_erf(g); weights/bias pre-interleaved in 32-column groups  */
+#define ICD_GEMM_OUT_F32    2   /* out is float (attention scores before softmax)                                   */
+#define ICD_GEMM_OUT_TRANS  4   /* out[(b*N + n)*ldo + (m % rows_per_sample)], b = m / rows_per_sample  (V^T)      */
+
+/* out = alpha * (A (*) W^T) + bias[n] + rowbias[m / rows_per_sample][n] + resid[m][n]
+ * A is either a dense row-major [M, K] matrix (mode 0; Linear, 1x1 conv, attention bmm) or the implicit im2col
+ * view of one/two NHWC tensors (mode 1; conv3x3 pad 1, stride 1|2, optional nearest-2x upsample in the loader,
+ * optional channel concat cat([a0, a1], C) in the loader).  W is [N, K] row-major, K = taps * Cin (tap-major).
+ * Replaces: torch conv2d / linear / baddbmm / bmm issued by diffusers ResnetBlock2D, Transformer2DModel,
+ * Attention (utils/p2p.py:321-342), FeedForward(GEGLU), Down/Upsample2D, TimestepEmbedding. */
+typedef struct {
+    const void* a0;          /* fp16 */
+    const void* a1;          /* fp16, second concat source or NULL */
+    const void* w;           /* fp16 [Nw, K] */
+    const float* bias;       /* fp32 [N] or NULL */
+    const void* rowbias;     /* fp16 [B, ld_rowbias] or NULL (time-embedding projection) */
+    const void* resid;       /* fp16 [M, ldr] or NULL */
+    void* out;               /* fp16 (or fp32 with ICD_GEMM_OUT_F32) */
+    int32_t M, N, K, Nw;     /* Nw = rows of W that exist (rows >= Nw read as zero), usually == N */
+    int32_t lda, ldw, ldo, ldr, ld_rowbias;
+    int32_t rows_per_sample; /* Hout*Wout (tokens per sample) */
+    int32_t mode;            /* 0 dense, 1 conv */
+    int32_t C0, C1;          /* channels of a0 / a1 (conv mode) */
+    int32_t Hin, Win, Hout, Wout, ksize, stride, upsample;
+    int32_t batch;           /* grid.z; z -> (z / zdiv, z % zdiv) */
+    int32_t zdiv;
+    int64_t a_bs0, a_bs1, w_bs0, w_bs1, o_bs0, o_bs1;  /* element strides */
+    float alpha;
+    int32_t flags;
+} icd_gemm_desc;
+
+int icd_gemm(const icd_gemm_desc* d, void* stream);
+
+/* GroupNorm(32 groups, affine, eps) [+ SiLU] over NHWC fp16, input optionally the channel concat of two tensors
+ * (up-block skip connections), output a single NHWC tensor.  stats_ws: >= B*split*groups*2 floats.
+ * Replaces: torch group_norm + silu in ResnetBlock2D / Transformer2DModel.norm / conv_norm_out. */
+int icd_groupnorm(const void* x0, int32_t C0, const void* x1, int32_t C1, int32_t B, int32_t HW, int32_t groups,
+                  const float* gamma, const float* beta, float eps, int32_t silu, void* out, float* stats_ws,
+                  void* stream);
+int64_t icd_groupnorm_ws_floats(int32_t B, int32_t HW, int32_t groups);
+
+/* LayerNorm over the last dim of [rows, C] fp16 (eps 1e-5, affine).  Replaces torch layer_norm in BasicTransformerBlock. */
+int icd_layernorm(const void* x, int64_t rows, int32_t C, const float* gamma, const float* beta, float eps, void* out,
+                  void* stream);
+
+/* Row softmax: P[r, 0:cols] = softmax(scale * S[r, 0:cols]) (fp32 in, fp16 out, pad columns [cols, ld) zeroed).
+ * Replaces Attention.get_attention_scores' softmax (utils/p2p.py:335). */
+int icd_softmax_rows(const float* s, int64_t rows, int32_t cols, int32_t ld_s, float scale, void* p, int32_t ld_p,
+                     void* stream);
+
+/* Fused attention without materialised probabilities (flash style):
+ *   out[b, n, h*d:(h+1)*d] = softmax(scale * q[b,n,h,:] . k[b,:,h,:]) @ v
+ * q: [B, Nq, ldq] (head h at column h*d), k: [B, Nk, ldk], vt: V TRANSPOSED [B, H*d, ldvt] (keys contiguous),
+ * out: [B, Nq, ldo].  d in {40, 64, 80, 160} (any multiple of 8 up to 160).
+ * Used on layers whose controller does not need P (utils/p2p.py:147,184-188: N > 32^2, or no controller). */
+int icd_attention_fused(const void* q, const void* k, const void* vt, void* out, int32_t B, int32_t H, int32_t Nq,
+                        int32_t Nk, int32_t d, int32_t ldq, int32_t ldk, int32_t ldvt, int32_t ldo, float scale,
+                        void* stream);
+
+/* Sinusoidal embeddings.  kind 0: diffusers Timesteps(dim, flip_sin_to_cos=True, shift=0) -> [cos || sin];
+ * kind 1: guidance_scale_embedding (utils/generation.py:96-122) -> [sin || cos] of 1000*w, denominator half-1.
+ * vals: fp32 [n] on device; out fp16 [n, dim]. */
+int icd_sinusoid(const float* vals, int32_t n, int32_t dim, int32_t kind, void* out, void* stream);
+
+/* y = silu(x) over n fp16 elements (time-embedding activation shared by all ResnetBlock2D.time_emb_proj). */
+int icd_silu(const void* x, int64_t n, void* out, void* stream);
+
+/* conv_in: 3x3 pad 1, Cin=4 NCHW latents (fp16 or fp32) -> NHWC fp16 [B, H*W, Cout].  w: fp16 [Cout, 3,3,4]. */
+int icd_conv_in(const void* x_nchw, int32_t x_is_f32, int32_t B, int32_t H, int32_t W, const void* w,
+                const float* bias, int32_t Cout, void* out, void* stream);
+
+/* conv_out: 3x3 pad 1 over NHWC fp16 [B,H*W,Cin] -> NCHW eps [B,4,H,W] (fp16 or fp32).  w: fp16 [4, 3,3,Cin]. */
+int icd_conv_out(const void* x, int32_t B, int32_t H, int32_t W, int32_t Cin, const void* w, const float* bias,
+                 void* eps_nchw, int32_t out_is_f32, void* stream);
+
+/* Consistency boundary step, eps-prediction (utils/generation.py:136-155 == utils/generation_sdxl.py:112-132):
+ *   x0 = (x - sigma_t*eps)/alpha_t ; out = alpha_s*x0 + sigma_s*eps, (alpha_s, sigma_s) := (1, 0) where s == 0.
+ * coef: fp32 [B,4] = (alpha_t, sigma_t, alpha_s, sigma_s) per sample (host gathers them from the 1000-entry
+ * tables, as the reference does with extract_into_tensor).  x/eps/out: [B, per_sample]; dtype_flags bit0: x is fp32,
+ * bit1: eps is fp32, bit2: out is fp32 (otherwise fp16).  Arithmetic is fp32 without FMA contraction, i.e. the
+ * reference's torch expression evaluated in fp32 (tables are fp32, so torch promotes). */
+int icd_x0_step(const void* x, const void* eps, const float* coef, int32_t B, int64_t per_sample, int32_t dtype_flags,
+                void* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Whole-U-Net executor (native runtime: plan + arena + launches; one call per UNet evaluation).
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t in_channels, out_channels;
+    int32_t num_levels;                 /* 4 (SD1.5) or 3 (SDXL) */
+    int32_t block_out_channels[4];
+    int32_t down_has_attn[4], up_has_attn[4];
+    int32_t transformer_layers[4];      /* per down level */
+    int32_t num_heads[4];               /* per down level */
+    int32_t layers_per_block;
+    int32_t cross_dim;
+    int32_t use_linear_projection;      /* informational: proj_in/out are GEMMs either way in NHWC */
+    int32_t time_cond_proj_dim;         /* 512 or 0 */
+    int32_t addition_time_embed_dim;    /* 256 (SDXL) or 0 */
+    int32_t add_in_dim;                 /* 2816 (SDXL) or 0 */
+    int32_t norm_groups;
+} icd_unet_config;
+
+typedef struct icd_unet icd_unet;
+
+/* Attention plugin callback - the C form of `controller(attention_probs, is_cross, place_in_unet)` (utils/p2p.py:336).
+ * Called on the host, in module-execution order, once per Attention module per forward with phase 0:
+ *   phase 0 (ICD_HOOK_QUERY): return 0 -> run this layer fused (no P); return 1 -> materialise P: the hook must have
+ *            stored in *probs a device buffer of bh*nq*ld fp16 elements (a FRESH allocation if it intends to keep
+ *            it, cf. AttentionStore's views utils/p2p.py:148).
+ *   phase 1 (ICD_HOOK_PROBS): P has been enqueued on `stream`; the hook may enqueue in-place edits on the same
+ *            stream.  Return 0; negative aborts the forward with ICD_ERR_HOOK.
+ * place: 0 down, 1 mid, 2 up.  P layout: [bh = B*heads (row b*heads+h), nq, ld] with nk valid columns. */
+#define ICD_HOOK_QUERY 0
+#define ICD_HOOK_PROBS 1
+typedef int (*icd_attn_hook)(void* user, int32_t phase, int32_t layer, int32_t is_cross, int32_t place, int64_t bh,
+                             int64_t nq, int64_t nk, int64_t ld, void** probs);
+
+int icd_unet_create(const icd_unet_config* cfg, icd_unet** out);
+void icd_unet_destroy(icd_unet* u);
+/* Bind one packed tensor (see invertible_cd_amd/unet.py for the packing).  dtype: 0 fp16, 1 fp32. */
+int icd_unet_set_tensor(icd_unet* u, const char* name, const void* ptr, int32_t dtype, int64_t numel);
+/* Validate that every tensor the plan needs is bound. */
+int icd_unet_finalize(icd_unet* u);
+int32_t icd_unet_num_attention_layers(const icd_unet* u);
+int64_t icd_unet_workspace_bytes(const icd_unet* u, int32_t batch, int32_t H, int32_t W, int32_t n_ctx);
+
+typedef struct {
+    const void* sample;        /* NCHW [B, in_ch, H, W], fp16 or fp32 (sample_is_f32) */
+    const float* timesteps;    /* fp32 [B] (device) */
+    const void* context;       /* fp16 [B, n_ctx, cross_dim] */
+    const void* timestep_cond; /* fp16 [B, time_cond_proj_dim] or NULL */
+    const void* text_embeds;   /* fp16 [B, add_in_dim - 6*addition_time_embed_dim] (SDXL) or NULL */
+    const float* time_ids;     /* fp32 [B, 6] (SDXL) or NULL */
+    void* eps;                 /* NCHW [B, out_ch, H, W] (same dtype as sample) */
+    void* workspace;
+    int64_t workspace_bytes;
+    int32_t batch, H, W, n_ctx;
+    int32_t sample_is_f32;
+    icd_attn_hook hook;        /* NULL: every attention layer fused */
+    void* hook_user;
+} icd_unet_io;
+
+int icd_unet_forward(icd_unet* u, const icd_unet_io* io, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ICD_AMD_H */

@@ -1,0 +1,111 @@
+"""ctypes binding of libicd_amd.so (the C ABI declared in include/icd_amd.h).
+
+The product path fails loudly when the HIP extension is missing: there is NO CPU fallback.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libicd_amd.so")
+
+ICD_GEMM_GEGLU = 1
+ICD_GEMM_OUT_F32 = 2
+ICD_GEMM_OUT_TRANS = 4
+ICD_HOOK_QUERY = 0
+ICD_HOOK_PROBS = 1
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [
+        ("a0", C.c_void_p), ("a1", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p), ("rowbias", C.c_void_p),
+        ("resid", C.c_void_p), ("out", C.c_void_p),
+        ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("Nw", C.c_int32),
+        ("lda", C.c_int32), ("ldw", C.c_int32), ("ldo", C.c_int32), ("ldr", C.c_int32), ("ld_rowbias", C.c_int32),
+        ("rows_per_sample", C.c_int32), ("mode", C.c_int32), ("C0", C.c_int32), ("C1", C.c_int32),
+        ("Hin", C.c_int32), ("Win", C.c_int32), ("Hout", C.c_int32), ("Wout", C.c_int32), ("ksize", C.c_int32),
+        ("stride", C.c_int32), ("upsample", C.c_int32), ("batch", C.c_int32), ("zdiv", C.c_int32),
+        ("a_bs0", C.c_int64), ("a_bs1", C.c_int64), ("w_bs0", C.c_int64), ("w_bs1", C.c_int64),
+        ("o_bs0", C.c_int64), ("o_bs1", C.c_int64), ("alpha", C.c_float), ("flags", C.c_int32),
+    ]
+
+
+class UNetConfig(C.Structure):
+    _fields_ = [
+        ("in_channels", C.c_int32), ("out_channels", C.c_int32), ("num_levels", C.c_int32),
+        ("block_out_channels", C.c_int32 * 4), ("down_has_attn", C.c_int32 * 4), ("up_has_attn", C.c_int32 * 4),
+        ("transformer_layers", C.c_int32 * 4), ("num_heads", C.c_int32 * 4), ("layers_per_block", C.c_int32),
+        ("cross_dim", C.c_int32), ("use_linear_projection", C.c_int32), ("time_cond_proj_dim", C.c_int32),
+        ("addition_time_embed_dim", C.c_int32), ("add_in_dim", C.c_int32), ("norm_groups", C.c_int32),
+    ]
+
+
+ATTN_HOOK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int64,
+                        C.c_int64, C.c_int64, C.POINTER(C.c_void_p))
+
+
+class UNetIO(C.Structure):
+    _fields_ = [
+        ("sample", C.c_void_p), ("timesteps", C.c_void_p), ("context", C.c_void_p), ("timestep_cond", C.c_void_p),
+        ("text_embeds", C.c_void_p), ("time_ids", C.c_void_p), ("eps", C.c_void_p), ("workspace", C.c_void_p),
+        ("workspace_bytes", C.c_int64), ("batch", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("n_ctx", C.c_int32),
+        ("sample_is_f32", C.c_int32), ("hook", ATTN_HOOK), ("hook_user", C.c_void_p),
+    ]
+
+
+# name -> (restype, argtypes); mirrors include/icd_amd.h one to one (tests/test_cabi.py checks the export list)
+SIGNATURES = {
+    "icd_last_error": (C.c_char_p, []),
+    "icd_version": (C.c_int, []),
+    "icd_gemm": (C.c_int, [C.POINTER(GemmDesc), C.c_void_p]),
+    "icd_groupnorm": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                C.c_void_p, C.c_void_p, C.c_float, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "icd_groupnorm_ws_floats": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
+    "icd_layernorm": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p,
+                                C.c_void_p]),
+    "icd_softmax_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_int32,
+                                   C.c_void_p]),
+    "icd_attention_fused": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                      C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float,
+                                      C.c_void_p]),
+    "icd_sinusoid": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "icd_silu": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "icd_conv_in": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                              C.c_int32, C.c_void_p, C.c_void_p]),
+    "icd_conv_out": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                               C.c_void_p, C.c_int32, C.c_void_p]),
+    "icd_x0_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_void_p,
+                              C.c_void_p]),
+    "icd_unet_create": (C.c_int, [C.POINTER(UNetConfig), C.POINTER(C.c_void_p)]),
+    "icd_unet_destroy": (None, [C.c_void_p]),
+    "icd_unet_set_tensor": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int32, C.c_int64]),
+    "icd_unet_finalize": (C.c_int, [C.c_void_p]),
+    "icd_unet_num_attention_layers": (C.c_int32, [C.c_void_p]),
+    "icd_unet_workspace_bytes": (C.c_int64, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "icd_unet_forward": (C.c_int, [C.c_void_p, C.POINTER(UNetIO), C.c_void_p]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libicd_amd.so and set the prototypes.  Raises (never falls back) if the library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: the MI355X HIP extension is not built.  Run `python -m invertible_cd_amd.build` "
+            "(or __graft_entry__.build()).  There is no CPU fallback for the product path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status, what=""):
+    if status != 0:
+        msg = load().icd_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"libicd_amd {what} failed (status {status}): {msg}")

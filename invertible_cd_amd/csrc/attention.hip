@@ -1,0 +1,240 @@
+// attention.hip - fused (flash-style) attention for layers whose controller does not need the probabilities.
+//
+// Replaces the un-fused baddbmm -> softmax -> bmm the p2p hook forces in the reference (utils/p2p.py:335-338) on every
+// layer where the plugin is a data no-op (N > 32^2 for every shipped controller, utils/p2p.py:147,184-188; all layers
+// when no controller is registered, e.g. the whole SDXL path utils/generation_sdxl.py:445-453).
+//
+// CDNA4 design:
+//   * one workgroup = 4 waves = 128 query rows of one (batch, head); KV tiles of 64 keys, double-buffered in LDS via
+//     global_load_lds (K tile [64][dpad16], V^T tile [dpad32][64]; V arrives already transposed from the to_v GEMM
+//     epilogue, so both MFMA operands are K-contiguous and no transposing LDS read is needed).
+//   * S^T = K.Q^T with v_mfma_f32_32x32x16_f16 (K as A operand, Q fragments held in registers as B operand): each lane
+//     owns ONE query column and 32 of the tile's 64 keys, so the online-softmax row reductions are in-lane plus one
+//     cross-half shuffle.
+//   * O^T += V^T.P^T reuses the S^T accumulator registers directly as the B operand: the k-index <-> key permutation is
+//     chosen to match the 32x32 accumulator layout (keys 16s+4h+{0..3,8..11}), V^T fragments are fetched with two
+//     ds_read_b64 in the same permutation.  P never leaves registers.
+//   * XCD-aware block order: the q-tiles of one (b, h) run on one XCD so its K/V stay in that XCD's L2.
+#include "common.h"
+
+namespace {
+
+template <int NCH>
+__device__ __forceinline__ int k_swz(int row, int chunk) {
+    if (NCH % 16 == 0) return chunk ^ (row & 15);
+    if (NCH % 8 == 0) return chunk ^ ((row >> 1) & 7);
+    if (NCH % 4 == 0) return chunk ^ ((row >> 2) & 3);
+    return chunk;
+}
+
+struct AttnK {
+    const half_t* q; const half_t* k; const half_t* vt; half_t* out;
+    int B, H, Nq, Nk, d, ldq, ldk, ldvt, ldo;
+    float scale_log2;
+    int nqt;
+};
+
+// KS = number of 16-wide k-steps over the head dim (dpad16 = 16*KS); DT = number of 32-row tiles of the head dim.
+template <int KS, int DT>
+__global__ __launch_bounds__(256, 2) void attn_fused_kernel(AttnK p) {
+    constexpr int NCH = 2 * KS;                       // 16-B chunks per K row
+    constexpr int KT_BYTES = 64 * NCH * 16;           // K tile
+    constexpr int VT_BYTES = DT * 32 * 128;           // V^T tile, 64 keys = 128 B per row
+    constexpr int STAGE = KT_BYTES + VT_BYTES;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, wv = tid >> 6, l = tid & 63, lr = l & 31, lh = l >> 5;
+
+    int bid = blockIdx.x;
+    {
+        const int nblk = gridDim.x;
+        const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
+        bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    }
+    const int qt = bid % p.nqt, bh = bid / p.nqt;
+    const int b = bh / p.H, h = bh - b * p.H;
+    const int q0 = qt * 128 + wv * 32;
+    const half_t* zero = reinterpret_cast<const half_t*>(icd_zero_page);
+
+    const half_t* Kb = p.k + (long long)b * p.Nk * p.ldk + h * p.d;
+    const half_t* Vb = p.vt + ((long long)b * p.H * p.d + (long long)h * p.d) * p.ldvt;
+
+    // Q fragments: lane = query row q0+lr, head-dim offset ks*16 + lh*8
+    f16x8 qf[KS];
+    {
+        const int qrow = q0 + lr;
+        const half_t* qp = p.q + ((long long)b * p.Nq + qrow) * p.ldq + h * p.d;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int dd = ks * 16 + lh * 8;
+            if (qrow < p.Nq && dd < p.d) qf[ks] = *reinterpret_cast<const f16x8*>(qp + dd);
+            else
+#pragma unroll
+                for (int e = 0; e < 8; ++e) qf[ks][e] = (half_t)0.f;
+        }
+    }
+
+    auto issue = [&](int t, int buf) {
+        unsigned char* sk = smem + buf * STAGE;
+        unsigned char* sv = sk + KT_BYTES;
+        const int kv0 = t * 64;
+        // K tile: 64 rows x NCH chunks = 2*KS groups of 64 chunks
+#pragma unroll
+        for (int g = wv; g < 2 * KS; g += 4) {
+            const int cid = g * 64 + l;
+            const int row = cid / NCH, pc = cid - row * NCH;
+            const int lc = k_swz<NCH>(row, pc);
+            const int key = kv0 + row, dd = lc * 8;
+            const half_t* src = (key < p.Nk && dd < p.d) ? Kb + (long long)key * p.ldk + dd : zero;
+            glds16(src, sk + g * 1024);
+        }
+        // V^T tile: DT*32 rows x 8 chunks = 4*DT groups
+#pragma unroll
+        for (int g = wv; g < 4 * DT; g += 4) {
+            const int cid = g * 64 + l;
+            const int row = cid >> 3, pc = cid & 7;
+            const int lc = pc ^ ((row >> 1) & 7);
+            const int key = kv0 + lc * 8;
+            const half_t* src = (row < p.d && key < p.ldvt) ? Vb + (long long)row * p.ldvt + key : zero;
+            glds16(src, sv + g * 1024);
+        }
+    };
+
+    f32x16 o[DT];
+#pragma unroll
+    for (int i = 0; i < DT; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[i][e] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const int nt = (p.Nk + 63) >> 6;
+    issue(0, 0);
+    for (int t = 0; t < nt; ++t) {
+        __builtin_amdgcn_s_waitcnt(0x0f70);
+        __syncthreads();
+        if (t + 1 < nt) issue(t + 1, (t + 1) & 1);
+        const unsigned char* sk = smem + (t & 1) * STAGE;
+        const unsigned char* sv = sk + KT_BYTES;
+
+        // ---- S^T[key][q] for two 32-key tiles ----
+        f32x16 s[2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s[kt][e] = 0.f;
+            const int row = kt * 32 + lr;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int c = ks * 2 + lh;
+                f16x8 kf = *reinterpret_cast<const f16x8*>(sk + (row * NCH + k_swz<NCH>(row, c)) * 16);
+                s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s[kt], 0, 0, 0);
+            }
+        }
+        // ---- online softmax (lane owns query column lr; keys 32kt + 8g + 4lh + i) ----
+        const bool ragged = (t + 1) * 64 > p.Nk;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float v = s[kt][e] * p.scale_log2;
+                if (ragged) {
+                    const int key = t * 64 + kt * 32 + 8 * (e >> 2) + 4 * lh + (e & 3);
+                    if (key >= p.Nk) v = -INFINITY;
+                }
+                s[kt][e] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = exp2f(m_run - m_new);
+        float rs = 0.f;
+        f16x8 pf[4];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float pv = exp2f(s[kt][e] - m_new);
+                rs += pv;
+                pf[kt * 2 + (e >> 3)][e & 7] = (half_t)pv;
+            }
+        l_run = l_run * alpha + rs;
+        m_run = m_new;
+#pragma unroll
+        for (int i = 0; i < DT; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) o[i][e] *= alpha;
+        // ---- O^T[dcol][q] += V^T[dcol][keys] . P^T[keys][q] ----
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            const int c0 = st * 2;                      // keys 16st + 4lh + {0..3} and +8
+#pragma unroll
+            for (int i = 0; i < DT; ++i) {
+                const int row = i * 32 + lr;
+                const unsigned char* rp = sv + row * 128 + lh * 8;
+                const int x = (row >> 1) & 7;
+                f16x4 v0 = *reinterpret_cast<const f16x4*>(rp + ((c0 ^ x) << 4));
+                f16x4 v1 = *reinterpret_cast<const f16x4*>(rp + (((c0 + 1) ^ x) << 4));
+                f16x8 vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                o[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[st], o[i], 0, 0, 0);
+            }
+        }
+    }
+    // ---- normalise and store: lane holds 4 consecutive head-dim columns of query row q0+lr ----
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv = 1.0f / l_tot;
+    const int qrow = q0 + lr;
+    if (qrow < p.Nq) {
+        half_t* op = p.out + ((long long)b * p.Nq + qrow) * p.ldo + h * p.d;
+#pragma unroll
+        for (int i = 0; i < DT; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int dc = i * 32 + 8 * g + 4 * lh;
+                if (dc < p.d) {
+                    f16x4 v = {(half_t)(o[i][4 * g] * inv), (half_t)(o[i][4 * g + 1] * inv),
+                               (half_t)(o[i][4 * g + 2] * inv), (half_t)(o[i][4 * g + 3] * inv)};
+                    *reinterpret_cast<f16x4*>(op + dc) = v;
+                }
+            }
+    }
+}
+
+template <int KS, int DT>
+int launch_attn(const AttnK& k, hipStream_t st) {
+    constexpr int smem = 2 * (64 * 2 * KS * 16 + DT * 32 * 128);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fused_kernel<KS, DT>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((attn_fused_kernel<KS, DT>), dim3(k.nqt * k.B * k.H), dim3(256), smem, st, k);
+    ICD_CHECK_LAUNCH("icd_attention_fused");
+    return ICD_OK;
+}
+
+}  // namespace
+
+extern "C" int icd_attention_fused(const void* q, const void* k, const void* vt, void* out, int32_t B, int32_t H,
+                                   int32_t Nq, int32_t Nk, int32_t d, int32_t ldq, int32_t ldk, int32_t ldvt,
+                                   int32_t ldo, float scale, void* stream) {
+    ICD_CHECK_ARG(q && k && vt && out, "icd_attention_fused: null pointer");
+    ICD_CHECK_ARG(B > 0 && H > 0 && Nq > 0 && Nk > 0, "icd_attention_fused: empty shape");
+    ICD_CHECK_ARG(d > 0 && d % 8 == 0 && d <= 160, "icd_attention_fused: head dim must be a multiple of 8, <= 160 (got %d)", d);
+    ICD_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldvt % 8 == 0 && ldo % 4 == 0 && ldvt >= Nk,
+                  "icd_attention_fused: leading dims must be 16-byte aligned and ldvt >= Nk");
+    AttnK a;
+    a.q = (const half_t*)q; a.k = (const half_t*)k; a.vt = (const half_t*)vt; a.out = (half_t*)out;
+    a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.d = d; a.ldq = ldq; a.ldk = ldk; a.ldvt = ldvt; a.ldo = ldo;
+    a.scale_log2 = scale * 1.4426950408889634f;
+    a.nqt = (Nq + 127) / 128;
+    hipStream_t st = (hipStream_t)stream;
+    if (d <= 16) return launch_attn<1, 1>(a, st);
+    if (d <= 32) return launch_attn<2, 1>(a, st);
+    if (d <= 48) return launch_attn<3, 2>(a, st);
+    if (d <= 64) return launch_attn<4, 2>(a, st);
+    if (d <= 80) return launch_attn<5, 3>(a, st);
+    if (d <= 96) return launch_attn<6, 3>(a, st);
+    if (d <= 128) return launch_attn<8, 4>(a, st);
+    return launch_attn<10, 5>(a, st);
+}

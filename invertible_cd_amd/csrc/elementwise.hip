@@ -1,0 +1,207 @@
+// elementwise.hip - small HBM/latency-bound pieces of the UNet path on gfx950:
+//   sinusoidal embeddings, SiLU, conv_in (NCHW latents -> NHWC), conv_out (NHWC -> NCHW eps) and the consistency
+//   boundary step predicted_origin (utils/generation.py:136-155).
+#include "common.h"
+
+namespace {
+
+// kind 0: diffusers Timesteps(dim, flip_sin_to_cos=True, downscale_freq_shift=0): [cos(t f_i) || sin(t f_i)],
+//         f_i = exp(-ln(1e4) i / half)
+// kind 1: guidance_scale_embedding (utils/generation.py:96-122): [sin(1000 w f_i) || cos(..)], f_i = exp(-ln(1e4) i/(half-1))
+__global__ void sinusoid_kernel(const float* __restrict__ vals, int n, int dim, int kind, half_t* __restrict__ out) {
+    const int half = dim >> 1;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * half) return;
+    const int r = idx / half, i = idx - r * half;
+    const float lg = 9.210340371976184f;   // ln(10000)
+    if (kind == 0) {
+        const float f = expf(-lg * (float)i / (float)half);
+        const float a = vals[r] * f;
+        out[(long long)r * dim + i] = (half_t)cosf(a);
+        out[(long long)r * dim + half + i] = (half_t)sinf(a);
+    } else {
+        const float step = lg / (float)(half - 1);
+        const float f = expf((float)i * -step);
+        const float a = (vals[r] * 1000.0f) * f;
+        out[(long long)r * dim + i] = (half_t)sinf(a);
+        out[(long long)r * dim + half + i] = (half_t)cosf(a);
+        if ((dim & 1) && i == 0) out[(long long)r * dim + dim - 1] = (half_t)0.f;
+    }
+}
+
+__global__ void silu_kernel(const half_t* __restrict__ x, long long n8, half_t* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n8) return;
+    f16x8 v = *reinterpret_cast<const f16x8*>(x + i * 8), o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (half_t)silu_f((float)v[e]);
+    *reinterpret_cast<f16x8*>(out + i * 8) = o;
+}
+
+// conv_in: thread = (pixel, 8 output channels).  Input NCHW with 4 channels; weights [Cout][3][3][4] fp16.
+template <typename TIn>
+__global__ __launch_bounds__(256) void conv_in_kernel(const TIn* __restrict__ x, int B, int H, int W,
+                                                       const half_t* __restrict__ w, const float* __restrict__ bias,
+                                                       int Cout, half_t* __restrict__ out) {
+    const int nch = Cout >> 3;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)B * H * W * nch;
+    if (idx >= total) return;
+    const int oc = (int)(idx % nch) * 8;
+    const long long pix = idx / nch;
+    const int HW = H * W;
+    const int b = (int)(pix / HW), rem = (int)(pix - (long long)b * HW);
+    const int y = rem / W, xx = rem - y * W;
+    float in[36];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int yy = y + t / 3 - 1, xc = xx + t % 3 - 1;
+        const bool ok = (unsigned)yy < (unsigned)H && (unsigned)xc < (unsigned)W;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            in[t * 4 + c] = ok ? (float)x[((long long)(b * 4 + c) * H + yy) * W + xc] : 0.f;
+    }
+    f16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const half_t* wr = w + (long long)(oc + e) * 36;
+        float acc = bias ? bias[oc + e] : 0.f;
+#pragma unroll
+        for (int k = 0; k < 36; k += 4) {
+            f16x4 wv = *reinterpret_cast<const f16x4*>(wr + k);
+            acc += in[k] * (float)wv[0] + in[k + 1] * (float)wv[1] + in[k + 2] * (float)wv[2] + in[k + 3] * (float)wv[3];
+        }
+        o[e] = (half_t)acc;
+    }
+    *reinterpret_cast<f16x8*>(out + pix * Cout + oc) = o;
+}
+
+// conv_out: one wave per output pixel; lanes stride over 8-channel chunks; 4 output channels.  w: [4][3][3][Cin].
+template <typename TOut>
+__global__ __launch_bounds__(256) void conv_out_kernel(const half_t* __restrict__ x, int B, int H, int W, int Cin,
+                                                        const half_t* __restrict__ w, const float* __restrict__ bias,
+                                                        TOut* __restrict__ eps) {
+    const int l = threadIdx.x & 63;
+    const long long pix = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int HW = H * W;
+    if (pix >= (long long)B * HW) return;
+    const int b = (int)(pix / HW), rem = (int)(pix - (long long)b * HW);
+    const int y = rem / W, xx = rem - y * W;
+    const int nch = Cin >> 3;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < 9; ++t) {
+        const int yy = y + t / 3 - 1, xc = xx + t % 3 - 1;
+        if ((unsigned)yy >= (unsigned)H || (unsigned)xc >= (unsigned)W) continue;   // wave-uniform
+        const half_t* xp = x + ((long long)b * HW + yy * W + xc) * Cin;
+        for (int c = l; c < nch; c += 64) {
+            f16x8 v = *reinterpret_cast<const f16x8*>(xp + c * 8);
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                f16x8 wv = *reinterpret_cast<const f16x8*>(w + ((long long)(o * 9 + t)) * Cin + c * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[o] += (float)v[e] * (float)wv[e];
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < 4; ++o) acc[o] = wave_sum(acc[o]);
+    if (l < 4) {
+        const float v = (l == 0 ? acc[0] : l == 1 ? acc[1] : l == 2 ? acc[2] : acc[3]) + (bias ? bias[l] : 0.f);
+        eps[((long long)(b * 4 + l) * H + y) * W + xx] = (TOut)v;
+    }
+}
+
+// predicted_origin, eps-prediction.  Evaluation order and roundings mirror the reference's fp32 torch expression
+// (no FMA contraction): x0 = (x - sigma_t*eps) / alpha_t ; out = alpha_s*x0 + sigma_s*eps.
+template <typename TX, typename TE, typename TO>
+__global__ void x0_step_kernel(const TX* __restrict__ x, const TE* __restrict__ eps, const float* __restrict__ coef,
+                               long long per_sample, long long total, TO* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int b = (int)(i / per_sample);
+    const float a_t = coef[b * 4 + 0], s_t = coef[b * 4 + 1], a_s = coef[b * 4 + 2], s_s = coef[b * 4 + 3];
+    const float xv = (float)x[i], ev = (float)eps[i];
+    const float x0 = __fdiv_rn(__fsub_rn(xv, __fmul_rn(s_t, ev)), a_t);
+    out[i] = (TO)__fadd_rn(__fmul_rn(a_s, x0), __fmul_rn(s_s, ev));
+}
+
+}  // namespace
+
+extern "C" int icd_sinusoid(const float* vals, int32_t n, int32_t dim, int32_t kind, void* out, void* stream) {
+    ICD_CHECK_ARG(vals && out && n > 0 && dim >= 2, "icd_sinusoid: bad arguments");
+    ICD_CHECK_ARG(kind == 0 || kind == 1, "icd_sinusoid: kind must be 0 or 1");
+    ICD_CHECK_ARG(kind == 1 || dim % 2 == 0, "icd_sinusoid: Timesteps dim must be even");
+    const int total = n * (dim / 2);
+    hipLaunchKernelGGL(sinusoid_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, vals, n, dim, kind,
+                       (half_t*)out);
+    ICD_CHECK_LAUNCH("icd_sinusoid");
+    return ICD_OK;
+}
+
+extern "C" int icd_silu(const void* x, int64_t n, void* out, void* stream) {
+    ICD_CHECK_ARG(x && out && n > 0 && n % 8 == 0, "icd_silu: n must be a positive multiple of 8");
+    const long long n8 = n / 8;
+    hipLaunchKernelGGL(silu_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const half_t*)x, n8, (half_t*)out);
+    ICD_CHECK_LAUNCH("icd_silu");
+    return ICD_OK;
+}
+
+extern "C" int icd_conv_in(const void* x_nchw, int32_t x_is_f32, int32_t B, int32_t H, int32_t W, const void* w,
+                           const float* bias, int32_t Cout, void* out, void* stream) {
+    ICD_CHECK_ARG(x_nchw && w && out, "icd_conv_in: null pointer");
+    ICD_CHECK_ARG(B > 0 && H > 0 && W > 0 && Cout > 0 && Cout % 8 == 0, "icd_conv_in: bad shape");
+    const long long total = (long long)B * H * W * (Cout / 8);
+    dim3 grid((unsigned)((total + 255) / 256));
+    if (x_is_f32)
+        hipLaunchKernelGGL(conv_in_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x_nchw, B, H, W,
+                           (const half_t*)w, bias, Cout, (half_t*)out);
+    else
+        hipLaunchKernelGGL(conv_in_kernel<half_t>, grid, dim3(256), 0, (hipStream_t)stream, (const half_t*)x_nchw, B, H,
+                           W, (const half_t*)w, bias, Cout, (half_t*)out);
+    ICD_CHECK_LAUNCH("icd_conv_in");
+    return ICD_OK;
+}
+
+extern "C" int icd_conv_out(const void* x, int32_t B, int32_t H, int32_t W, int32_t Cin, const void* w,
+                            const float* bias, void* eps_nchw, int32_t out_is_f32, void* stream) {
+    ICD_CHECK_ARG(x && w && eps_nchw, "icd_conv_out: null pointer");
+    ICD_CHECK_ARG(B > 0 && H > 0 && W > 0 && Cin > 0 && Cin % 8 == 0, "icd_conv_out: bad shape");
+    const long long pixels = (long long)B * H * W;
+    dim3 grid((unsigned)((pixels + 3) / 4));
+    if (out_is_f32)
+        hipLaunchKernelGGL(conv_out_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const half_t*)x, B, H, W, Cin,
+                           (const half_t*)w, bias, (float*)eps_nchw);
+    else
+        hipLaunchKernelGGL(conv_out_kernel<half_t>, grid, dim3(256), 0, (hipStream_t)stream, (const half_t*)x, B, H, W, Cin,
+                           (const half_t*)w, bias, (half_t*)eps_nchw);
+    ICD_CHECK_LAUNCH("icd_conv_out");
+    return ICD_OK;
+}
+
+extern "C" int icd_x0_step(const void* x, const void* eps, const float* coef, int32_t B, int64_t per_sample,
+                           int32_t dtype_flags, void* out, void* stream) {
+    ICD_CHECK_ARG(x && eps && coef && out && B > 0 && per_sample > 0, "icd_x0_step: bad arguments");
+    ICD_CHECK_ARG(dtype_flags >= 0 && dtype_flags < 8, "icd_x0_step: bad dtype flags");
+    const long long total = (long long)B * per_sample;
+    dim3 grid((unsigned)((total + 255) / 256)), blk(256);
+    hipStream_t st = (hipStream_t)stream;
+#define X0_CASE(F, TX, TE, TO)                                                                                       \
+    case F:                                                                                                          \
+        hipLaunchKernelGGL((x0_step_kernel<TX, TE, TO>), grid, blk, 0, st, (const TX*)x, (const TE*)eps, coef,      \
+                           (long long)per_sample, total, (TO*)out);                                                  \
+        break;
+    switch (dtype_flags) {
+        X0_CASE(0, half_t, half_t, half_t)
+        X0_CASE(1, float, half_t, half_t)
+        X0_CASE(2, half_t, float, half_t)
+        X0_CASE(3, float, float, half_t)
+        X0_CASE(4, half_t, half_t, float)
+        X0_CASE(5, float, half_t, float)
+        X0_CASE(6, half_t, float, float)
+        X0_CASE(7, float, float, float)
+    }
+#undef X0_CASE
+    ICD_CHECK_LAUNCH("icd_x0_step");
+    return ICD_OK;
+}

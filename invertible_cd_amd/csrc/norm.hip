@@ -1,0 +1,244 @@
+// norm.hip - HBM-bound normalisation kernels of the UNet path (gfx950): GroupNorm(+SiLU), LayerNorm, row softmax.
+//
+// All of them move fp16 NHWC / token-major activations with 16-byte per-lane accesses; statistics are fp32 and
+// reduced in a fixed order (no atomics) so results are bit-reproducible run to run.
+#include "common.h"
+
+namespace {
+
+constexpr int GN_THREADS = 512;
+
+__host__ __device__ inline int gn_pix_per_split(int HW) {
+    int p = (HW + 63) / 64;
+    return p < 64 ? 64 : p;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// GroupNorm pass 1: per (sample, pixel-slab) partial (sum, sumsq) per group.  Thread -> fixed 8-channel chunk.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const half_t* __restrict__ x0, int C0,
+                                                               const half_t* __restrict__ x1, int C1, int HW,
+                                                               int groups, int pix_per_split, float* __restrict__ ws) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float* part = reinterpret_cast<float*>(smem_raw);          // [rows_per_iter][C][2]
+    const int C = C0 + C1, nchunk = C >> 3;
+    const int rpi = GN_THREADS / nchunk;
+    const int tid = threadIdx.x;
+    const int chunk = tid % nchunk, rsub = tid / nchunk;
+    const int b = blockIdx.y, sp = blockIdx.x, nsplit = gridDim.x;
+    const int p_begin = sp * pix_per_split;
+    const int p_end = min(HW, p_begin + pix_per_split);
+    float s[8], q[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
+    if (rsub < rpi) {
+        const int ch = chunk * 8;
+        const bool first = ch < C0;
+        const half_t* base = first ? x0 + (long long)b * HW * C0 + ch : x1 + (long long)b * HW * C1 + (ch - C0);
+        const int cs = first ? C0 : C1;
+        for (int p = p_begin + rsub; p < p_end; p += rpi) {
+            f16x8 v = *reinterpret_cast<const f16x8*>(base + (long long)p * cs);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float f = (float)v[e]; s[e] += f; q[e] += f * f; }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            part[((rsub * C) + ch + e) * 2 + 0] = s[e];
+            part[((rsub * C) + ch + e) * 2 + 1] = q[e];
+        }
+    }
+    __syncthreads();
+    if (tid < groups) {
+        const int cpg = C / groups;
+        float ss = 0.f, qq = 0.f;
+        for (int r = 0; r < rpi; ++r)
+            for (int c = 0; c < cpg; ++c) {
+                ss += part[((r * C) + tid * cpg + c) * 2 + 0];
+                qq += part[((r * C) + tid * cpg + c) * 2 + 1];
+            }
+        float* o = ws + (((long long)b * nsplit + sp) * groups + tid) * 2;
+        o[0] = ss; o[1] = qq;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// GroupNorm pass 2: finish the statistics (fixed order), normalise, affine, optional SiLU, write one NHWC tensor.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const half_t* __restrict__ x0, int C0,
+                                                               const half_t* __restrict__ x1, int C1, int HW,
+                                                               int groups, int nsplit, int pix_per_block,
+                                                               const float* __restrict__ ws,
+                                                               const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, float eps, int silu,
+                                                               half_t* __restrict__ out) {
+    __shared__ float s_mean[64], s_rstd[64];
+    const int C = C0 + C1, nchunk = C >> 3;
+    const int rpi = GN_THREADS / nchunk;
+    const int tid = threadIdx.x, b = blockIdx.y;
+    if (tid < groups) {
+        float ss = 0.f, qq = 0.f;
+        for (int sp = 0; sp < nsplit; ++sp) {
+            const float* o = ws + (((long long)b * nsplit + sp) * groups + tid) * 2;
+            ss += o[0]; qq += o[1];
+        }
+        const float n = (float)HW * (float)(C / groups);
+        const float mean = ss / n;
+        const float var = fmaxf(qq / n - mean * mean, 0.f);
+        s_mean[tid] = mean;
+        s_rstd[tid] = rsqrtf(var + eps);
+    }
+    __syncthreads();
+    const int chunk = tid % nchunk, rsub = tid / nchunk;
+    if (rsub >= rpi) return;
+    const int ch = chunk * 8, cpg = C / groups;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int g = (ch + e) / cpg;
+        sc[e] = s_rstd[g] * gamma[ch + e];
+        sh[e] = beta[ch + e] - s_mean[g] * sc[e];
+    }
+    const bool first = ch < C0;
+    const half_t* base = first ? x0 + (long long)b * HW * C0 + ch : x1 + (long long)b * HW * C1 + (ch - C0);
+    const int cs = first ? C0 : C1;
+    half_t* ob = out + (long long)b * HW * C + ch;
+    const int p_begin = blockIdx.x * pix_per_block;
+    const int p_end = min(HW, p_begin + pix_per_block);
+    for (int p = p_begin + rsub; p < p_end; p += rpi) {
+        f16x8 v = *reinterpret_cast<const f16x8*>(base + (long long)p * cs);
+        f16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float f = (float)v[e] * sc[e] + sh[e];
+            if (silu) f = silu_f(f);
+            o[e] = (half_t)f;
+        }
+        *reinterpret_cast<f16x8*>(ob + (long long)p * C) = o;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// LayerNorm: one wave per token row, row kept in registers (C <= 2048), exact two-pass mean / variance.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void layernorm_kernel(const half_t* __restrict__ x, long long rows, int C,
+                                                         const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, float eps,
+                                                         half_t* __restrict__ out) {
+    const int l = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nchunk = C >> 3;
+    const half_t* xr = x + row * C;
+    f16x8 v[4];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = l + i * 64;
+        if (c < nchunk) {
+            v[i] = *reinterpret_cast<const f16x8*>(xr + c * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sum += (float)v[i][e];
+        }
+    }
+    const float mean = wave_sum(sum) / (float)C;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = l + i * 64;
+        if (c < nchunk) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = (float)v[i][e] - mean; sq += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(sq) / (float)C + eps);
+    half_t* orow = out + row * C;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = l + i * 64;
+        if (c < nchunk) {
+            f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + c * 8), g1 = *reinterpret_cast<const f32x4*>(gamma + c * 8 + 4);
+            f32x4 b0 = *reinterpret_cast<const f32x4*>(beta + c * 8), b1 = *reinterpret_cast<const f32x4*>(beta + c * 8 + 4);
+            f16x8 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                o[e] = (half_t)(((float)v[i][e] - mean) * rstd * g0[e] + b0[e]);
+                o[4 + e] = (half_t)(((float)v[i][4 + e] - mean) * rstd * g1[e] + b1[e]);
+            }
+            *reinterpret_cast<f16x8*>(orow + c * 8) = o;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Row softmax for the materialised-P path: fp32 scores -> fp16 probabilities, pad columns zeroed. One wave / row.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ s, long long rows, int cols,
+                                                            int ld_s, float scale, half_t* __restrict__ p, int ld_p) {
+    const int l = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* sr = s + row * ld_s;
+    float mx = -INFINITY;
+    for (int c = l; c < cols; c += 64) mx = fmaxf(mx, sr[c]);
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int c = l; c < cols; c += 64) sum += __expf((sr[c] - mx) * scale);
+    const float inv = 1.0f / wave_sum(sum);
+    half_t* pr = p + row * ld_p;
+    for (int c = l; c < ld_p; c += 64) pr[c] = c < cols ? (half_t)(__expf((sr[c] - mx) * scale) * inv) : (half_t)0.f;
+}
+
+}  // namespace
+
+extern "C" int64_t icd_groupnorm_ws_floats(int32_t B, int32_t HW, int32_t groups) {
+    const int pps = gn_pix_per_split(HW);
+    const int nsplit = (HW + pps - 1) / pps;
+    return (int64_t)B * nsplit * groups * 2;
+}
+
+extern "C" int icd_groupnorm(const void* x0, int32_t C0, const void* x1, int32_t C1, int32_t B, int32_t HW,
+                             int32_t groups, const float* gamma, const float* beta, float eps, int32_t silu,
+                             void* out, float* stats_ws, void* stream) {
+    ICD_CHECK_ARG(x0 && out && stats_ws && gamma && beta, "icd_groupnorm: null pointer");
+    const int C = C0 + C1;
+    ICD_CHECK_ARG(C0 > 0 && C0 % 8 == 0 && C1 >= 0 && C1 % 8 == 0, "icd_groupnorm: channels must be multiples of 8");
+    ICD_CHECK_ARG((C1 == 0) == (x1 == nullptr), "icd_groupnorm: x1/C1 mismatch");
+    ICD_CHECK_ARG(groups > 0 && groups <= 64 && C % groups == 0, "icd_groupnorm: bad group count %d for C=%d", groups, C);
+    ICD_CHECK_ARG(C / 8 <= GN_THREADS, "icd_groupnorm: C=%d too large", C);
+    ICD_CHECK_ARG(B > 0 && HW > 0, "icd_groupnorm: empty input");
+    const int pps = gn_pix_per_split(HW);
+    const int nsplit = (HW + pps - 1) / pps;
+    const int rpi = GN_THREADS / (C / 8);
+    const size_t smem = (size_t)rpi * C * 2 * sizeof(float);
+    ICD_CHECK_ARG(smem <= 64 * 1024, "icd_groupnorm: LDS budget exceeded");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(nsplit, B), dim3(GN_THREADS), smem, st, (const half_t*)x0, C0,
+                       (const half_t*)x1, C1, HW, groups, pps, stats_ws);
+    ICD_CHECK_LAUNCH("icd_groupnorm(stats)");
+    const int ppb = HW >= 4096 ? 128 : 64;
+    hipLaunchKernelGGL(gn_apply_kernel, dim3((HW + ppb - 1) / ppb, B), dim3(GN_THREADS), 0, st, (const half_t*)x0, C0,
+                       (const half_t*)x1, C1, HW, groups, nsplit, ppb, stats_ws, gamma, beta, eps, silu, (half_t*)out);
+    ICD_CHECK_LAUNCH("icd_groupnorm(apply)");
+    return ICD_OK;
+}
+
+extern "C" int icd_layernorm(const void* x, int64_t rows, int32_t C, const float* gamma, const float* beta, float eps,
+                             void* out, void* stream) {
+    ICD_CHECK_ARG(x && out && gamma && beta, "icd_layernorm: null pointer");
+    ICD_CHECK_ARG(C > 0 && C % 8 == 0 && C <= 2048, "icd_layernorm: C must be a multiple of 8 and <= 2048 (got %d)", C);
+    ICD_CHECK_ARG(rows > 0, "icd_layernorm: empty input");
+    hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       (const half_t*)x, (long long)rows, C, gamma, beta, eps, (half_t*)out);
+    ICD_CHECK_LAUNCH("icd_layernorm");
+    return ICD_OK;
+}
+
+extern "C" int icd_softmax_rows(const float* s, int64_t rows, int32_t cols, int32_t ld_s, float scale, void* p,
+                                int32_t ld_p, void* stream) {
+    ICD_CHECK_ARG(s && p, "icd_softmax_rows: null pointer");
+    ICD_CHECK_ARG(rows > 0 && cols > 0 && ld_s >= cols && ld_p >= cols, "icd_softmax_rows: bad shape");
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, s,
+                       (long long)rows, cols, ld_s, scale, (half_t*)p, ld_p);
+    ICD_CHECK_LAUNCH("icd_softmax_rows");
+    return ICD_OK;
+}

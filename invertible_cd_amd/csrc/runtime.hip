@@ -1,0 +1,540 @@
+// runtime.hip - native executor of one UNet2DConditionModel evaluation (SD1.5 / SDXL topologies) on gfx950.
+//
+// This is the body of the reference's `model.unet(...)` / `pipe.unet(...)` call (utils/generation.py:241-244,
+// utils/generation_sdxl.py:445-453) rebuilt as: a host-side walk of the architecture that bump-allocates activations
+// from a caller-owned arena and enqueues the HIP kernels of this library on ONE stream - no per-op Python, no host
+// synchronisation (the reference syncs at t.item() every step).  The p2p plugin (utils/p2p.py:291-386) is served by a C
+// callback invoked in module-execution order between the probability kernel and the P.V kernel.
+//
+// Layout: activations fp16 token-major [B, H*W, C]; skip concat is folded into the consumers' loaders (never
+// materialised); V is produced transposed by the to_v GEMM epilogue; all ResnetBlock2D time projections are ONE GEMM.
+#include <string>
+#include <unordered_map>
+#include <vector>
+#include <algorithm>
+#include <string.h>
+#include "common.h"
+
+namespace {
+
+struct Tensor { const void* ptr; int dtype; long long numel; };
+
+struct Arena {
+    char* base = nullptr;
+    long long cap = 0, peak = 0;
+    bool dry = false;
+    struct Blk { long long off, size; };
+    std::vector<Blk> free_list;   // sorted by offset
+    std::vector<Blk> live;
+    void reset(void* b, long long c, bool d) {
+        base = (char*)b; cap = c; dry = d; peak = 0;
+        free_list.clear(); live.clear();
+        free_list.push_back({0, d ? (1LL << 60) : c});
+    }
+    void* alloc(long long bytes) {
+        bytes = (bytes + 255) & ~255LL;
+        if (bytes == 0) bytes = 256;
+        for (size_t i = 0; i < free_list.size(); ++i) {
+            if (free_list[i].size >= bytes) {
+                const long long off = free_list[i].off;
+                free_list[i].off += bytes; free_list[i].size -= bytes;
+                if (free_list[i].size == 0) free_list.erase(free_list.begin() + i);
+                live.push_back({off, bytes});
+                peak = std::max(peak, off + bytes);
+                return (dry ? (char*)0x100000 : base) + off;
+            }
+        }
+        return nullptr;
+    }
+    void release(void* p) {
+        if (!p) return;
+        const long long off = (char*)p - (dry ? (char*)0x100000 : base);
+        for (size_t i = 0; i < live.size(); ++i)
+            if (live[i].off == off) {
+                Blk b = live[i];
+                live.erase(live.begin() + i);
+                auto it = std::lower_bound(free_list.begin(), free_list.end(), b,
+                                           [](const Blk& x, const Blk& y) { return x.off < y.off; });
+                it = free_list.insert(it, b);
+                if (it + 1 != free_list.end() && it->off + it->size == (it + 1)->off) {
+                    it->size += (it + 1)->size; free_list.erase(it + 1);
+                }
+                if (it != free_list.begin() && (it - 1)->off + (it - 1)->size == it->off) {
+                    (it - 1)->size += it->size; free_list.erase(it);
+                }
+                return;
+            }
+    }
+};
+
+}  // namespace
+
+struct icd_unet {
+    icd_unet_config cfg;
+    std::unordered_map<std::string, Tensor> tensors;
+    bool finalized = false;
+    int n_attn = 0;
+    int temb_total = 0;
+};
+
+namespace {
+
+struct Act { half_t* p; int C; };          // token-major activation [B*HW, C]
+
+struct Exec {
+    icd_unet* u;
+    const icd_unet_io* io;
+    hipStream_t st;
+    Arena ar;
+    bool dry;
+    int probs_mode;                          // dry-run materialisation rule (0 none, 1 shipped controllers, 2 all)
+    std::vector<std::string>* missing;       // finalize(): collect missing tensor names
+    int B, H0, W0, nctx;
+    int layer = 0;
+    float* gn_ws = nullptr;
+    half_t* temb_all = nullptr;
+    int temb_off = 0;
+    int status = ICD_OK;
+
+    const void* T(const std::string& name, int dtype, long long numel) {
+        auto it = u->tensors.find(name);
+        if (it == u->tensors.end()) {
+            if (missing) { missing->push_back(name); return (const void*)0x1000; }
+            icd_set_error("icd_unet_forward: tensor '%s' is not bound", name.c_str());
+            status = ICD_ERR_MISSING_TENSOR;
+            return nullptr;
+        }
+        if (it->second.dtype != dtype || it->second.numel != numel) {
+            icd_set_error("tensor '%s': expected dtype %d numel %lld, bound dtype %d numel %lld", name.c_str(), dtype, numel,
+                          it->second.dtype, it->second.numel);
+            status = ICD_ERR_INVALID_ARG;
+            return nullptr;
+        }
+        return it->second.ptr;
+    }
+    const half_t* Wh(const std::string& n, long long numel) { return (const half_t*)T(n, 0, numel); }
+    const float* Wf(const std::string& n, long long numel) { return (const float*)T(n, 1, numel); }
+
+    template <typename TT> TT* alloc(long long elems) {
+        void* p = ar.alloc(elems * (long long)sizeof(TT));
+        if (!p && status == ICD_OK) {
+            icd_set_error("icd_unet_forward: workspace too small (%lld bytes given); query icd_unet_workspace_bytes", ar.cap);
+            status = ICD_ERR_WORKSPACE;
+        }
+        return (TT*)p;
+    }
+    void release(void* p) { ar.release(p); }
+    bool ok() const { return status == ICD_OK; }
+    void run(int rc) { if (rc != ICD_OK && status == ICD_OK) status = rc; }
+
+    // ---------------------------------------------------------------------------------------------- op wrappers
+    void gemm_desc(icd_gemm_desc& d) {
+        if (!ok() || dry) return;
+        run(icd_gemm(&d, st));
+    }
+    // dense: out[M,N] (ldo) = a[M,K](lda) @ w[N,K]^T + bias + resid
+    void linear(const half_t* a, int lda, int M, int K, const half_t* w, int N, const float* bias, const half_t* resid,
+                int ldr, half_t* out, int ldo, int flags = 0, int rps = 0) {
+        icd_gemm_desc d; memset(&d, 0, sizeof(d));
+        d.a0 = a; d.w = w; d.bias = bias; d.resid = resid; d.out = out;
+        d.M = M; d.N = N; d.K = K; d.Nw = N; d.lda = lda; d.ldw = K; d.ldo = ldo; d.ldr = ldr;
+        d.rows_per_sample = rps; d.mode = 0; d.batch = 1; d.zdiv = 1; d.alpha = 1.f; d.flags = flags;
+        gemm_desc(d);
+    }
+    void conv(const Act& x0, const Act* x1, int Hin, int Win, int ksize, int stride, int upsample, const half_t* w, int Cout,
+              const float* bias, const half_t* rowbias, int ld_rowbias, const half_t* resid, half_t* out) {
+        icd_gemm_desc d; memset(&d, 0, sizeof(d));
+        const int Hu = Hin << upsample, Wu = Win << upsample;
+        const int Ho = (Hu + stride - 1) / stride, Wo = (Wu + stride - 1) / stride;
+        d.a0 = x0.p; d.a1 = x1 ? x1->p : nullptr; d.w = w; d.bias = bias; d.rowbias = rowbias; d.resid = resid; d.out = out;
+        d.C0 = x0.C; d.C1 = x1 ? x1->C : 0;
+        d.M = B * Ho * Wo; d.N = Cout; d.K = ksize * ksize * (d.C0 + d.C1); d.Nw = Cout;
+        d.ldw = d.K; d.ldo = Cout; d.ldr = Cout; d.ld_rowbias = ld_rowbias; d.rows_per_sample = Ho * Wo;
+        d.mode = 1; d.Hin = Hin; d.Win = Win; d.Hout = Ho; d.Wout = Wo; d.ksize = ksize; d.stride = stride; d.upsample = upsample;
+        d.batch = 1; d.zdiv = 1; d.alpha = 1.f;
+        gemm_desc(d);
+    }
+    void groupnorm(const Act& x0, const Act* x1, int HW, const float* g, const float* b, float eps, int silu, half_t* out) {
+        if (!ok() || dry) return;
+        run(icd_groupnorm(x0.p, x0.C, x1 ? x1->p : nullptr, x1 ? x1->C : 0, B, HW, u->cfg.norm_groups, g, b, eps, silu, out, gn_ws, st));
+    }
+    void layernorm(const half_t* x, long long rows, int C, const float* g, const float* b, half_t* out) {
+        if (!ok() || dry) return;
+        run(icd_layernorm(x, rows, C, g, b, 1e-5f, out, st));
+    }
+
+    // ---------------------------------------------------------------------------------------------- blocks
+    Act resnet(const std::string& p, const Act& x0, const Act* x1, int Hh, int Ww, int Cout) {
+        const int HW = Hh * Ww, Cin = x0.C + (x1 ? x1->C : 0);
+        const long long M = (long long)B * HW;
+        half_t* n1 = alloc<half_t>(M * Cin);
+        groupnorm(x0, x1, HW, Wf(p + ".norm1.weight", Cin), Wf(p + ".norm1.bias", Cin), 1e-5f, 1, n1);
+        half_t* h1 = alloc<half_t>(M * Cout);
+        Act n1a{n1, Cin};
+        conv(n1a, nullptr, Hh, Ww, 3, 1, 0, Wh(p + ".conv1.weight", 9LL * Cin * Cout), Cout, Wf(p + ".conv1.bias", Cout),
+             temb_all + temb_off, u->temb_total, nullptr, h1);
+        temb_off += Cout;
+        release(n1);
+        half_t* n2 = alloc<half_t>(M * Cout);
+        Act h1a{h1, Cout};
+        groupnorm(h1a, nullptr, HW, Wf(p + ".norm2.weight", Cout), Wf(p + ".norm2.bias", Cout), 1e-5f, 1, n2);
+        release(h1);
+        const half_t* resid = x0.p;
+        half_t* sc = nullptr;
+        if (Cin != Cout) {
+            sc = alloc<half_t>(M * Cout);
+            conv(x0, x1, Hh, Ww, 1, 1, 0, Wh(p + ".conv_shortcut.weight", (long long)Cin * Cout), Cout,
+                 Wf(p + ".conv_shortcut.bias", Cout), nullptr, 0, nullptr, sc);
+            resid = sc;
+        }
+        half_t* out = alloc<half_t>(M * Cout);
+        Act n2a{n2, Cout};
+        conv(n2a, nullptr, Hh, Ww, 3, 1, 0, Wh(p + ".conv2.weight", 9LL * Cout * Cout), Cout, Wf(p + ".conv2.bias", Cout),
+             nullptr, 0, resid, out);
+        release(n2);
+        release(sc);
+        return Act{out, Cout};
+    }
+
+    // one attention module: q [B*Nq, ldq] (head h at col h*d), k [B*Nk, ldk], vt [B, C, ldv]; out [B*Nq, C]
+    void attention(bool is_cross, int place, const half_t* q, int ldq, const half_t* k, int ldk, const half_t* vt, int ldv,
+                   int heads, int Nq, int Nk, int d, half_t* out, int C) {
+        const int my_layer = layer++;
+        const long long ldp = (Nk + 7) / 8 * 8;
+        const float scale = 1.0f / sqrtf((float)d);
+        bool mat = false;
+        void* probs = nullptr;
+        if (dry) mat = probs_mode == 2 || (probs_mode == 1 && (is_cross || Nq <= 1024));
+        else if (io->hook && ok()) {
+            const int r = io->hook(io->hook_user, ICD_HOOK_QUERY, my_layer, is_cross, place, (long long)B * heads, Nq, Nk, ldp, &probs);
+            if (r < 0) { icd_set_error("attention hook (query) failed at layer %d", my_layer); status = ICD_ERR_HOOK; return; }
+            mat = r == 1;
+            if (mat && !probs) { icd_set_error("attention hook returned 1 without a probability buffer (layer %d)", my_layer); status = ICD_ERR_HOOK; return; }
+        }
+        if (!mat) {
+            if (ok() && !dry) run(icd_attention_fused(q, k, vt, out, B, heads, Nq, Nk, d, ldq, ldk, ldv, C, scale, st));
+            return;
+        }
+        // materialised path (utils/p2p.py:335-338): S = scale q.k^T (fp32) -> softmax -> P (fp16) -> hook -> P.V
+        const long long per_b = (long long)heads * Nq * ldp;            // fp32 elements of S per sample
+        int nb = (int)std::max<long long>(1, (1LL << 28) / per_b);      // <= 1 GiB of fp32 scores at a time
+        nb = std::min(nb, B);
+        float* S = alloc<float>(per_b * nb);
+        for (int b0 = 0; b0 < B && ok(); b0 += nb) {
+            const int cb = std::min(nb, B - b0);
+            icd_gemm_desc g; memset(&g, 0, sizeof(g));
+            g.a0 = q + (long long)b0 * Nq * ldq; g.w = k + (long long)b0 * Nk * ldk; g.out = S;
+            g.M = Nq; g.N = (int)ldp; g.K = d; g.Nw = Nk; g.lda = ldq; g.ldw = ldk; g.ldo = (int)ldp;
+            g.mode = 0; g.batch = cb * heads; g.zdiv = heads;
+            g.a_bs0 = (long long)Nq * ldq; g.a_bs1 = d; g.w_bs0 = (long long)Nk * ldk; g.w_bs1 = d;
+            g.o_bs0 = per_b; g.o_bs1 = (long long)Nq * ldp;
+            g.alpha = scale; g.flags = ICD_GEMM_OUT_F32;
+            gemm_desc(g);
+            if (ok() && !dry)
+                run(icd_softmax_rows(S, (long long)cb * heads * Nq, Nk, (int)ldp, 1.0f, (half_t*)probs + (long long)b0 * per_b, (int)ldp, st));
+        }
+        release(S);
+        if (!dry && ok()) {
+            const int r = io->hook(io->hook_user, ICD_HOOK_PROBS, my_layer, is_cross, place, (long long)B * heads, Nq, Nk, ldp, &probs);
+            if (r < 0) { icd_set_error("attention hook (probs) failed at layer %d", my_layer); status = ICD_ERR_HOOK; return; }
+        }
+        icd_gemm_desc g; memset(&g, 0, sizeof(g));
+        g.a0 = probs; g.w = vt; g.out = out;
+        g.M = Nq; g.N = d; g.K = (int)ldp; g.Nw = d; g.lda = (int)ldp; g.ldw = ldv; g.ldo = C;
+        g.mode = 0; g.batch = B * heads; g.zdiv = heads;
+        g.a_bs0 = per_b; g.a_bs1 = (long long)Nq * ldp; g.w_bs0 = (long long)C * ldv; g.w_bs1 = (long long)d * ldv;
+        g.o_bs0 = (long long)Nq * C; g.o_bs1 = d;
+        g.alpha = 1.f;
+        gemm_desc(g);
+    }
+
+    Act transformer(const std::string& p, const Act& x, int Hh, int Ww, int depth, int heads, int place) {
+        const int HW = Hh * Ww, C = x.C, d = C / heads, X = u->cfg.cross_dim;
+        const long long M = (long long)B * HW;
+        const int Mc = B * nctx;
+        const int ldv_self = (HW + 7) / 8 * 8, ldv_cross = (nctx + 7) / 8 * 8;
+        half_t* n = alloc<half_t>(M * C);
+        groupnorm(x, nullptr, HW, Wf(p + ".norm.weight", C), Wf(p + ".norm.bias", C), 1e-6f, 0, n);
+        half_t* h = alloc<half_t>(M * C);
+        linear(n, C, (int)M, C, Wh(p + ".proj_in.weight", (long long)C * C), C, Wf(p + ".proj_in.bias", C), nullptr, 0, h, C);
+        release(n);
+        for (int kb = 0; kb < depth && ok(); ++kb) {
+            const std::string b = p + ".transformer_blocks." + std::to_string(kb);
+            // ---- self attention ----
+            half_t* ln = alloc<half_t>(M * C);
+            layernorm(h, M, C, Wf(b + ".norm1.weight", C), Wf(b + ".norm1.bias", C), ln);
+            half_t* qk = alloc<half_t>(M * 2 * C);
+            linear(ln, C, (int)M, C, Wh(b + ".attn1.to_qk.weight", 2LL * C * C), 2 * C, nullptr, nullptr, 0, qk, 2 * C);
+            half_t* vt = alloc<half_t>((long long)B * C * ldv_self);
+            linear(ln, C, (int)M, C, Wh(b + ".attn1.to_v.weight", (long long)C * C), C, nullptr, nullptr, 0, vt, ldv_self,
+                   ICD_GEMM_OUT_TRANS, HW);
+            half_t* ao = ln;     // ln is dead once q/k/v^T are enqueued: reuse it for the attention output
+            attention(false, place, qk, 2 * C, qk + C, 2 * C, vt, ldv_self, heads, HW, HW, d, ao, C);
+            release(qk); release(vt);
+            linear(ao, C, (int)M, C, Wh(b + ".attn1.to_out.0.weight", (long long)C * C), C, Wf(b + ".attn1.to_out.0.bias", C), h, C, h, C);
+            // ---- cross attention ----
+            layernorm(h, M, C, Wf(b + ".norm2.weight", C), Wf(b + ".norm2.bias", C), ln);
+            half_t* q2 = alloc<half_t>(M * C);
+            linear(ln, C, (int)M, C, Wh(b + ".attn2.to_q.weight", (long long)C * C), C, nullptr, nullptr, 0, q2, C);
+            half_t* k2 = alloc<half_t>((long long)Mc * C);
+            linear((const half_t*)io->context, X, Mc, X, Wh(b + ".attn2.to_k.weight", (long long)C * X), C, nullptr, nullptr, 0, k2, C);
+            half_t* vt2 = alloc<half_t>((long long)B * C * ldv_cross);
+            linear((const half_t*)io->context, X, Mc, X, Wh(b + ".attn2.to_v.weight", (long long)C * X), C, nullptr, nullptr, 0, vt2,
+                   ldv_cross, ICD_GEMM_OUT_TRANS, nctx);
+            attention(true, place, q2, C, k2, C, vt2, ldv_cross, heads, HW, nctx, d, ln, C);
+            release(q2); release(k2); release(vt2);
+            linear(ln, C, (int)M, C, Wh(b + ".attn2.to_out.0.weight", (long long)C * C), C, Wf(b + ".attn2.to_out.0.bias", C), h, C, h, C);
+            // ---- GEGLU feed-forward ----
+            layernorm(h, M, C, Wf(b + ".norm3.weight", C), Wf(b + ".norm3.bias", C), ln);
+            half_t* ff = alloc<half_t>(M * 4 * C);
+            linear(ln, C, (int)M, C, Wh(b + ".ff.net.0.proj.weight", 8LL * C * C), 8 * C, Wf(b + ".ff.net.0.proj.bias", 8 * C), nullptr, 0,
+                   ff, 4 * C, ICD_GEMM_GEGLU);
+            release(ln);
+            linear(ff, 4 * C, (int)M, 4 * C, Wh(b + ".ff.net.2.weight", 4LL * C * C), C, Wf(b + ".ff.net.2.bias", C), h, C, h, C);
+            release(ff);
+        }
+        half_t* out = alloc<half_t>(M * C);
+        linear(h, C, (int)M, C, Wh(p + ".proj_out.weight", (long long)C * C), C, Wf(p + ".proj_out.bias", C), x.p, C, out, C);
+        release(h);
+        return Act{out, C};
+    }
+
+    int forward() {
+        const icd_unet_config& c = u->cfg;
+        const int L = c.num_levels, ch0 = c.block_out_channels[0], temb = ch0 * 4;
+        const int HW0 = H0 * W0;
+        gn_ws = alloc<float>(icd_groupnorm_ws_floats(B, HW0, c.norm_groups));
+        // ---------------- time embedding: Timesteps -> (+cond_proj) -> Linear -> SiLU -> Linear (+ SDXL add_embedding)
+        half_t* tsin = alloc<half_t>((long long)B * ch0);
+        if (ok() && !dry) run(icd_sinusoid(io->timesteps, B, ch0, 0, tsin, st));
+        half_t* tin = tsin;
+        if (c.time_cond_proj_dim > 0 && (dry ? true : io->timestep_cond != nullptr)) {
+            tin = alloc<half_t>((long long)B * ch0);
+            linear((const half_t*)io->timestep_cond, c.time_cond_proj_dim, B, c.time_cond_proj_dim,
+                   Wh("time_embedding.cond_proj.weight", (long long)ch0 * c.time_cond_proj_dim), ch0, nullptr, tsin, ch0, tin, ch0);
+        }
+        half_t* e1 = alloc<half_t>((long long)B * temb);
+        linear(tin, ch0, B, ch0, Wh("time_embedding.linear_1.weight", (long long)temb * ch0), temb, Wf("time_embedding.linear_1.bias", temb),
+               nullptr, 0, e1, temb);
+        if (ok() && !dry) run(icd_silu(e1, (long long)B * temb, e1, st));
+        half_t* emb = alloc<half_t>((long long)B * temb);
+        linear(e1, temb, B, temb, Wh("time_embedding.linear_2.weight", (long long)temb * temb), temb, Wf("time_embedding.linear_2.bias", temb),
+               nullptr, 0, emb, temb);
+        if (c.add_in_dim > 0) {
+            const int tdim = c.addition_time_embed_dim, pooled = c.add_in_dim - 6 * tdim;
+            half_t* tid = alloc<half_t>((long long)B * 6 * tdim);
+            if (ok() && !dry) {
+                if (!io->time_ids || !io->text_embeds) { icd_set_error("SDXL forward needs text_embeds and time_ids"); return ICD_ERR_INVALID_ARG; }
+                run(icd_sinusoid(io->time_ids, B * 6, tdim, 0, tid, st));
+            }
+            half_t* a1 = alloc<half_t>((long long)B * temb);
+            // Linear over cat([text_embeds, time_embeds]) without materialising the concat: 1x1 "conv" with two sources
+            Act s0{(half_t*)io->text_embeds, pooled}, s1{tid, 6 * tdim};
+            const int saveB = B;
+            {
+                icd_gemm_desc d; memset(&d, 0, sizeof(d));
+                d.a0 = s0.p; d.a1 = s1.p; d.w = Wh("add_embedding.linear_1.weight", (long long)temb * c.add_in_dim);
+                d.bias = Wf("add_embedding.linear_1.bias", temb); d.out = a1;
+                d.C0 = s0.C; d.C1 = s1.C; d.M = saveB; d.N = temb; d.K = c.add_in_dim; d.Nw = temb; d.ldw = d.K; d.ldo = temb;
+                d.rows_per_sample = 1; d.mode = 1; d.Hin = d.Win = d.Hout = d.Wout = 1; d.ksize = 1; d.stride = 1; d.batch = 1; d.zdiv = 1; d.alpha = 1.f;
+                gemm_desc(d);
+            }
+            if (ok() && !dry) run(icd_silu(a1, (long long)B * temb, a1, st));
+            linear(a1, temb, B, temb, Wh("add_embedding.linear_2.weight", (long long)temb * temb), temb, Wf("add_embedding.linear_2.bias", temb),
+                   emb, temb, emb, temb);
+            release(a1); release(tid);
+        }
+        if (ok() && !dry) run(icd_silu(emb, (long long)B * temb, e1, st));      // e1 := SiLU(emb), shared by every resnet
+        temb_all = alloc<half_t>((long long)B * u->temb_total);
+        linear(e1, temb, B, temb, Wh("time_emb_proj_cat.weight", (long long)u->temb_total * temb), u->temb_total,
+               Wf("time_emb_proj_cat.bias", u->temb_total), nullptr, 0, temb_all, u->temb_total);
+        temb_off = 0;
+        release(e1); release(emb); if (tin != tsin) release(tin); release(tsin);
+
+        // ---------------- conv_in
+        std::vector<Act> skips;
+        std::vector<int> skipH;
+        Act h{alloc<half_t>((long long)B * HW0 * ch0), ch0};
+        if (ok() && !dry)
+            run(icd_conv_in(io->sample, io->sample_is_f32, B, H0, W0, Wh("conv_in.weight", 36LL * ch0), Wf("conv_in.bias", ch0), ch0, h.p, st));
+        else { Wh("conv_in.weight", 36LL * ch0); Wf("conv_in.bias", ch0); }
+        skips.push_back(h);
+        int Hh = H0, Ww = W0;
+        // ---------------- down
+        for (int i = 0; i < L && ok(); ++i) {
+            const int Cout = c.block_out_channels[i];
+            for (int j = 0; j < c.layers_per_block && ok(); ++j) {
+                const std::string rp = "down_blocks." + std::to_string(i) + ".resnets." + std::to_string(j);
+                Act r = resnet(rp, h, nullptr, Hh, Ww, Cout);
+                // h stays alive: it is on the skip stack
+                h = r;
+                if (c.down_has_attn[i]) {
+                    Act t = transformer("down_blocks." + std::to_string(i) + ".attentions." + std::to_string(j), h, Hh, Ww,
+                                        c.transformer_layers[i], c.num_heads[i], 0);
+                    release(h.p);
+                    h = t;
+                }
+                skips.push_back(h);
+            }
+            if (i < L - 1) {
+                const std::string dp = "down_blocks." + std::to_string(i) + ".downsamplers.0.conv";
+                Act dn{alloc<half_t>((long long)B * (Hh / 2) * (Ww / 2) * Cout), Cout};
+                conv(h, nullptr, Hh, Ww, 3, 2, 0, Wh(dp + ".weight", 9LL * Cout * Cout), Cout, Wf(dp + ".bias", Cout), nullptr, 0, nullptr, dn.p);
+                Hh /= 2; Ww /= 2;
+                h = dn;
+                skips.push_back(h);
+            }
+        }
+        // ---------------- mid
+        {
+            const int Cm = c.block_out_channels[L - 1];
+            Act r0 = resnet("mid_block.resnets.0", h, nullptr, Hh, Ww, Cm);     // h is the last skip: stays alive
+            Act t = transformer("mid_block.attentions.0", r0, Hh, Ww, c.transformer_layers[L - 1], c.num_heads[L - 1], 1);
+            release(r0.p);
+            Act r1 = resnet("mid_block.resnets.1", t, nullptr, Hh, Ww, Cm);
+            release(t.p);
+            h = r1;
+        }
+        // ---------------- up
+        for (int i = 0; i < L && ok(); ++i) {
+            const int lvl = L - 1 - i;
+            const int Cout = c.block_out_channels[lvl];
+            for (int j = 0; j < c.layers_per_block + 1 && ok(); ++j) {
+                Act sk = skips.back(); skips.pop_back();
+                const std::string rp = "up_blocks." + std::to_string(i) + ".resnets." + std::to_string(j);
+                Act r = resnet(rp, h, &sk, Hh, Ww, Cout);
+                release(h.p); release(sk.p);
+                h = r;
+                if (c.up_has_attn[i]) {
+                    Act t = transformer("up_blocks." + std::to_string(i) + ".attentions." + std::to_string(j), h, Hh, Ww,
+                                        c.transformer_layers[lvl], c.num_heads[lvl], 2);
+                    release(h.p);
+                    h = t;
+                }
+            }
+            if (i < L - 1) {
+                const std::string upn = "up_blocks." + std::to_string(i) + ".upsamplers.0.conv";
+                Act up{alloc<half_t>((long long)B * (Hh * 2) * (Ww * 2) * Cout), Cout};
+                conv(h, nullptr, Hh, Ww, 3, 1, 1, Wh(upn + ".weight", 9LL * Cout * Cout), Cout, Wf(upn + ".bias", Cout), nullptr, 0, nullptr, up.p);
+                release(h.p);
+                Hh *= 2; Ww *= 2;
+                h = up;
+            }
+        }
+        // ---------------- out
+        half_t* n = alloc<half_t>((long long)B * HW0 * ch0);
+        groupnorm(h, nullptr, HW0, Wf("conv_norm_out.weight", ch0), Wf("conv_norm_out.bias", ch0), 1e-5f, 1, n);
+        release(h.p);
+        const half_t* wo = Wh("conv_out.weight", 9LL * ch0 * c.out_channels);
+        const float* bo = Wf("conv_out.bias", c.out_channels);
+        if (ok() && !dry) run(icd_conv_out(n, B, H0, W0, ch0, wo, bo, io->eps, io->sample_is_f32, st));
+        release(n);
+        release(temb_all);
+        return status;
+    }
+};
+
+int count_attn(const icd_unet_config& c) {
+    int n = 0;
+    const int L = c.num_levels;
+    for (int i = 0; i < L; ++i) if (c.down_has_attn[i]) n += c.layers_per_block * c.transformer_layers[i] * 2;
+    n += c.transformer_layers[L - 1] * 2;
+    for (int i = 0; i < L; ++i) if (c.up_has_attn[i]) n += (c.layers_per_block + 1) * c.transformer_layers[L - 1 - i] * 2;
+    return n;
+}
+
+int temb_total(const icd_unet_config& c) {
+    int t = 0;
+    const int L = c.num_levels;
+    for (int i = 0; i < L; ++i) t += c.layers_per_block * c.block_out_channels[i];
+    t += 2 * c.block_out_channels[L - 1];
+    for (int i = 0; i < L; ++i) t += (c.layers_per_block + 1) * c.block_out_channels[L - 1 - i];
+    return t;
+}
+
+}  // namespace
+
+extern "C" int icd_unet_create(const icd_unet_config* cfg, icd_unet** out) {
+    ICD_CHECK_ARG(cfg && out, "icd_unet_create: null argument");
+    ICD_CHECK_ARG(cfg->num_levels >= 2 && cfg->num_levels <= 4, "icd_unet_create: num_levels must be 2..4");
+    ICD_CHECK_ARG(cfg->in_channels == 4 && cfg->out_channels == 4, "icd_unet_create: latent channels must be 4");
+    ICD_CHECK_ARG(cfg->norm_groups > 0 && cfg->norm_groups <= 64, "icd_unet_create: bad norm_groups");
+    for (int i = 0; i < cfg->num_levels; ++i) {
+        const int C = cfg->block_out_channels[i];
+        ICD_CHECK_ARG(C > 0 && C % 8 == 0 && C % cfg->norm_groups == 0, "icd_unet_create: block_out_channels[%d]=%d unsupported", i, C);
+        const int hd = C / std::max(1, cfg->num_heads[i]);
+        ICD_CHECK_ARG(cfg->num_heads[i] > 0 && C % cfg->num_heads[i] == 0 && hd % 8 == 0 && hd <= 160,
+                      "icd_unet_create: level %d head dim %d unsupported (multiple of 8, <= 160)", i, hd);
+    }
+    ICD_CHECK_ARG(cfg->cross_dim > 0 && cfg->cross_dim % 8 == 0, "icd_unet_create: cross_dim must be a multiple of 8");
+    icd_unet* u = new icd_unet();
+    u->cfg = *cfg;
+    u->n_attn = count_attn(*cfg);
+    u->temb_total = temb_total(*cfg);
+    *out = u;
+    return ICD_OK;
+}
+
+extern "C" void icd_unet_destroy(icd_unet* u) { delete u; }
+
+extern "C" int icd_unet_set_tensor(icd_unet* u, const char* name, const void* ptr, int32_t dtype, int64_t numel) {
+    ICD_CHECK_ARG(u && name && ptr && numel > 0 && (dtype == 0 || dtype == 1), "icd_unet_set_tensor: bad argument");
+    u->tensors[name] = Tensor{ptr, dtype, (long long)numel};
+    u->finalized = false;
+    return ICD_OK;
+}
+
+extern "C" int32_t icd_unet_num_attention_layers(const icd_unet* u) { return u ? u->n_attn : 0; }
+
+static int dry_walk(icd_unet* u, int batch, int H, int W, int nctx, int probs_mode, std::vector<std::string>* missing,
+                    long long* peak) {
+    Exec e;
+    icd_unet_io io; memset(&io, 0, sizeof(io));
+    io.batch = batch; io.H = H; io.W = W; io.n_ctx = nctx;
+    e.u = u; e.io = &io; e.st = nullptr; e.dry = true; e.probs_mode = probs_mode; e.missing = missing;
+    e.B = batch; e.H0 = H; e.W0 = W; e.nctx = nctx;
+    e.ar.reset(nullptr, 0, true);
+    const int rc = e.forward();
+    if (peak) *peak = e.ar.peak;
+    return rc;
+}
+
+extern "C" int icd_unet_finalize(icd_unet* u) {
+    ICD_CHECK_ARG(u, "icd_unet_finalize: null handle");
+    std::vector<std::string> missing;
+    const int div = 1 << (u->cfg.num_levels - 1);
+    const int rc = dry_walk(u, 1, div, div, 8, 0, &missing, nullptr);
+    if (!missing.empty()) {
+        std::string msg = "icd_unet_finalize: " + std::to_string(missing.size()) + " tensors not bound, first: " + missing[0];
+        icd_set_error("%s", msg.c_str());
+        return ICD_ERR_MISSING_TENSOR;
+    }
+    if (rc != ICD_OK) return rc;
+    u->finalized = true;
+    return ICD_OK;
+}
+
+extern "C" int64_t icd_unet_workspace_bytes(const icd_unet* u, int32_t batch, int32_t H, int32_t W, int32_t n_ctx) {
+    if (!u || batch <= 0 || H <= 0 || W <= 0 || n_ctx <= 0) return -1;
+    long long peak = 0;
+    std::vector<std::string> missing;
+    // sized for the worst shipped-controller case: probabilities materialised on every cross layer and every layer
+    // with <= 32^2 queries (utils/p2p.py:147); the fused-only requirement is a subset of it.
+    dry_walk(const_cast<icd_unet*>(u), batch, H, W, n_ctx, 2, &missing, &peak);
+    return peak + 4096;
+}
+
+extern "C" int icd_unet_forward(icd_unet* u, const icd_unet_io* io, void* stream) {
+    ICD_CHECK_ARG(u && io, "icd_unet_forward: null argument");
+    ICD_CHECK_ARG(u->finalized, "icd_unet_forward: call icd_unet_finalize first");
+    ICD_CHECK_ARG(io->sample && io->timesteps && io->context && io->eps && io->workspace, "icd_unet_forward: null buffer");
+    const int div = 1 << (u->cfg.num_levels - 1);
+    ICD_CHECK_ARG(io->batch > 0 && io->H > 0 && io->W > 0 && io->H % div == 0 && io->W % div == 0,
+                  "icd_unet_forward: H and W must be positive multiples of %d", div);
+    ICD_CHECK_ARG(io->n_ctx > 0, "icd_unet_forward: n_ctx must be positive");
+    Exec e;
+    e.u = u; e.io = io; e.st = (hipStream_t)stream; e.dry = false; e.probs_mode = 0; e.missing = nullptr;
+    e.B = io->batch; e.H0 = io->H; e.W0 = io->W; e.nctx = io->n_ctx;
+    e.ar.reset(io->workspace, io->workspace_bytes, false);
+    return e.forward();
+}

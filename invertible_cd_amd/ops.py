@@ -1,0 +1,221 @@
+"""Block-level operators of the UNet path: thin torch-tensor front ends over the C ABI (include/icd_amd.h).
+
+torch is used here for device memory and streams only; every arithmetic op is a HIP kernel in libicd_amd.so.
+Activations are fp16, token-major ("NHWC"): a feature map is a [B, H*W, C] tensor.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import GemmDesc, ICD_GEMM_GEGLU, ICD_GEMM_OUT_F32, ICD_GEMM_OUT_TRANS
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _chk16(t, name):
+    assert t.is_cuda and t.dtype == torch.float16 and t.is_contiguous(), f"{name}: need contiguous cuda fp16"
+
+
+# ------------------------------------------------------------------------------------------------ packing helpers
+def pack_conv_weight(w_oihw):
+    """[O, I, kh, kw] -> [O, kh*kw*I] fp16 (tap-major, channel-minor: the K order of the implicit GEMM)."""
+    o = w_oihw.shape[0]
+    return w_oihw.permute(0, 2, 3, 1).reshape(o, -1).to(torch.float16).contiguous()
+
+
+def geglu_perm(n_out):
+    """Row permutation of ff.net.0.proj ([2*n_out, C]) so that packed rows alternate 32 'value' / 32 'gate' rows."""
+    assert n_out % 32 == 0
+    idx = torch.arange(2 * n_out)
+    blk, within = idx // 32, idx % 32
+    return torch.where(blk % 2 == 0, (blk // 2) * 32 + within, n_out + (blk // 2) * 32 + within)
+
+
+# ------------------------------------------------------------------------------------------------ operators
+def gemm(a, w, bias=None, resid=None, rowbias=None, rows_per_sample=0, geglu=False, out=None, alpha=1.0,
+         out_f32=False):
+    """out[M, N] = alpha * a[M, K] @ w[N, K]^T (+bias[N] fp32) (+rowbias[m // rps]) (+resid) ; GEGLU halves N."""
+    _chk16(a, "a"); _chk16(w, "w")
+    M, K = a.shape
+    N = w.shape[0]
+    n_out = N // 2 if geglu else N
+    if out is None:
+        out = torch.empty((M, n_out), device=a.device, dtype=torch.float32 if out_f32 else torch.float16)
+    d = GemmDesc()
+    d.a0, d.w, d.out = a.data_ptr(), w.data_ptr(), out.data_ptr()
+    d.bias = bias.data_ptr() if bias is not None else None
+    d.resid = resid.data_ptr() if resid is not None else None
+    d.rowbias = rowbias.data_ptr() if rowbias is not None else None
+    d.M, d.N, d.K, d.Nw = M, N, K, N
+    d.lda, d.ldw, d.ldo = a.stride(0), w.stride(0), out.stride(0)
+    d.ldr = resid.stride(0) if resid is not None else 0
+    d.ld_rowbias = rowbias.stride(0) if rowbias is not None else 0
+    d.rows_per_sample = rows_per_sample
+    d.mode, d.batch, d.zdiv, d.alpha = 0, 1, 1, alpha
+    d.flags = (ICD_GEMM_GEGLU if geglu else 0) | (ICD_GEMM_OUT_F32 if out_f32 else 0)
+    _lib.check(_lib.load().icd_gemm(C.byref(d), _stream()), "icd_gemm")
+    return out
+
+
+def conv3x3(x, B, H, W, w_packed, bias=None, x2=None, stride=1, upsample=False, resid=None, rowbias=None, ksize=3):
+    """Implicit-GEMM conv over NHWC x [B*H*W, C0] (optionally cat with x2 [.., C1]); returns [B*Ho*Wo, Cout]."""
+    _chk16(x, "x"); _chk16(w_packed, "w")
+    C0 = x.shape[-1]
+    C1 = x2.shape[-1] if x2 is not None else 0
+    Hu, Wu = (H * 2, W * 2) if upsample else (H, W)
+    Ho, Wo = (Hu + stride - 1) // stride, (Wu + stride - 1) // stride
+    N = w_packed.shape[0]
+    out = torch.empty((B * Ho * Wo, N), device=x.device, dtype=torch.float16)
+    d = GemmDesc()
+    d.a0, d.a1, d.w, d.out = x.data_ptr(), (x2.data_ptr() if x2 is not None else None), w_packed.data_ptr(), out.data_ptr()
+    d.bias = bias.data_ptr() if bias is not None else None
+    d.resid = resid.data_ptr() if resid is not None else None
+    d.rowbias = rowbias.data_ptr() if rowbias is not None else None
+    d.M, d.N, d.K, d.Nw = B * Ho * Wo, N, ksize * ksize * (C0 + C1), N
+    d.lda, d.ldw, d.ldo = 0, w_packed.stride(0), N
+    d.ldr = resid.stride(0) if resid is not None else 0
+    d.ld_rowbias = rowbias.stride(0) if rowbias is not None else 0
+    d.rows_per_sample = Ho * Wo
+    d.mode, d.C0, d.C1 = 1, C0, C1
+    d.Hin, d.Win, d.Hout, d.Wout, d.ksize, d.stride, d.upsample = H, W, Ho, Wo, ksize, stride, int(upsample)
+    d.batch, d.zdiv, d.alpha, d.flags = 1, 1, 1.0, 0
+    _lib.check(_lib.load().icd_gemm(C.byref(d), _stream()), "icd_gemm(conv)")
+    return out
+
+
+def groupnorm(x, B, HW, gamma, beta, eps, silu, x2=None, groups=32):
+    _chk16(x, "x")
+    C0 = x.shape[-1]
+    C1 = x2.shape[-1] if x2 is not None else 0
+    lib = _lib.load()
+    ws = torch.empty((lib.icd_groupnorm_ws_floats(B, HW, groups),), device=x.device, dtype=torch.float32)
+    out = torch.empty((B * HW, C0 + C1), device=x.device, dtype=torch.float16)
+    _lib.check(lib.icd_groupnorm(_p(x), C0, _p(x2), C1, B, HW, groups, _p(gamma), _p(beta), eps, int(silu), _p(out),
+                                 _p(ws), _stream()), "icd_groupnorm")
+    return out
+
+
+def layernorm(x, gamma, beta, eps=1e-5):
+    _chk16(x, "x")
+    rows, Cc = x.shape
+    out = torch.empty_like(x)
+    _lib.check(_lib.load().icd_layernorm(_p(x), rows, Cc, _p(gamma), _p(beta), eps, _p(out), _stream()), "icd_layernorm")
+    return out
+
+
+def softmax_rows(s, cols, ld_p, scale=1.0):
+    assert s.dtype == torch.float32 and s.is_contiguous()
+    rows, ld_s = s.shape
+    p = torch.empty((rows, ld_p), device=s.device, dtype=torch.float16)
+    _lib.check(_lib.load().icd_softmax_rows(_p(s), rows, cols, ld_s, scale, _p(p), ld_p, _stream()), "icd_softmax_rows")
+    return p
+
+
+def project_vt(x, w, B, n_tokens, ld_keys):
+    """V^T[b, c, key] = (x[b*n_tokens + key] @ w^T)[c]  -> [B, N, ld_keys] (pad columns zero)."""
+    _chk16(x, "x"); _chk16(w, "w")
+    M, K = x.shape
+    N = w.shape[0]
+    out = torch.empty((B, N, ld_keys), device=x.device, dtype=torch.float16)
+    d = GemmDesc()
+    d.a0, d.w, d.out = x.data_ptr(), w.data_ptr(), out.data_ptr()
+    d.M, d.N, d.K, d.Nw = M, N, K, N
+    d.lda, d.ldw, d.ldo = x.stride(0), w.stride(0), ld_keys
+    d.rows_per_sample = n_tokens
+    d.mode, d.batch, d.zdiv, d.alpha, d.flags = 0, 1, 1, 1.0, ICD_GEMM_OUT_TRANS
+    _lib.check(_lib.load().icd_gemm(C.byref(d), _stream()), "icd_gemm(V^T)")
+    return out
+
+
+def attention_fused(q, k, vt, B, H, Nq, Nk, d, scale):
+    """q [B*Nq, H*d], k [B*Nk, H*d], vt [B, H*d, ld] -> out [B*Nq, H*d]."""
+    _chk16(q, "q"); _chk16(k, "k"); _chk16(vt, "vt")
+    out = torch.empty_like(q)
+    _lib.check(_lib.load().icd_attention_fused(_p(q), _p(k), _p(vt), _p(out), B, H, Nq, Nk, d, q.stride(0), k.stride(0),
+                                               vt.stride(1), out.stride(0), scale, _stream()), "icd_attention_fused")
+    return out
+
+
+def attention_scores(q, k, B, H, Nq, Nk, d, scale, ld):
+    """S[b*H+h, n, m] = scale * q[b,n,h,:].k[b,m,h,:]  (fp32, [B*H, Nq, ld], columns >= Nk are zero)."""
+    s = torch.empty((B * H, Nq, ld), device=q.device, dtype=torch.float32)
+    dsc = GemmDesc()
+    dsc.a0, dsc.w, dsc.out = q.data_ptr(), k.data_ptr(), s.data_ptr()
+    dsc.M, dsc.N, dsc.K, dsc.Nw = Nq, ld, d, Nk
+    dsc.lda, dsc.ldw, dsc.ldo = q.stride(0), k.stride(0), ld
+    dsc.mode, dsc.batch, dsc.zdiv = 0, B * H, H
+    dsc.a_bs0, dsc.a_bs1 = Nq * q.stride(0), d
+    dsc.w_bs0, dsc.w_bs1 = Nk * k.stride(0), d
+    dsc.o_bs0, dsc.o_bs1 = H * Nq * ld, Nq * ld
+    dsc.alpha, dsc.flags = scale, ICD_GEMM_OUT_F32
+    _lib.check(_lib.load().icd_gemm(C.byref(dsc), _stream()), "icd_gemm(QK^T)")
+    return s
+
+
+def attention_apply(p, vt, B, H, Nq, d, out=None):
+    """out[b, n, h*d:(h+1)*d] = P[b*H+h, n, :] @ V[b, :, h, :]   with P [B*H, Nq, ld], vt [B, H*d, ld]."""
+    ld = p.stride(1)
+    if out is None:
+        out = torch.empty((B * Nq, H * d), device=p.device, dtype=torch.float16)
+    dsc = GemmDesc()
+    dsc.a0, dsc.w, dsc.out = p.data_ptr(), vt.data_ptr(), out.data_ptr()
+    dsc.M, dsc.N, dsc.K, dsc.Nw = Nq, ((d + 7) // 8) * 8, ld, d
+    dsc.lda, dsc.ldw, dsc.ldo = ld, vt.stride(1), out.stride(0)
+    dsc.mode, dsc.batch, dsc.zdiv = 0, B * H, H
+    dsc.a_bs0, dsc.a_bs1 = H * p.stride(0), p.stride(0)
+    dsc.w_bs0, dsc.w_bs1 = vt.stride(0), d * vt.stride(1)
+    dsc.o_bs0, dsc.o_bs1 = Nq * out.stride(0), d
+    dsc.alpha, dsc.flags = 1.0, 0
+    _lib.check(_lib.load().icd_gemm(C.byref(dsc), _stream()), "icd_gemm(PV)")
+    return out
+
+
+def sinusoid(vals, dim, kind):
+    vals = vals.to(torch.float32).contiguous()
+    out = torch.empty((vals.numel(), dim), device=vals.device, dtype=torch.float16)
+    _lib.check(_lib.load().icd_sinusoid(_p(vals), vals.numel(), dim, kind, _p(out), _stream()), "icd_sinusoid")
+    return out
+
+
+def silu(x):
+    _chk16(x, "x")
+    out = torch.empty_like(x)
+    _lib.check(_lib.load().icd_silu(_p(x), x.numel(), _p(out), _stream()), "icd_silu")
+    return out
+
+
+def conv_in(x_nchw, w_packed, bias):
+    B, Cin, H, W = x_nchw.shape
+    assert Cin == 4 and x_nchw.is_contiguous() and x_nchw.dtype in (torch.float16, torch.float32)
+    Cout = w_packed.shape[0]
+    out = torch.empty((B * H * W, Cout), device=x_nchw.device, dtype=torch.float16)
+    _lib.check(_lib.load().icd_conv_in(_p(x_nchw), int(x_nchw.dtype == torch.float32), B, H, W, _p(w_packed), _p(bias),
+                                       Cout, _p(out), _stream()), "icd_conv_in")
+    return out
+
+
+def conv_out(x, B, H, W, w_packed, bias, out_dtype=torch.float16):
+    _chk16(x, "x")
+    eps = torch.empty((B, 4, H, W), device=x.device, dtype=out_dtype)
+    _lib.check(_lib.load().icd_conv_out(_p(x), B, H, W, x.shape[-1], _p(w_packed), _p(bias), _p(eps),
+                                        int(out_dtype == torch.float32), _stream()), "icd_conv_out")
+    return eps
+
+
+def x0_step(x, eps, coef, out_dtype=None):
+    """predicted_origin (eps-prediction); coef fp32 [B,4] = (alpha_t, sigma_t, alpha_s, sigma_s)."""
+    assert x.is_contiguous() and eps.is_contiguous() and x.shape == eps.shape
+    out_dtype = out_dtype or x.dtype
+    out = torch.empty(x.shape, device=x.device, dtype=out_dtype)
+    B = x.shape[0]
+    flags = int(x.dtype == torch.float32) | (int(eps.dtype == torch.float32) << 1) | (int(out_dtype == torch.float32) << 2)
+    coef = coef.to(device=x.device, dtype=torch.float32).contiguous()
+    _lib.check(_lib.load().icd_x0_step(_p(x), _p(eps), _p(coef), B, x.numel() // B, flags, _p(out), _stream()), "icd_x0_step")
+    return out

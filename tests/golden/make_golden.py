@@ -207,7 +207,9 @@ def gold_timesteps():
     res["ddimsolver_explicit"] = dict(endpoints=s.endpoints.tolist(), inverse_endpoints=s.inverse_endpoints.tolist())
     res["alphas_cumprod_probe"] = {str(i): float(ac[i]) for i in (0, 19, 249, 259, 339, 499, 519, 699, 779, 999)}
     jdump("timesteps.json", res)
-    npz("alphas_cumprod.npz", alphas_cumprod=ac)
+    # torch's CPU sqrt is not correctly rounded and differs between CPU vendors: pin the tables the reference used
+    act = alphas_cumprod()
+    npz("alphas_cumprod.npz", alphas_cumprod=ac, alpha_table=torch.sqrt(act), sigma_table=torch.sqrt(1 - act))
 
 
 def gold_wembed():

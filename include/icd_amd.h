@@ -192,6 +192,32 @@ typedef struct {
 
 int icd_unet_forward(icd_unet* u, const icd_unet_io* io, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Per-kernel-family timing of the executor's launches with HIP events recorded on the launch stream (bench.py's
+ * roofline leg).  No reference counterpart (the reference has no timing code at all).
+ * ---------------------------------------------------------------------------------------------------------- */
+#define ICD_PROF_GEMM_CONV    0   /* implicit-GEMM conv3x3 / 1x1 (gemm_kernel<1,*>)            */
+#define ICD_PROF_GEMM_DENSE   1   /* Linear layers (gemm_kernel<0,*>, batch 1)                 */
+#define ICD_PROF_GEMM_BATCHED 2   /* attention bmm of the materialised-P path                  */
+#define ICD_PROF_ATTN_FUSED   3
+#define ICD_PROF_GROUPNORM    4
+#define ICD_PROF_LAYERNORM    5
+#define ICD_PROF_SOFTMAX      6
+#define ICD_PROF_MISC         7
+#define ICD_PROF_KINDS        8
+typedef struct {
+    int32_t kind;
+    int32_t launches;
+    double ms;        /* sum of event-to-event durations */
+    double flops;     /* ALGORITHMIC flops (2*M*N*K incl. zero-padded taps; 4*B*H*Nq*Nk*d for attention) */
+    double bytes;     /* ALGORITHMIC HBM bytes for the bandwidth-bound families */
+} icd_profile_row;
+/* enable != 0: start a fresh recording; enable == 0: stop.  While enabled every executor launch is bracketed by two
+ * hipEventRecord calls on its stream. */
+int icd_profile_enable(int32_t enable);
+/* After the stream has been synchronised: fills rows[0..ICD_PROF_KINDS) and returns the number of rows. */
+int icd_profile_read(icd_profile_row* rows, int32_t max_rows);
+
 #ifdef __cplusplus
 }
 #endif

@@ -43,6 +43,13 @@ ATTN_HOOK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.
                         C.c_int64, C.c_int64, C.POINTER(C.c_void_p))
 
 
+class ProfileRow(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("launches", C.c_int32), ("ms", C.c_double), ("flops", C.c_double), ("bytes", C.c_double)]
+
+
+PROF_KINDS = ("gemm_conv", "gemm_dense", "gemm_batched", "attn_fused", "groupnorm", "layernorm", "softmax", "misc")
+
+
 class UNetIO(C.Structure):
     _fields_ = [
         ("sample", C.c_void_p), ("timesteps", C.c_void_p), ("context", C.c_void_p), ("timestep_cond", C.c_void_p),
@@ -82,6 +89,8 @@ SIGNATURES = {
     "icd_unet_num_attention_layers": (C.c_int32, [C.c_void_p]),
     "icd_unet_workspace_bytes": (C.c_int64, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "icd_unet_forward": (C.c_int, [C.c_void_p, C.POINTER(UNetIO), C.c_void_p]),
+    "icd_profile_enable": (C.c_int, [C.c_int32]),
+    "icd_profile_read": (C.c_int, [C.POINTER(ProfileRow), C.c_int32]),
 }
 
 _lib = None
@@ -109,3 +118,16 @@ def check(status, what=""):
     if status != 0:
         msg = load().icd_last_error().decode("utf-8", "replace")
         raise RuntimeError(f"libicd_amd {what} failed (status {status}): {msg}")
+
+
+def profile_enable(on=True):
+    check(load().icd_profile_enable(int(on)), "icd_profile_enable")
+
+
+def profile_read():
+    """{family: dict(launches, ms, flops, bytes)} - call after synchronising the stream."""
+    rows = (ProfileRow * len(PROF_KINDS))()
+    n = load().icd_profile_read(rows, len(PROF_KINDS))
+    if n < 0:
+        check(n, "icd_profile_read")
+    return {PROF_KINDS[r.kind]: dict(launches=r.launches, ms=r.ms, flops=r.flops, bytes=r.bytes) for r in rows[:n]}

@@ -19,6 +19,30 @@ namespace {
 
 struct Tensor { const void* ptr; int dtype; long long numel; };
 
+// ---- per-family launch timing (HIP events on the launch stream) ------------------------------------------------
+struct ProfRec { hipEvent_t a, b; int kind; double flops, bytes; };
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof;
+std::vector<hipEvent_t> g_ev_pool;
+
+hipEvent_t prof_event() {
+    if (!g_ev_pool.empty()) { hipEvent_t e = g_ev_pool.back(); g_ev_pool.pop_back(); return e; }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+}
+struct ProfScope {
+    bool on; hipStream_t st; size_t idx;
+    ProfScope(bool active, hipStream_t s, int kind, double flops, double bytes) : on(active && g_prof_on), st(s), idx(0) {
+        if (!on) return;
+        ProfRec r{prof_event(), prof_event(), kind, flops, bytes};
+        (void)hipEventRecord(r.a, st);
+        idx = g_prof.size();
+        g_prof.push_back(r);
+    }
+    ~ProfScope() { if (on) (void)hipEventRecord(g_prof[idx].b, st); }
+};
+
 struct Arena {
     char* base = nullptr;
     long long cap = 0, peak = 0;
@@ -130,6 +154,9 @@ struct Exec {
     // ---------------------------------------------------------------------------------------------- op wrappers
     void gemm_desc(icd_gemm_desc& d) {
         if (!ok() || dry) return;
+        const int nb = d.batch > 0 ? d.batch : 1;
+        ProfScope ps(true, st, d.mode == 1 ? ICD_PROF_GEMM_CONV : (nb > 1 ? ICD_PROF_GEMM_BATCHED : ICD_PROF_GEMM_DENSE),
+                     2.0 * d.M * (double)d.N * d.K * nb, 0.0);
         run(icd_gemm(&d, st));
     }
     // dense: out[M,N] (ldo) = a[M,K](lda) @ w[N,K]^T + bias + resid
@@ -156,10 +183,12 @@ struct Exec {
     }
     void groupnorm(const Act& x0, const Act* x1, int HW, const float* g, const float* b, float eps, int silu, half_t* out) {
         if (!ok() || dry) return;
+        ProfScope ps(true, st, ICD_PROF_GROUPNORM, 0.0, 6.0 * B * (double)HW * (x0.C + (x1 ? x1->C : 0)));
         run(icd_groupnorm(x0.p, x0.C, x1 ? x1->p : nullptr, x1 ? x1->C : 0, B, HW, u->cfg.norm_groups, g, b, eps, silu, out, gn_ws, st));
     }
     void layernorm(const half_t* x, long long rows, int C, const float* g, const float* b, half_t* out) {
         if (!ok() || dry) return;
+        ProfScope ps(true, st, ICD_PROF_LAYERNORM, 0.0, 4.0 * (double)rows * C);
         run(icd_layernorm(x, rows, C, g, b, 1e-5f, out, st));
     }
 
@@ -212,7 +241,10 @@ struct Exec {
             if (mat && !probs) { icd_set_error("attention hook returned 1 without a probability buffer (layer %d)", my_layer); status = ICD_ERR_HOOK; return; }
         }
         if (!mat) {
-            if (ok() && !dry) run(icd_attention_fused(q, k, vt, out, B, heads, Nq, Nk, d, ldq, ldk, ldv, C, scale, st));
+            if (ok() && !dry) {
+                ProfScope ps(true, st, ICD_PROF_ATTN_FUSED, 4.0 * B * heads * (double)Nq * Nk * d, 0.0);
+                run(icd_attention_fused(q, k, vt, out, B, heads, Nq, Nk, d, ldq, ldk, ldv, C, scale, st));
+            }
             return;
         }
         // materialised path (utils/p2p.py:335-338): S = scale q.k^T (fp32) -> softmax -> P (fp16) -> hook -> P.V
@@ -230,8 +262,10 @@ struct Exec {
             g.o_bs0 = per_b; g.o_bs1 = (long long)Nq * ldp;
             g.alpha = scale; g.flags = ICD_GEMM_OUT_F32;
             gemm_desc(g);
-            if (ok() && !dry)
+            if (ok() && !dry) {
+                ProfScope ps(true, st, ICD_PROF_SOFTMAX, 0.0, (double)cb * heads * Nq * ldp * 14.0);
                 run(icd_softmax_rows(S, (long long)cb * heads * Nq, Nk, (int)ldp, 1.0f, (half_t*)probs + (long long)b0 * per_b, (int)ldp, st));
+            }
         }
         release(S);
         if (!dry && ok()) {
@@ -355,8 +389,10 @@ struct Exec {
         std::vector<Act> skips;
         std::vector<int> skipH;
         Act h{alloc<half_t>((long long)B * HW0 * ch0), ch0};
-        if (ok() && !dry)
+        if (ok() && !dry) {
+            ProfScope ps(true, st, ICD_PROF_MISC, 2.0 * B * (double)HW0 * 36 * ch0, 0.0);
             run(icd_conv_in(io->sample, io->sample_is_f32, B, H0, W0, Wh("conv_in.weight", 36LL * ch0), Wf("conv_in.bias", ch0), ch0, h.p, st));
+        }
         else { Wh("conv_in.weight", 36LL * ch0); Wf("conv_in.bias", ch0); }
         skips.push_back(h);
         int Hh = H0, Ww = W0;
@@ -427,7 +463,10 @@ struct Exec {
         release(h.p);
         const half_t* wo = Wh("conv_out.weight", 9LL * ch0 * c.out_channels);
         const float* bo = Wf("conv_out.bias", c.out_channels);
-        if (ok() && !dry) run(icd_conv_out(n, B, H0, W0, ch0, wo, bo, io->eps, io->sample_is_f32, st));
+        if (ok() && !dry) {
+            ProfScope ps(true, st, ICD_PROF_MISC, 2.0 * B * (double)HW0 * 9 * ch0 * c.out_channels, 0.0);
+            run(icd_conv_out(n, B, H0, W0, ch0, wo, bo, io->eps, io->sample_is_f32, st));
+        }
         release(n);
         release(temb_all);
         return status;
@@ -453,6 +492,24 @@ int temb_total(const icd_unet_config& c) {
 }
 
 }  // namespace
+
+extern "C" int icd_profile_enable(int32_t enable) {
+    for (auto& r : g_prof) { g_ev_pool.push_back(r.a); g_ev_pool.push_back(r.b); }
+    g_prof.clear();
+    g_prof_on = enable != 0;
+    return ICD_OK;
+}
+
+extern "C" int icd_profile_read(icd_profile_row* rows, int32_t max_rows) {
+    ICD_CHECK_ARG(rows && max_rows >= ICD_PROF_KINDS, "icd_profile_read: need room for %d rows", ICD_PROF_KINDS);
+    for (int k = 0; k < ICD_PROF_KINDS; ++k) { rows[k].kind = k; rows[k].launches = 0; rows[k].ms = rows[k].flops = rows[k].bytes = 0.0; }
+    for (auto& r : g_prof) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) { icd_set_error("icd_profile_read: events not complete (synchronise the stream first)"); return ICD_ERR_HIP; }
+        rows[r.kind].launches += 1; rows[r.kind].ms += ms; rows[r.kind].flops += r.flops; rows[r.kind].bytes += r.bytes;
+    }
+    return ICD_PROF_KINDS;
+}
 
 extern "C" int icd_unet_create(const icd_unet_config* cfg, icd_unet** out) {
     ICD_CHECK_ARG(cfg && out, "icd_unet_create: null argument");

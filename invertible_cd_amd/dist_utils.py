@@ -1,0 +1,65 @@
+"""Process-group bootstrap + the data-parallel sharding / gather of the iCD drivers (mirror of utils/dist_utils.py and
+of the DP pieces of running/sd1.5/generate.py:29-39,372-397).
+
+One process per GPU (torchrun), backend "nccl" which IS RCCL on ROCm; the only collective on the path is ONE all-gather
+of the finished samples at the end of a run (uint8 images or fp16 latents + int64 ids) - samples are independent, the
+U-Net loop itself never communicates.
+"""
+import os
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def get_world_size():
+    return dist.get_world_size() if dist.is_initialized() else 1
+
+
+def get_rank():
+    return dist.get_rank() if dist.is_initialized() else 0
+
+
+def init(backend=None):
+    """utils/dist_utils.py:8-22: env:// rendezvous with single-process defaults; binds the rank to its GPU."""
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29500')
+    os.environ.setdefault('RANK', '0')
+    os.environ.setdefault('LOCAL_RANK', '0')
+    os.environ.setdefault('WORLD_SIZE', '1')
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')     # dmabuf IPC for RCCL on this driver
+    if backend is None:
+        backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+    if torch.cuda.is_available():
+        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
+    if not dist.is_initialized():
+        dist.init_process_group(backend=backend, init_method='env://')
+
+
+def prepare_val_prompts(all_text, bs=20, max_cnt=5000):
+    """Round-robin batch sharding of running/sd1.5/generate.py:29-39 (== running/sdxl/generate.py:25-35):
+    ((N-1)//(bs*W)+1)*W batches via array_split, rank r takes batches r::W.  Returns (batches, index batches, texts)."""
+    all_text = all_text[:max_cnt]
+    W, r = get_world_size(), get_rank()
+    num_batches = ((len(all_text) - 1) // (bs * W) + 1) * W
+    batches = np.array_split(np.array(all_text), num_batches)[r::W]
+    index = np.array_split(np.arange(len(all_text)), num_batches)[r::W]
+    return batches, index, all_text
+
+
+def gather_samples(local, local_ids):
+    """ONE all-gather of this rank's finished samples + their global ids (running/sd1.5/generate.py:372-378), then
+    reorder by id (:386-397).  `local`: [N_local, ...] tensor (uint8 images or fp16 latents), `local_ids`: int64 [N_local].
+    Every rank must contribute the same N_local (the reference has the same equal-shape requirement).
+    Returns (samples ordered by global id, sorted ids) on every rank."""
+    W = get_world_size()
+    if W == 1:
+        order = torch.argsort(local_ids)
+        return local[order], local_ids[order]
+    bufs = [torch.empty_like(local) for _ in range(W)]
+    ids = [torch.empty_like(local_ids) for _ in range(W)]
+    dist.all_gather(bufs, local.contiguous())
+    dist.all_gather(ids, local_ids.contiguous())
+    allx, alli = torch.cat(bufs, 0), torch.cat(ids, 0)
+    order = torch.argsort(alli)
+    return allx[order], alli[order]

@@ -1,0 +1,295 @@
+"""SDXL iCD sampler / inverter on the native MI355X UNet (API mirror of the reference's utils/generation_sdxl.py).
+
+Kept: `sample_deterministic`, `inverse_sample_deterministic`, `DDIMSolver`, `predicted_origin`, `extract_into_tensor`,
+`guidance_scale_embedding`, `linear_schedule_old`, `compute_embeddings`, `encode_prompt` - same signatures, same
+timestep / boundary construction, same per-step arithmetic (pinned by tests/golden/sdxl_loops.npz).
+
+Differences underneath: `pipe.unet` is the native executor (one call per step, no hooks on this path); the boundary
+step is the fused HIP kernel; per-step device constants are cached so the loop never synchronises.  One deliberate
+superset: with `use_dynamic_guidance=True` the reference only works for a batch of one (it builds
+`torch.tensor([tensor_of_len_B] * B)`, utils/generation_sdxl.py:439-440, which raises for B > 1); here the same scalar
+rule is applied to every sample, which is what the reference computes for B == 1.
+"""
+import copy
+import random
+
+import numpy as np
+import torch
+
+
+def encode_prompt(prompt_batch, text_encoders, tokenizers, proportion_empty_prompts, is_train=True):
+    """Two-encoder SDXL prompt encoding: penultimate hidden states concatenated + pooled output of the last encoder."""
+    captions = []
+    for caption in prompt_batch:
+        if random.random() < proportion_empty_prompts:
+            captions.append("")
+        elif isinstance(caption, str):
+            captions.append(caption)
+        elif isinstance(caption, (list, np.ndarray)):
+            captions.append(random.choice(caption) if is_train else caption[0])
+    per_encoder = []
+    with torch.no_grad():
+        for tok, enc in zip(tokenizers, text_encoders):
+            ids = tok(captions, padding="max_length", max_length=tok.model_max_length, truncation=True,
+                      return_tensors="pt").input_ids
+            out = enc(ids.to(enc.device), output_hidden_states=True)
+            pooled = out[0]
+            hidden = out.hidden_states[-2]
+            per_encoder.append(hidden.view(hidden.shape[0], hidden.shape[1], -1))
+    prompt_embeds = torch.concat(per_encoder, dim=-1)
+    return prompt_embeds, pooled.view(prompt_embeds.shape[0], -1)
+
+
+def compute_embeddings(prompt_batch, original_sizes, crop_coords, proportion_empty_prompts, text_encoders, tokenizers,
+                       is_train=True, device='cuda'):
+    """{prompt_embeds [B,77,2048], text_embeds [B,1280], time_ids [B,6] = (orig h,w, crop t,l, target 1024,1024)}."""
+    original_sizes = torch.tensor(original_sizes, dtype=torch.long)
+    crops = torch.tensor(crop_coords, dtype=torch.long)
+    prompt_embeds, pooled = encode_prompt(prompt_batch, text_encoders, tokenizers, proportion_empty_prompts, is_train)
+    target = torch.tensor([[1024, 1024]]).repeat(len(prompt_batch), 1)
+    time_ids = torch.cat([original_sizes, crops, target], dim=-1).to(device, dtype=prompt_embeds.dtype)
+    return {"prompt_embeds": prompt_embeds.to(device), "text_embeds": pooled.to(device), "time_ids": time_ids}
+
+
+def extract_into_tensor(a, t, x_shape):
+    b, *_ = t.shape
+    return a.gather(-1, t).reshape(b, *((1,) * (len(x_shape) - 1)))
+
+
+def guidance_scale_embedding(w, embedding_dim=512, dtype=torch.float32):
+    """Same embedding as the SD1.5 path (utils/generation_sdxl.py:84-110)."""
+    assert len(w.shape) == 1
+    w = w * 1000.0
+    half_dim = embedding_dim // 2
+    step = torch.log(torch.tensor(10000.0)) / (half_dim - 1)
+    freqs = torch.exp(torch.arange(half_dim, dtype=dtype) * -step)
+    ang = w.to(dtype)[:, None] * freqs[None, :]
+    emb = torch.cat([torch.sin(ang), torch.cos(ang)], dim=1)
+    if embedding_dim % 2 == 1:
+        emb = torch.nn.functional.pad(emb, (0, 1))
+    assert emb.shape == (w.shape[0], embedding_dim)
+    return emb
+
+
+def predicted_origin(model_output, timesteps, boundary_timesteps, sample, prediction_type, alphas, sigmas):
+    """utils/generation_sdxl.py:112-132 (generic torch form; the loops below use the fused HIP kernel on the GPU)."""
+    sigmas_s = extract_into_tensor(sigmas, boundary_timesteps, sample.shape)
+    alphas_s = extract_into_tensor(alphas, boundary_timesteps, sample.shape)
+    sigmas_t = extract_into_tensor(sigmas, timesteps, sample.shape)
+    alphas_t = extract_into_tensor(alphas, timesteps, sample.shape)
+    alphas_s[boundary_timesteps == 0] = 1.0
+    sigmas_s[boundary_timesteps == 0] = 0.0
+    if prediction_type == "epsilon":
+        x0 = (sample - sigmas_t * model_output) / alphas_t
+        return alphas_s * x0 + sigmas_s * model_output
+    if prediction_type == "v_prediction":
+        assert boundary_timesteps == 0, "v_prediction does not support multiple endpoints at the moment"
+        return alphas_t * sample - sigmas_t * model_output
+    raise ValueError(f"Prediction type {prediction_type} currently not supported.")
+
+
+class DDIMSolver:
+    """Endpoint tables of the multi-boundary consistency model (utils/generation_sdxl.py:135-199)."""
+
+    def __init__(self, alpha_cumprods, timesteps=1000, ddim_timesteps=50, num_endpoints=1, num_inverse_endpoints=1,
+                 max_inverse_timestep_index=49, endpoints=None, inverse_endpoints=None):
+        ratio = timesteps // ddim_timesteps
+        grid = (np.arange(1, ddim_timesteps + 1) * ratio).round().astype(np.int64) - 1
+        self.ddim_timesteps = torch.from_numpy(grid).long()
+        self.ddim_alpha_cumprods = torch.from_numpy(alpha_cumprods[grid])
+        self.ddim_alpha_cumprods_prev = torch.from_numpy(np.asarray([alpha_cumprods[0]] + alpha_cumprods[grid[:-1]].tolist()))
+        self.ddim_alpha_cumprods_next = torch.from_numpy(np.asarray(alpha_cumprods[grid[1:]].tolist() + [0.0]))
+
+        def interval_idx(n):
+            step = ddim_timesteps // n + int(ddim_timesteps % n > 0)
+            return torch.arange(step, ddim_timesteps, step) - 1
+
+        if endpoints is None:
+            self.endpoints = torch.tensor([0] + self.ddim_timesteps[interval_idx(num_endpoints)].tolist())
+        else:
+            self.endpoints = torch.tensor([int(e) for e in endpoints.split(',')])
+            assert len(self.endpoints) == num_endpoints
+        if inverse_endpoints is None:
+            idx = torch.tensor(interval_idx(num_inverse_endpoints).tolist() + [max_inverse_timestep_index])
+            self.inverse_endpoints = self.ddim_timesteps[idx]
+        else:
+            self.inverse_endpoints = torch.tensor([int(e) for e in inverse_endpoints.split(',')])
+            assert len(self.inverse_endpoints) == num_inverse_endpoints
+
+    def to(self, device):
+        for name in ("endpoints", "inverse_endpoints", "ddim_timesteps", "ddim_alpha_cumprods", "ddim_alpha_cumprods_prev",
+                     "ddim_alpha_cumprods_next"):
+            setattr(self, name, getattr(self, name).to(device))
+        return self
+
+    def ddim_step(self, pred_x0, pred_noise, timestep_index):
+        a_prev = extract_into_tensor(self.ddim_alpha_cumprods_prev, timestep_index, pred_x0.shape)
+        return a_prev.sqrt() * pred_x0 + (1.0 - a_prev).sqrt() * pred_noise
+
+    def inverse_ddim_step(self, pred_x0, pred_noise, timestep_index):
+        a_next = extract_into_tensor(self.ddim_alpha_cumprods_next, timestep_index, pred_x0.shape)
+        return a_next.sqrt() * pred_x0 + (1.0 - a_next).sqrt() * pred_noise
+
+
+def linear_schedule_old(t, guidance_scale, tau1, tau2):
+    u = t / 1000
+    if u <= tau1:
+        gamma = 1.0
+    elif u >= tau2:
+        gamma = 0.0
+    else:
+        gamma = (tau2 - u) / (tau2 - tau1)
+    return gamma * guidance_scale
+
+
+# --------------------------------------------------------------------------------------------- shared loop pieces
+_CONST_CACHE = {}
+
+
+def _cached(key, make):
+    v = _CONST_CACHE.get(key)
+    if v is None:
+        if len(_CONST_CACHE) > 256:
+            _CONST_CACHE.clear()
+        v = _CONST_CACHE[key] = make()
+    return v
+
+
+def _text_conditioning(pipe, prompt, compute_embeddings_fn, is_sdxl, device):
+    if compute_embeddings_fn is not None:
+        if is_sdxl:
+            enc = compute_embeddings_fn(prompt, [(1024, 1024)] * len(prompt), [(0, 0)] * len(prompt))
+            prompt_embeds = enc.pop("prompt_embeds")
+        else:
+            prompt_embeds, enc = compute_embeddings_fn(prompt)["prompt_embeds"], {}
+        prompt_embeds = prompt_embeds.to(pipe.unet.dtype)
+    else:
+        prompt_embeds, enc = pipe.encode_prompt(prompt, device, 1, False)[0], {}
+    assert prompt_embeds.dtype == pipe.unet.dtype
+    return prompt_embeds, enc
+
+
+def _w_embedding(values, device, dtype):
+    key = ("w", tuple(float(v) for v in values), str(device), dtype)
+    return _cached(key, lambda: guidance_scale_embedding(torch.tensor([float(v) for v in values]), embedding_dim=512)
+                   .to(device=device, dtype=dtype))
+
+
+def _boundary_step(noise_pred, t, s, latents, prediction_type, alpha_schedule, sigma_schedule, out_dtype):
+    B = len(latents)
+    if latents.is_cuda and prediction_type == "epsilon":
+        from . import ops
+        ti, si = int(t), int(s)
+
+        def make():
+            a_s, s_s = (1.0, 0.0) if si == 0 else (float(alpha_schedule[si]), float(sigma_schedule[si]))
+            row = [float(alpha_schedule[ti]), float(sigma_schedule[ti]), a_s, s_s]
+            return torch.tensor([row] * B, dtype=torch.float32).to(latents.device)
+        coef = _cached(("coef", ti, si, B, str(latents.device), float(alpha_schedule[ti])), make)
+        return ops.x0_step(latents.contiguous(), noise_pred.contiguous(), coef, out_dtype=out_dtype)
+    dev = latents.device
+    return predicted_origin(noise_pred, torch.tensor([t] * B, device=dev), torch.tensor([s] * B, device=dev), latents,
+                            prediction_type, alpha_schedule.to(dev), sigma_schedule.to(dev)).to(out_dtype)
+
+
+# --------------------------------------------------------------------------------------------- forward (inversion)
+def inverse_sample_deterministic(pipe, images, prompt, generator=None, num_scales=50, num_inference_steps=1, timesteps=None,
+                                 start_timestep=19, max_inverse_timestep_index=49, return_start_latent=False,
+                                 guidance_scale=None, compute_embeddings_fn=None, is_sdxl=False, inverse_endpoints=None, seed=0):
+    """Forward consistency model: image latents noised at timesteps[0] -> noise latents (utils/generation_sdxl.py:204-310)."""
+    if prompt is not None and isinstance(prompt, str):
+        batch_size = 1
+    elif prompt is not None and isinstance(prompt, list):
+        batch_size = len(prompt)
+    device = pipe._execution_device
+    prompt_embeds, encoded_text = _text_conditioning(pipe, prompt, compute_embeddings_fn, is_sdxl, device)
+
+    endpoints = ','.join(['0'] + inverse_endpoints.split(',')[:-1]) if inverse_endpoints is not None else None
+    solver = DDIMSolver(pipe.scheduler.alphas_cumprod.cpu().numpy(), timesteps=pipe.scheduler.num_train_timesteps,
+                        ddim_timesteps=num_scales, num_endpoints=num_inference_steps, num_inverse_endpoints=num_inference_steps,
+                        max_inverse_timestep_index=max_inverse_timestep_index, endpoints=endpoints,
+                        inverse_endpoints=inverse_endpoints).to(device)
+    if timesteps is None:
+        timesteps, boundary_timesteps = solver.inverse_endpoints.flip(0), solver.endpoints.flip(0)
+    else:
+        boundary = timesteps[1:] + [999]
+        timesteps, boundary_timesteps = torch.tensor(timesteps), torch.tensor(boundary)
+
+    alpha_schedule = torch.sqrt(pipe.scheduler.alphas_cumprod).cpu()
+    sigma_schedule = torch.sqrt(1 - pipe.scheduler.alphas_cumprod).cpu()
+    start_latents = pipe.prepare_latents(images, timesteps[0], batch_size, 1, prompt_embeds.dtype, device,
+                                         generator=torch.Generator().manual_seed(seed))
+    latents = start_latents.clone()
+    w_embedding = None if guidance_scale is None else _w_embedding([guidance_scale] * batch_size, latents.device, latents.dtype)
+    ptype = pipe.scheduler.config.prediction_type
+    for t, s in zip(timesteps.cpu(), boundary_timesteps.cpu()):
+        noise_pred = pipe.unet(latents.to(prompt_embeds.dtype), t, encoder_hidden_states=prompt_embeds, return_dict=False,
+                               timestep_cond=w_embedding, added_cond_kwargs=encoded_text)[0]
+        latents = _boundary_step(noise_pred, t, s, latents, ptype, alpha_schedule, sigma_schedule, prompt_embeds.dtype)
+    return (latents, start_latents) if return_start_latent else latents
+
+
+# --------------------------------------------------------------------------------------------- reverse (generation)
+@torch.no_grad()
+def sample_deterministic(pipe, prompt, latents=None, generator=None, num_scales=50, num_inference_steps=1, timesteps=None,
+                         start_timestep=19, max_inverse_timestep_index=49, return_latent=False, guidance_scale=None,
+                         compute_embeddings_fn=None, is_sdxl=False, endpoints=None, use_dynamic_guidance=False, tau1=0.7,
+                         tau2=0.7, amplify_prompt=None):
+    """Reverse consistency model: noise latents -> image (utils/generation_sdxl.py:324-473)."""
+    height = pipe.unet.config.sample_size * pipe.vae_scale_factor
+    width = pipe.unet.config.sample_size * pipe.vae_scale_factor
+    if prompt is not None and isinstance(prompt, str):
+        batch_size = 1
+    elif prompt is not None and isinstance(prompt, list):
+        batch_size = len(prompt)
+    device = pipe._execution_device
+    prompt_embeds, encoded_text = _text_conditioning(pipe, prompt, compute_embeddings_fn, is_sdxl, device)
+    amplify_prompt_embeds = None
+    if compute_embeddings_fn is not None and is_sdxl and amplify_prompt is not None:
+        enc_amp = compute_embeddings_fn(amplify_prompt, [(1024, 1024)] * len(amplify_prompt), [(0, 0)] * len(amplify_prompt))
+        amplify_prompt_embeds = enc_amp.pop("prompt_embeds")
+
+    inverse_endpoints = ','.join(endpoints.split(',')[1:] + ['999']) if endpoints is not None else None
+    ac = pipe.scheduler.alphas_cumprod
+    solver = DDIMSolver(ac.cpu().numpy(), timesteps=pipe.scheduler.num_train_timesteps, ddim_timesteps=num_scales,
+                        num_endpoints=num_inference_steps, num_inverse_endpoints=num_inference_steps,
+                        max_inverse_timestep_index=max_inverse_timestep_index, endpoints=endpoints,
+                        inverse_endpoints=inverse_endpoints).to(device)
+    prompt_embeds_init = copy.deepcopy(prompt_embeds)
+    if timesteps is None:
+        timesteps, boundary_timesteps = solver.inverse_endpoints.flip(0), solver.endpoints.flip(0)
+    else:
+        ts = list(reversed(timesteps))                      # the caller's list is left untouched (deepcopy in the reference)
+        timesteps, boundary_timesteps = torch.tensor(ts), torch.tensor(ts[1:] + [0])
+
+    alpha_schedule, sigma_schedule = torch.sqrt(ac).cpu(), torch.sqrt(1 - ac).cpu()
+    if latents is None:
+        latents = pipe.prepare_latents(batch_size, pipe.unet.config.in_channels, height, width, prompt_embeds.dtype, device,
+                                       generator, None)
+        assert latents.dtype == pipe.unet.dtype
+    else:
+        latents = latents.to(prompt_embeds.dtype)
+    w_embedding = None if guidance_scale is None else _w_embedding([guidance_scale] * batch_size, latents.device, latents.dtype)
+    ptype = pipe.scheduler.config.prediction_type
+    for t, s in zip(timesteps.cpu(), boundary_timesteps.cpu()):
+        if use_dynamic_guidance:
+            t_item = t if isinstance(t, int) else t.item()
+            if t_item > tau1 * 1000 and amplify_prompt is not None:
+                prompt_embeds = amplify_prompt_embeds
+            else:
+                prompt_embeds = prompt_embeds_init
+            # same fp32 arithmetic as the reference's `gamma * (ones(B) * guidance_scale)`, one scalar for the batch
+            gs_t = float(linear_schedule_old(t_item, torch.ones(1) * guidance_scale, tau1=tau1, tau2=tau2)[0])
+            w_embedding = _w_embedding([gs_t] * len(latents), latents.device, latents.dtype)
+        noise_pred = pipe.unet(latents, t, encoder_hidden_states=prompt_embeds, cross_attention_kwargs=None, return_dict=False,
+                               timestep_cond=w_embedding, added_cond_kwargs=encoded_text)[0]
+        latents = _boundary_step(noise_pred, t, s, latents, ptype, alpha_schedule, sigma_schedule, pipe.unet.dtype)
+
+    vae = getattr(pipe, "vae", None)
+    if vae is None:          # VAE decode is outside this path: hand the latents back
+        image = latents
+    else:
+        vae.to(torch.float32)
+        image = vae.decode(latents.to(torch.float32) / vae.config.scaling_factor, return_dict=False)[0]
+        image = pipe.image_processor.postprocess(image, output_type="pil", do_denormalize=[True] * image.shape[0])
+    return (image, latents) if return_latent else image

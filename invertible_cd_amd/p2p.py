@@ -1,0 +1,414 @@
+"""Prompt-to-prompt attention-control plugin for the native UNet (API mirror of the reference's utils/p2p.py).
+
+Same module globals (NUM_DDIM_STEPS / tokenizer / device / LOW_RESOURCE / MAX_NUM_WORDS, utils/p2p.py:9-13), same classes
+(AttentionStore, AttentionReplace, AttentionRefine, AttentionReweight, LocalBlend, EmptyControl, SpatialReplace) and the
+same entry points (register_attention_control, make_controller, get_equalizer, get_word_inds,
+get_time_words_attention_alpha).  Semantics are pinned by golden vectors captured from the reference
+(tests/golden/p2p.npz, tests/test_p2p_golden.py).
+
+What is different underneath: the reference monkey-patches every diffusers `Attention.forward` (utils/p2p.py:291-386).
+Here `register_attention_control` hands the controller to the native executor, which calls back (C ABI hook,
+include/icd_amd.h) once per Attention module in module-execution order; `HookAdapter` decides per layer whether the
+probabilities must be materialised at all:
+  * layers the controller does not read or edit (`needs_probs` False, e.g. N > 32^2 self-attention for every shipped
+    controller, utils/p2p.py:147,184-188) run the fused flash kernel and only tick the controller's counters;
+  * when the sampler eliminated the dead unconditional half of the CFG batch (utils/generation.py:247-251 discards it
+    when w_embed_dim > 0) the controller's `forward` - which in the reference only ever sees the conditional half,
+    utils/p2p.py:106-107 - is applied to the whole (cond-only) tensor.
+"""
+import abc
+from typing import Dict, List, Optional, Tuple, Union
+
+import numpy as np
+import torch
+import torch.nn.functional as nnf
+
+from . import seq_aligner
+
+MAX_NUM_WORDS = 77
+LOW_RESOURCE = False
+NUM_DDIM_STEPS = 50
+device = "cuda"
+tokenizer = None
+
+
+# ------------------------------------------------------------------------------------------- latent blending
+class LocalBlend:
+    """Word-localised latent blending from the accumulated 16x16 cross-attention maps (utils/p2p.py:18-70)."""
+
+    def __init__(self, prompts: List[str], words, substruct_words=None, start_blend=0.2, th=(.3, .3)):
+        self.alpha_layers = self._word_mask(prompts, words).to(device)
+        self.substruct_layers = None if substruct_words is None else self._word_mask(prompts, substruct_words).to(device)
+        self.start_blend = int(start_blend * NUM_DDIM_STEPS)
+        self.counter = 0
+        self.th = th
+
+    @staticmethod
+    def _word_mask(prompts, words):
+        mask = torch.zeros(len(prompts), 1, 1, 1, 1, MAX_NUM_WORDS)
+        for i, (prompt, ws) in enumerate(zip(prompts, words)):
+            for w in ([ws] if isinstance(ws, str) else ws):
+                mask[i, :, :, :, :, get_word_inds(prompt, w, tokenizer)] = 1
+        return mask
+
+    def get_mask(self, maps, alpha, use_pool, x_t):
+        k = 1
+        m = (maps * alpha).sum(-1).mean(1)
+        if use_pool:
+            m = nnf.max_pool2d(m, (2 * k + 1, 2 * k + 1), (1, 1), padding=(k, k))
+        m = nnf.interpolate(m, size=(x_t.shape[2:]))
+        m = m / m.max(2, keepdims=True)[0].max(3, keepdims=True)[0]
+        m = m.gt(self.th[1 - int(use_pool)])
+        return m[:1] + m
+
+    def __call__(self, x_t, attention_store):
+        self.counter += 1
+        if self.counter <= self.start_blend:
+            return x_t
+        picked = attention_store["down_cross"][2:4] + attention_store["up_cross"][:3]
+        maps = torch.cat([m.reshape(self.alpha_layers.shape[0], -1, 1, 16, 16, MAX_NUM_WORDS) for m in picked], dim=1)
+        mask = self.get_mask(maps, self.alpha_layers, True, x_t)
+        if self.substruct_layers is not None:
+            mask = mask * ~self.get_mask(maps, self.substruct_layers, False, x_t)
+        mask = mask.float()
+        return x_t[:1] + mask * (x_t - x_t[:1])
+
+
+# ------------------------------------------------------------------------------------------- controllers
+class EmptyControl:
+    def step_callback(self, x_t):
+        return x_t
+
+    def between_steps(self):
+        return
+
+    def needs_probs(self, is_cross, n_queries, place_in_unet):
+        return False
+
+    def __call__(self, attn, is_cross: bool, place_in_unet: str):
+        return attn
+
+
+class AttentionControl(abc.ABC):
+    """Counter logic of utils/p2p.py:85-122.  `forward` receives the conditional rows only."""
+
+    def __init__(self):
+        self.cur_step = 0
+        self.num_att_layers = -1
+        self.cur_att_layer = 0
+
+    def step_callback(self, x_t):
+        return x_t
+
+    def between_steps(self):
+        return
+
+    @property
+    def num_uncond_att_layers(self):
+        return self.num_att_layers if LOW_RESOURCE else 0
+
+    @abc.abstractmethod
+    def forward(self, attn, is_cross: bool, place_in_unet: str):
+        raise NotImplementedError
+
+    def needs_probs(self, is_cross, n_queries, place_in_unet):
+        """May `forward` read or modify the probabilities of such a layer?  Unknown subclasses: always."""
+        return True
+
+    def _advance(self):
+        self.cur_att_layer += 1
+        if self.cur_att_layer == self.num_att_layers + self.num_uncond_att_layers:
+            self.cur_att_layer = 0
+            self.cur_step += 1
+            self.between_steps()
+
+    def __call__(self, attn, is_cross: bool, place_in_unet: str):
+        """CFG-doubled layout [uncond rows ; cond rows] (utils/p2p.py:101-113): edit the second half in place."""
+        if self.cur_att_layer >= self.num_uncond_att_layers:
+            if LOW_RESOURCE:
+                attn = self.forward(attn, is_cross, place_in_unet)
+            else:
+                half = attn.shape[0] // 2
+                attn[half:] = self.forward(attn[half:], is_cross, place_in_unet)
+        self._advance()
+        return attn
+
+    def call_cond_only(self, attn, is_cross: bool, place_in_unet: str):
+        """The whole tensor is the conditional half (dead unconditional rows were never computed)."""
+        if self.cur_att_layer >= self.num_uncond_att_layers:
+            new = self.forward(attn, is_cross, place_in_unet)
+            if new is not attn:
+                attn.copy_(new)
+        self._advance()
+        return attn
+
+    def tick(self):
+        """A layer whose probabilities this controller neither reads nor edits was executed (fused kernel)."""
+        self._advance()
+
+    def reset(self):
+        self.cur_step = 0
+        self.cur_att_layer = 0
+
+
+class SpatialReplace(EmptyControl):
+    def __init__(self, stop_inject: float):
+        super().__init__()
+        self.stop_inject = int((1 - stop_inject) * NUM_DDIM_STEPS)
+
+    def step_callback(self, x_t):
+        if self.cur_step < self.stop_inject:
+            x_t = x_t[:1].expand(x_t.shape[0], *x_t.shape[1:])
+        return x_t
+
+
+class AttentionStore(AttentionControl):
+    """Keeps (views of) the conditional probabilities of every layer with <= 32^2 queries and sums them over steps
+    (utils/p2p.py:138-173)."""
+
+    STORE_MAX_QUERIES = 32 ** 2
+
+    def __init__(self):
+        super().__init__()
+        self.step_store = self.get_empty_store()
+        self.attention_store = {}
+
+    @staticmethod
+    def get_empty_store():
+        return {f"{place}_{kind}": [] for kind in ("cross", "self") for place in ("down", "mid", "up")}
+
+    def needs_probs(self, is_cross, n_queries, place_in_unet):
+        return n_queries <= self.STORE_MAX_QUERIES
+
+    def forward(self, attn, is_cross: bool, place_in_unet: str):
+        if attn.shape[1] <= self.STORE_MAX_QUERIES:
+            self.step_store[f"{place_in_unet}_{'cross' if is_cross else 'self'}"].append(attn)
+        return attn
+
+    def between_steps(self):
+        if not self.attention_store:
+            self.attention_store = self.step_store
+        else:
+            for key, acc in self.attention_store.items():
+                for i, t in enumerate(acc):
+                    t += self.step_store[key][i]
+        self.step_store = self.get_empty_store()
+
+    def get_average_attention(self):
+        return {key: [t / self.cur_step for t in ts] for key, ts in self.attention_store.items()}
+
+    def reset(self):
+        super().reset()
+        self.step_store = self.get_empty_store()
+        self.attention_store = {}
+
+
+class AttentionControlEdit(AttentionStore, abc.ABC):
+    """Cross/self attention injection between a base prompt (row group 0) and its edits (utils/p2p.py:176-221)."""
+
+    def __init__(self, prompts, num_steps: int, cross_replace_steps, self_replace_steps, local_blend: Optional[LocalBlend]):
+        super().__init__()
+        self.batch_size = len(prompts)
+        self.cross_replace_alpha = get_time_words_attention_alpha(prompts, num_steps, cross_replace_steps, tokenizer).to(device)
+        if type(self_replace_steps) is float:
+            self_replace_steps = 0, self_replace_steps
+        self.num_self_replace = int(num_steps * self_replace_steps[0]), int(num_steps * self_replace_steps[1])
+        self.local_blend = local_blend
+
+    def needs_probs(self, is_cross, n_queries, place_in_unet):
+        return is_cross or n_queries <= self.STORE_MAX_QUERIES
+
+    def step_callback(self, x_t):
+        return x_t if self.local_blend is None else self.local_blend(x_t, self.attention_store)
+
+    def replace_self_attention(self, attn_base, att_replace, place_in_unet):
+        if att_replace.shape[2] > self.STORE_MAX_QUERIES:
+            return att_replace
+        return attn_base.unsqueeze(0).expand(att_replace.shape[0], *attn_base.shape)
+
+    @abc.abstractmethod
+    def replace_cross_attention(self, attn_base, att_replace):
+        raise NotImplementedError
+
+    def forward(self, attn, is_cross: bool, place_in_unet: str):
+        super().forward(attn, is_cross, place_in_unet)          # stores a VIEW: the stored tensor sees the edit below
+        in_self_window = self.num_self_replace[0] <= self.cur_step < self.num_self_replace[1]
+        if not (is_cross or in_self_window):
+            return attn
+        heads = attn.shape[0] // self.batch_size
+        grouped = attn.reshape(self.batch_size, heads, *attn.shape[1:])
+        base, edits = grouped[0], grouped[1:]
+        if is_cross:
+            a = self.cross_replace_alpha[self.cur_step]
+            grouped[1:] = self.replace_cross_attention(base, edits) * a + (1 - a) * edits
+        else:
+            grouped[1:] = self.replace_self_attention(base, edits, place_in_unet)
+        return grouped.reshape(self.batch_size * heads, *grouped.shape[2:])
+
+
+class AttentionReplace(AttentionControlEdit):
+    def __init__(self, prompts, num_steps: int, cross_replace_steps, self_replace_steps, local_blend: Optional[LocalBlend] = None):
+        super().__init__(prompts, num_steps, cross_replace_steps, self_replace_steps, local_blend)
+        self.mapper = seq_aligner.get_replacement_mapper(prompts, tokenizer).to(device)
+
+    def replace_cross_attention(self, attn_base, att_replace):
+        return torch.einsum("hpw,bwn->bhpn", attn_base, self.mapper.to(attn_base.dtype))
+
+
+class AttentionRefine(AttentionControlEdit):
+    def __init__(self, prompts, num_steps: int, cross_replace_steps, self_replace_steps, local_blend: Optional[LocalBlend] = None):
+        super().__init__(prompts, num_steps, cross_replace_steps, self_replace_steps, local_blend)
+        mapper, alphas = seq_aligner.get_refinement_mapper(prompts, tokenizer)
+        self.mapper = mapper.to(device)
+        self.alphas = alphas.to(device).reshape(alphas.shape[0], 1, 1, alphas.shape[1])
+
+    def replace_cross_attention(self, attn_base, att_replace):
+        gathered = attn_base[:, :, self.mapper].permute(2, 0, 1, 3)
+        return gathered * self.alphas + att_replace * (1 - self.alphas)
+
+
+class AttentionReweight(AttentionControlEdit):
+    def __init__(self, prompts, num_steps: int, cross_replace_steps, self_replace_steps, equalizer,
+                 local_blend: Optional[LocalBlend] = None, controller: Optional[AttentionControlEdit] = None):
+        super().__init__(prompts, num_steps, cross_replace_steps, self_replace_steps, local_blend)
+        self.equalizer = equalizer.to(device)
+        self.prev_controller = controller
+        self.attn = []
+
+    def replace_cross_attention(self, attn_base, att_replace):
+        if self.prev_controller is not None:
+            attn_base = self.prev_controller.replace_cross_attention(attn_base, att_replace)
+        return attn_base[None, :, :, :] * self.equalizer[:, None, None, :]
+
+
+def make_controller(prompts: List[str], is_replace_controller: bool, cross_replace_steps, self_replace_steps,
+                    blend_words=None, equilizer_params=None) -> AttentionControlEdit:
+    """utils/p2p.py:272-289 (argument names kept, incl. `equilizer_params`)."""
+    lb = None if blend_words is None else LocalBlend(prompts, blend_words, start_blend=0.0, th=(0.3, 0.3))
+    cls = AttentionReplace if is_replace_controller else AttentionRefine
+    controller = cls(prompts, NUM_DDIM_STEPS, cross_replace_steps=cross_replace_steps, self_replace_steps=self_replace_steps,
+                     local_blend=lb)
+    if equilizer_params is not None:
+        eq = get_equalizer(prompts[1], equilizer_params["words"], equilizer_params["values"])
+        controller = AttentionReweight(prompts, NUM_DDIM_STEPS, cross_replace_steps=cross_replace_steps,
+                                       self_replace_steps=self_replace_steps, equalizer=eq, local_blend=lb, controller=controller)
+    return controller
+
+
+# ------------------------------------------------------------------------------------------- registration
+class DummyController:
+    """What the reference installs for `controller=None` (utils/p2p.py:356-365)."""
+
+    def __init__(self):
+        self.num_att_layers = 0
+
+    def __call__(self, *args):
+        return args[0]
+
+
+def register_attention_control(model, controller):
+    """Attach `controller` to `model.unet` (utils/p2p.py:291-386).  Sets controller.num_att_layers to the number of
+    Attention modules (32 for SD1.5, 140 for SDXL), exactly as the reference's module walk does."""
+    if controller is None:
+        controller = DummyController()
+    unet = model.unet
+    if hasattr(unet, "num_attention_layers"):
+        unet.attn_controller = None if isinstance(controller, DummyController) else controller
+        controller.num_att_layers = unet.num_attention_layers
+    else:        # a foreign UNet object (e.g. a stub in tests): nothing to hook, the reference would count 0 modules
+        controller.num_att_layers = 0
+
+
+class HookAdapter:
+    """Bridges the executor's C callback (query / probs-ready per Attention module) to a controller object."""
+
+    def __init__(self, controller, cond_only: bool, dev):
+        self.c = controller
+        self.cond_only = cond_only
+        self.dev = dev
+        self.native = isinstance(controller, (AttentionControl, EmptyControl))
+        self.pending = None
+
+    def query(self, layer, is_cross, place, bh, nq, nk, ld):
+        c = self.c
+        if self.native and not c.needs_probs(is_cross, nq, place):
+            if isinstance(c, AttentionControl):
+                c.tick()
+            return None
+        # a FRESH buffer per layer call: AttentionStore keeps views of it alive across steps (utils/p2p.py:148,153-157)
+        buf = torch.empty((bh, nq, ld), dtype=torch.float16, device=self.dev)
+        self.pending = buf[:, :, :nk]
+        return buf
+
+    def probs_ready(self, layer, is_cross, place):
+        view, self.pending = self.pending, None
+        c = self.c
+        if self.cond_only and isinstance(c, AttentionControl):
+            c.call_cond_only(view, is_cross, place)
+            return
+        out = c(view, is_cross, place)
+        if out is not None and out is not view:
+            view.copy_(out)
+
+
+# ------------------------------------------------------------------------------------------- word / schedule helpers
+def get_word_inds(text: str, word_place, tokenizer):
+    """Token positions (1-based, after BOS) of a word given by value or by index (utils/p2p.py:422-440)."""
+    words = text.split(" ")
+    if type(word_place) is str:
+        word_place = [i for i, w in enumerate(words) if w == word_place]
+    elif type(word_place) is int:
+        word_place = [word_place]
+    found = []
+    if len(word_place) > 0:
+        pieces = [tokenizer.decode([tok]).strip("#") for tok in tokenizer.encode(text)][1:-1]
+        consumed, wi = 0, 0
+        for ti, piece in enumerate(pieces):
+            consumed += len(piece)
+            if wi in word_place:
+                found.append(ti + 1)
+            if consumed >= len(words[wi]):
+                wi += 1
+                consumed = 0
+    return np.array(found)
+
+
+def update_alpha_time_word(alpha, bounds, prompt_ind: int, word_inds: Optional[torch.Tensor] = None):
+    if type(bounds) is float:
+        bounds = 0, bounds
+    start, end = int(bounds[0] * alpha.shape[0]), int(bounds[1] * alpha.shape[0])
+    if word_inds is None:
+        word_inds = torch.arange(alpha.shape[2])
+    alpha[:start, prompt_ind, word_inds] = 0
+    alpha[start:end, prompt_ind, word_inds] = 1
+    alpha[end:, prompt_ind, word_inds] = 0
+    return alpha
+
+
+def get_time_words_attention_alpha(prompts, num_steps, cross_replace_steps, tokenizer, max_num_words=77):
+    """[num_steps+1, n_edits, 1, 1, 77] step/word gate of the cross-attention injection (utils/p2p.py:402-420)."""
+    if type(cross_replace_steps) is not dict:
+        cross_replace_steps = {"default_": cross_replace_steps}
+    if "default_" not in cross_replace_steps:
+        cross_replace_steps["default_"] = (0., 1.)
+    n_edits = len(prompts) - 1
+    alpha = torch.zeros(num_steps + 1, n_edits, max_num_words)
+    for i in range(n_edits):
+        alpha = update_alpha_time_word(alpha, cross_replace_steps["default_"], i)
+    for word, bounds in cross_replace_steps.items():
+        if word == "default_":
+            continue
+        for i in range(n_edits):
+            ind = get_word_inds(prompts[i + 1], word, tokenizer)
+            if len(ind) > 0:
+                alpha = update_alpha_time_word(alpha, bounds, i, ind)
+    return alpha.reshape(num_steps + 1, n_edits, 1, 1, max_num_words)
+
+
+def get_equalizer(text: str, word_select, values):
+    if type(word_select) is int or type(word_select) is str:
+        word_select = (word_select,)
+    eq = torch.ones(1, 77)
+    for word, val in zip(word_select, values):
+        eq[:, get_word_inds(text, word, tokenizer)] = val
+    return eq

@@ -1,0 +1,287 @@
+"""UNet2DConditionModel - the duck type the iCD sampler calls, backed by the native MI355X executor.
+
+Mirrors what the reference touches on diffusers' class: callable
+`unet(sample, t, encoder_hidden_states=, timestep_cond=, added_cond_kwargs=, return_dict=)` returning an object with
+`.sample` / `["sample"]` / `[0]`, plus `.dtype`, `.in_channels`, `.config`, `.named_children()`, `.to()`.
+Reference call sites: utils/generation.py:208,241-244; utils/generation_sdxl.py:288-295,445-453.
+
+All arithmetic happens in libicd_amd.so (HIP, gfx950); torch is used for device memory, streams and the weight
+re-layout at load time.  There is no CPU fallback: constructing this class without the built extension or without a GPU
+raises.
+"""
+import ctypes as C
+import types
+
+import torch
+
+from . import _lib
+from .ops import geglu_perm
+from .unet_config import UNetConfig
+
+PLACES = ("down", "mid", "up")
+
+
+class UNetOutput:
+    """Stands in for diffusers' UNet2DConditionOutput: `.sample`, ["sample"], [0]."""
+
+    def __init__(self, sample):
+        self.sample = sample
+
+    def __getitem__(self, k):
+        if k == "sample" or k == 0:
+            return self.sample
+        raise KeyError(k)
+
+    def __iter__(self):
+        return iter((self.sample,))
+
+
+def pack_state_dict(cfg: UNetConfig, sd, device):
+    """diffusers-layout state dict -> the packed tensors the native executor binds (fp16 weights, fp32 bias/norm).
+
+      conv [O,I,k,k]      -> [O, k*k*I]  (tap-major K of the implicit GEMM; 1x1 convs become plain [O,I])
+      attn1.to_q/to_k     -> attn1.to_qk [2C, C]   (one GEMM, q|k column blocks)
+      ff.net.0.proj       -> rows interleaved 32 value / 32 gate so GEGLU is applied in the GEMM epilogue
+      *.time_emb_proj     -> ONE [sum(Cout), 4*ch0] matrix in execution order (all resnets' time biases in one GEMM)
+    """
+    packed = {}
+
+    def w16(t):
+        return t.to(device=device, dtype=torch.float16).contiguous()
+
+    def f32(t):
+        return t.to(device=device, dtype=torch.float32).contiguous()
+
+    consumed = set()
+
+    def take(k):
+        consumed.add(k)
+        return sd[k]
+
+    def conv(name):
+        w = take(name + ".weight")
+        packed[name + ".weight"] = w16(w.permute(0, 2, 3, 1).reshape(w.shape[0], -1)) if w.dim() == 4 else w16(w)
+        packed[name + ".bias"] = f32(take(name + ".bias"))
+
+    def dense(name, bias=True):
+        w = take(name + ".weight")
+        packed[name + ".weight"] = w16(w.reshape(w.shape[0], -1))
+        if bias:
+            packed[name + ".bias"] = f32(take(name + ".bias"))
+
+    def affine(name):
+        packed[name + ".weight"] = f32(take(name + ".weight"))
+        packed[name + ".bias"] = f32(take(name + ".bias"))
+
+    conv("conv_in")
+    dense("time_embedding.linear_1")
+    dense("time_embedding.linear_2")
+    if cfg.time_cond_proj_dim:
+        dense("time_embedding.cond_proj", bias=False)
+    if cfg.add_in_dim:
+        dense("add_embedding.linear_1")
+        dense("add_embedding.linear_2")
+    tw, tb = [], []
+    for p, ci, co in cfg.resnet_names():
+        affine(p + ".norm1")
+        conv(p + ".conv1")
+        affine(p + ".norm2")
+        conv(p + ".conv2")
+        if ci != co:
+            conv(p + ".conv_shortcut")
+        tw.append(take(p + ".time_emb_proj.weight"))
+        tb.append(take(p + ".time_emb_proj.bias"))
+    packed["time_emb_proj_cat.weight"] = w16(torch.cat([t.to(device) for t in tw], 0))
+    packed["time_emb_proj_cat.bias"] = f32(torch.cat([t.to(device) for t in tb], 0))
+    for p, c, depth, _, _ in cfg.transformer_names():
+        affine(p + ".norm")
+        dense(p + ".proj_in")
+        dense(p + ".proj_out")
+        perm = geglu_perm(4 * c).to(device)
+        for k in range(depth):
+            b = f"{p}.transformer_blocks.{k}"
+            for n in ("norm1", "norm2", "norm3"):
+                affine(f"{b}.{n}")
+            packed[f"{b}.attn1.to_qk.weight"] = w16(torch.cat([take(f"{b}.attn1.to_q.weight").to(device),
+                                                               take(f"{b}.attn1.to_k.weight").to(device)], 0))
+            dense(f"{b}.attn1.to_v", bias=False)
+            dense(f"{b}.attn1.to_out.0")
+            dense(f"{b}.attn2.to_q", bias=False)
+            dense(f"{b}.attn2.to_k", bias=False)
+            dense(f"{b}.attn2.to_v", bias=False)
+            dense(f"{b}.attn2.to_out.0")
+            packed[f"{b}.ff.net.0.proj.weight"] = w16(take(f"{b}.ff.net.0.proj.weight").to(device)[perm])
+            packed[f"{b}.ff.net.0.proj.bias"] = f32(take(f"{b}.ff.net.0.proj.bias").to(device)[perm])
+            dense(f"{b}.ff.net.2")
+    for i in range(cfg.num_levels - 1):
+        conv(f"down_blocks.{i}.downsamplers.0.conv")
+        conv(f"up_blocks.{i}.upsamplers.0.conv")
+    affine("conv_norm_out")
+    conv("conv_out")
+    missing = set(cfg.state_dict_shapes()) - consumed
+    if missing:
+        raise KeyError(f"state dict keys not consumed by the packer: {sorted(missing)[:5]}")
+    return packed
+
+
+class UNet2DConditionModel:
+    def __init__(self, cfg: UNetConfig, state_dict, device="cuda", dtype=torch.float16):
+        if not torch.cuda.is_available():
+            raise RuntimeError("invertible_cd_amd.UNet2DConditionModel needs an MI355X (no CPU fallback on the product path)")
+        self._lib = _lib.load()
+        self.cfg = cfg
+        self.device = torch.device(device)
+        self.dtype = dtype                       # I/O dtype seen by the sampler (compute is fp16 x fp16 -> fp32 accumulate)
+        self.in_channels = cfg.in_channels
+        self.config = types.SimpleNamespace(in_channels=cfg.in_channels, out_channels=cfg.out_channels,
+                                            sample_size=cfg.sample_size, time_cond_proj_dim=cfg.time_cond_proj_dim,
+                                            cross_attention_dim=cfg.cross_dim, block_out_channels=cfg.block_out_channels,
+                                            addition_time_embed_dim=cfg.addition_time_embed_dim or None)
+        shapes = cfg.state_dict_shapes()
+        for k, s in shapes.items():
+            if k not in state_dict:
+                raise KeyError(f"state dict is missing '{k}'")
+            if tuple(state_dict[k].shape) != tuple(s):
+                raise ValueError(f"state dict tensor '{k}' has shape {tuple(state_dict[k].shape)}, expected {s}")
+        self._packed = pack_state_dict(cfg, state_dict, self.device)
+        c = _lib.UNetConfig()
+        c.in_channels, c.out_channels, c.num_levels = cfg.in_channels, cfg.out_channels, cfg.num_levels
+        for i in range(cfg.num_levels):
+            c.block_out_channels[i] = cfg.block_out_channels[i]
+            c.down_has_attn[i] = int(cfg.down_has_attn[i])
+            c.up_has_attn[i] = int(cfg.up_has_attn[i])
+            c.transformer_layers[i] = cfg.transformer_layers[i]
+            c.num_heads[i] = cfg.num_heads[i]
+        c.layers_per_block, c.cross_dim = cfg.layers_per_block, cfg.cross_dim
+        c.use_linear_projection = int(cfg.use_linear_projection)
+        c.time_cond_proj_dim, c.addition_time_embed_dim = cfg.time_cond_proj_dim, cfg.addition_time_embed_dim
+        c.add_in_dim, c.norm_groups = cfg.add_in_dim, cfg.norm_groups
+        h = C.c_void_p()
+        _lib.check(self._lib.icd_unet_create(C.byref(c), C.byref(h)), "icd_unet_create")
+        self._h = h
+        for name, t in self._packed.items():
+            _lib.check(self._lib.icd_unet_set_tensor(h, name.encode(), C.c_void_p(t.data_ptr()),
+                                                     0 if t.dtype == torch.float16 else 1, t.numel()), "icd_unet_set_tensor")
+        _lib.check(self._lib.icd_unet_finalize(h), "icd_unet_finalize")
+        self.num_attention_layers = self._lib.icd_unet_num_attention_layers(h)
+        assert self.num_attention_layers == cfg.num_attention_layers
+        self._ws = None
+        self._ws_key = None
+        # p2p plugin state (set by p2p.register_attention_control / Generator.get_noise_pred)
+        self.attn_controller = None
+        self.attn_cond_only = False
+        self._live = []
+
+    # ------------------------------------------------------------------ duck-typed nn.Module surface
+    def named_children(self):
+        return []
+
+    def to(self, *args, **kwargs):
+        for a in list(args) + list(kwargs.values()):
+            if isinstance(a, torch.dtype):
+                self.dtype = a
+        return self
+
+    def eval(self):
+        return self
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                self._lib.icd_unet_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ forward
+    def _workspace(self, B, H, W, n_ctx):
+        key = (B, H, W, n_ctx)
+        if self._ws_key != key:
+            nbytes = self._lib.icd_unet_workspace_bytes(self._h, B, H, W, n_ctx)
+            if nbytes <= 0:
+                raise RuntimeError("icd_unet_workspace_bytes failed")
+            self._ws = None
+            self._ws = torch.empty((nbytes,), dtype=torch.uint8, device=self.device)
+            self._ws_key = key
+        return self._ws
+
+    def _make_hook(self, errors):
+        ctrl = self.attn_controller
+        if ctrl is None:
+            return _lib.ATTN_HOOK(0)
+        from . import p2p
+        adapter = p2p.HookAdapter(ctrl, self.attn_cond_only, self.device)
+        live = self._live
+
+        def hook(user, phase, layer, is_cross, place, bh, nq, nk, ld, probs_pp):
+            try:
+                if phase == _lib.ICD_HOOK_QUERY:
+                    buf = adapter.query(layer, bool(is_cross), PLACES[place], bh, nq, nk, ld)
+                    if buf is None:
+                        return 0
+                    live.append(buf)
+                    probs_pp[0] = buf.data_ptr()
+                    return 1
+                adapter.probs_ready(layer, bool(is_cross), PLACES[place])
+                return 0
+            except BaseException as e:       # never let an exception cross the C boundary
+                errors.append(e)
+                return -1
+        return _lib.ATTN_HOOK(hook)
+
+    @torch.no_grad()
+    def __call__(self, sample, timestep, encoder_hidden_states=None, class_labels=None, timestep_cond=None,
+                 attention_mask=None, cross_attention_kwargs=None, added_cond_kwargs=None, return_dict=True, **kwargs):
+        if encoder_hidden_states is None:
+            raise ValueError("encoder_hidden_states is required")
+        if sample.dim() != 4 or sample.shape[1] != self.cfg.in_channels:
+            raise ValueError(f"sample must be [B,{self.cfg.in_channels},H,W], got {tuple(sample.shape)}")
+        dev = self.device
+        io_dtype = sample.dtype if sample.dtype in (torch.float16, torch.float32) else torch.float16
+        x = sample.to(device=dev, dtype=io_dtype).contiguous()
+        B, _, H, W = x.shape
+        if torch.is_tensor(timestep):
+            t = timestep.to(device=dev, dtype=torch.float32).reshape(-1)
+        else:
+            t = torch.tensor([float(timestep)], device=dev, dtype=torch.float32)
+        t = t.expand(B).contiguous() if t.numel() == 1 else t.contiguous()
+        ctx = encoder_hidden_states.to(device=dev, dtype=torch.float16).contiguous()
+        if ctx.shape[0] != B or ctx.shape[2] != self.cfg.cross_dim:
+            raise ValueError(f"encoder_hidden_states must be [{B}, n, {self.cfg.cross_dim}], got {tuple(ctx.shape)}")
+        n_ctx = ctx.shape[1]
+        io = _lib.UNetIO()
+        keep = [x, t, ctx]
+        if timestep_cond is not None:
+            if not self.cfg.time_cond_proj_dim:
+                raise ValueError("this UNet has no time_cond_proj (w-embedding) input")
+            cond = timestep_cond.to(device=dev, dtype=torch.float16).contiguous()
+            if tuple(cond.shape) != (B, self.cfg.time_cond_proj_dim):
+                raise ValueError(f"timestep_cond must be [{B}, {self.cfg.time_cond_proj_dim}]")
+            keep.append(cond)
+            io.timestep_cond = cond.data_ptr()
+        if self.cfg.addition_time_embed_dim:
+            if not added_cond_kwargs or "text_embeds" not in added_cond_kwargs or "time_ids" not in added_cond_kwargs:
+                raise ValueError("SDXL UNet needs added_cond_kwargs={'text_embeds','time_ids'}")
+            te = added_cond_kwargs["text_embeds"].to(device=dev, dtype=torch.float16).contiguous()
+            ti = added_cond_kwargs["time_ids"].to(device=dev, dtype=torch.float32).contiguous()
+            keep += [te, ti]
+            io.text_embeds, io.time_ids = te.data_ptr(), ti.data_ptr()
+        eps = torch.empty_like(x)
+        ws = self._workspace(B, H, W, n_ctx)
+        errors = []
+        hook = self._make_hook(errors)
+        io.sample, io.timesteps, io.context, io.eps = x.data_ptr(), t.data_ptr(), ctx.data_ptr(), eps.data_ptr()
+        io.workspace, io.workspace_bytes = ws.data_ptr(), ws.numel()
+        io.batch, io.H, io.W, io.n_ctx = B, H, W, n_ctx
+        io.sample_is_f32 = int(io_dtype == torch.float32)
+        io.hook = hook
+        rc = self._lib.icd_unet_forward(self._h, C.byref(io), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        self._live.clear()
+        if errors:
+            raise errors[0]
+        _lib.check(rc, "icd_unet_forward")
+        if not return_dict:
+            return (eps,)
+        return UNetOutput(eps)
+
+    forward = __call__

@@ -1,0 +1,68 @@
+"""Multi-process data-parallel path on CPU (gloo, world_size 2): prompt sharding matches the reference's
+prepare_val_prompts partitions and the single end-of-run all-gather reassembles the global order."""
+import json
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, golden_dir, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world))
+    from invertible_cd_amd import dist_utils
+    dist_utils.init(backend="gloo")
+    assert dist_utils.get_world_size() == world and dist_utils.get_rank() == rank
+    gold = [e for e in json.load(open(os.path.join(golden_dir, "sharding.json"))) if e["W"] == world and e["rank"] == rank]
+    ok = True
+    for e in gold:
+        texts = [f"p{i}" for i in range(e["N"])]
+        batches, index, allt = dist_utils.prepare_val_prompts(texts, bs=e["bs"], max_cnt=5000)
+        ok &= [list(map(int, b)) for b in index] == e["index"]
+        ok &= [list(map(str, b)) for b in batches] == e["batches"]
+    # each rank "generates" its shard (sample i is filled with the value i), then ONE gather + reorder
+    texts = [f"p{i}" for i in range(32)]
+    _, index, _ = dist_utils.prepare_val_prompts(texts, bs=4, max_cnt=5000)
+    ids = torch.tensor(np.concatenate(index), dtype=torch.int64)
+    local = ids.to(torch.float16).reshape(-1, 1, 1, 1).expand(-1, 4, 8, 8).contiguous()
+    allx, alli = dist_utils.gather_samples(local, ids)
+    ok &= alli.tolist() == list(range(32))
+    ok &= bool((allx[:, 0, 0, 0].float() == torch.arange(32).float()).all())
+    dist.barrier()
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_sharding_and_gather_world2(golden_dir):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, golden_dir, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == [(0, True), (1, True)]
+
+
+def test_single_process_defaults(golden_dir):
+    from invertible_cd_amd import dist_utils
+    assert dist_utils.get_world_size() == 1 and dist_utils.get_rank() == 0
+    for e in json.load(open(os.path.join(golden_dir, "sharding.json"))):
+        if e["W"] == 1:
+            b, idx, _ = dist_utils.prepare_val_prompts([f"p{i}" for i in range(e["N"])], bs=e["bs"])
+            assert [list(map(int, x)) for x in idx] == e["index"]
+    x, i = dist_utils.gather_samples(torch.arange(6).reshape(6, 1).float(), torch.tensor([3, 1, 2, 0, 5, 4]))
+    assert i.tolist() == [0, 1, 2, 3, 4, 5] and x[:, 0].tolist() == [3.0, 1.0, 2.0, 0.0, 5.0, 4.0]

@@ -76,9 +76,13 @@ typedef struct {
     int64_t a_bs0, a_bs1, w_bs0, w_bs1, o_bs0, o_bs1;  /* element strides */
     float alpha;
     int32_t flags;
+    void* splitk_ws;          /* optional fp32 scratch for split-K partial tiles (small-M / deep-K shapes); NULL: never split */
+    int64_t splitk_ws_bytes;
 } icd_gemm_desc;
 
 int icd_gemm(const icd_gemm_desc* d, void* stream);
+/* Bytes of split-K scratch icd_gemm would like for this shape (0: the shape is not split). */
+int64_t icd_gemm_workspace_bytes(int32_t M, int32_t N, int32_t K);
 
 /* GroupNorm(32 groups, affine, eps) [+ SiLU] over NHWC fp16, input optionally the channel concat of two tensors
  * (up-block skip connections), output a single NHWC tensor.  stats_ws: >= B*split*groups*2 floats.
@@ -217,6 +221,14 @@ typedef struct {
 int icd_profile_enable(int32_t enable);
 /* After the stream has been synchronised: fills rows[0..ICD_PROF_KINDS) and returns the number of rows. */
 int icd_profile_read(icd_profile_row* rows, int32_t max_rows);
+/* Per-launch records (GEMM: M,N,K, aux = flags or ksize*100+stride*10+upsample; attention: Nq,Nk,d, aux = heads).
+ * recs == NULL: returns the number of records available. */
+typedef struct {
+    int32_t kind, M, N, K, aux;
+    float ms;
+    double flops;
+} icd_profile_record;
+int icd_profile_dump(icd_profile_record* recs, int32_t max_recs);
 
 #ifdef __cplusplus
 }

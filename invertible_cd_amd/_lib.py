@@ -26,6 +26,7 @@ class GemmDesc(C.Structure):
         ("stride", C.c_int32), ("upsample", C.c_int32), ("batch", C.c_int32), ("zdiv", C.c_int32),
         ("a_bs0", C.c_int64), ("a_bs1", C.c_int64), ("w_bs0", C.c_int64), ("w_bs1", C.c_int64),
         ("o_bs0", C.c_int64), ("o_bs1", C.c_int64), ("alpha", C.c_float), ("flags", C.c_int32),
+        ("splitk_ws", C.c_void_p), ("splitk_ws_bytes", C.c_int64),
     ]
 
 
@@ -47,6 +48,11 @@ class ProfileRow(C.Structure):
     _fields_ = [("kind", C.c_int32), ("launches", C.c_int32), ("ms", C.c_double), ("flops", C.c_double), ("bytes", C.c_double)]
 
 
+class ProfileRecord(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("aux", C.c_int32), ("ms", C.c_float),
+                ("flops", C.c_double)]
+
+
 PROF_KINDS = ("gemm_conv", "gemm_dense", "gemm_batched", "attn_fused", "groupnorm", "layernorm", "softmax", "misc")
 
 
@@ -64,6 +70,7 @@ SIGNATURES = {
     "icd_last_error": (C.c_char_p, []),
     "icd_version": (C.c_int, []),
     "icd_gemm": (C.c_int, [C.POINTER(GemmDesc), C.c_void_p]),
+    "icd_gemm_workspace_bytes": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
     "icd_groupnorm": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                 C.c_void_p, C.c_void_p, C.c_float, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "icd_groupnorm_ws_floats": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
@@ -91,6 +98,7 @@ SIGNATURES = {
     "icd_unet_forward": (C.c_int, [C.c_void_p, C.POINTER(UNetIO), C.c_void_p]),
     "icd_profile_enable": (C.c_int, [C.c_int32]),
     "icd_profile_read": (C.c_int, [C.POINTER(ProfileRow), C.c_int32]),
+    "icd_profile_dump": (C.c_int, [C.POINTER(ProfileRecord), C.c_int32]),
 }
 
 _lib = None
@@ -131,3 +139,14 @@ def profile_read():
     if n < 0:
         check(n, "icd_profile_read")
     return {PROF_KINDS[r.kind]: dict(launches=r.launches, ms=r.ms, flops=r.flops, bytes=r.bytes) for r in rows[:n]}
+
+
+def profile_dump():
+    """Per-launch records [(family, M, N, K, aux, ms, flops)] - call after synchronising the stream."""
+    lib = load()
+    n = lib.icd_profile_dump(None, 0)
+    recs = (ProfileRecord * max(n, 1))()
+    n = lib.icd_profile_dump(recs, n)
+    if n < 0:
+        check(n, "icd_profile_dump")
+    return [(PROF_KINDS[r.kind], r.M, r.N, r.K, r.aux, r.ms, r.flops) for r in recs[:n]]

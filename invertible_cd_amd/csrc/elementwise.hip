@@ -116,13 +116,18 @@ __global__ __launch_bounds__(256) void conv_out_kernel(const half_t* __restrict_
 template <typename TX, typename TE, typename TO>
 __global__ void x0_step_kernel(const TX* __restrict__ x, const TE* __restrict__ eps, const float* __restrict__ coef,
                                long long per_sample, long long total, TO* __restrict__ out) {
+#pragma clang fp contract(off)      // hipcc contracts a*b+c into FMA by default; the reference rounds every op
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const int b = (int)(i / per_sample);
     const float a_t = coef[b * 4 + 0], s_t = coef[b * 4 + 1], a_s = coef[b * 4 + 2], s_s = coef[b * 4 + 3];
     const float xv = (float)x[i], ev = (float)eps[i];
-    const float x0 = __fdiv_rn(__fsub_rn(xv, __fmul_rn(s_t, ev)), a_t);
-    out[i] = (TO)__fadd_rn(__fmul_rn(a_s, x0), __fmul_rn(s_s, ev));
+    const float prod = s_t * ev;
+    const float diff = xv - prod;
+    const float x0 = diff / a_t;            // correctly rounded (-fhip-fp32-correctly-rounded-divide-sqrt is the default)
+    const float p1 = a_s * x0;
+    const float p2 = s_s * ev;
+    out[i] = (TO)(p1 + p2);
 }
 
 }  // namespace

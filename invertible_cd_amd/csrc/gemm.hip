@@ -6,47 +6,70 @@
 //   the materialised-P path (utils/p2p.py:335-338: baddbmm -> softmax -> controller -> bmm).
 //
 // Design (CDNA4):
-//   * 128x128x64 block tile, 256 threads = 4 waves (2x2), each wave 64x64 = 2x2 v_mfma_f32_32x32x16_f16 tiles, fp32 accum.
+//   * block tile (64*WM) x 128 x 64, WM*2 waves (WM x 2), each wave 64x64 = 2x2 v_mfma_f32_32x32x16_f16 tiles, fp32 accum.
+//     WM=4 (256x128, 8 waves, 3 LDS stages = 144 KiB, counted vmcnt: the loads of k-tile t+2 stay in flight across the
+//     barrier of k-tile t+1) is the throughput configuration; WM=2 (128x128, 4 waves, 2 stages, 2 blocks/CU) serves
+//     small problems.  Small-M / huge-K layers (8x8 and 16x16 feature maps, K up to 23040) are split along K over
+//     grid.y with fp32 partial tiles and a fused reduce+epilogue kernel, so they still fill 256 CUs.
 //   * Both operands are streamed global -> LDS with global_load_lds (16 B / lane, no VGPR round trip).  The im2col
 //     gather is done on the per-lane SOURCE address (tap / upsample / stride / concat / zero padding via a zero page),
-//     the LDS image stays lane-linear as the DMA requires.
+//     the LDS image stays lane-linear as the DMA requires.  The tap / channel position is tracked in SGPRs (it is
+//     wave-uniform whenever Cin % 64 == 0): the steady-state loader is a 64-bit pointer bump per chunk, the pixel
+//     arithmetic runs only when the tap or the concat source changes.
 //   * LDS tile rows are 128 B (64 halves); 16-B chunks are XOR-swizzled with ((row>>1)&7) so the ds_read_b128
 //     fragment reads of a 16-lane group hit 16 distinct (bank-row half, chunk) slots - conflict free.  The swizzle is
 //     applied on the source address (which chunk a lane fetches) and on the read address (same involution).
-//   * 2-stage pipeline: the loads of k-tile t+1 are issued before the MFMAs of k-tile t; one barrier per k-tile.
 //   * MFMA operands are swapped (weights as A, activations as B) so each lane ends up with 4 consecutive output
 //     channels of one output row; the tile is staged through LDS in fp32 and written with fully coalesced 16-B
 //     stores, with bias / time-bias / residual / GEGLU applied once, in fp32, before the single fp16 rounding.
 //   * blockIdx -> tile mapping is XCD-aware (block b runs on XCD b%8): every XCD gets a contiguous range of tiles
 //     so the n-tiles that share an activation tile hit the same private L2.
+#include <type_traits>
 #include "common.h"
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int TILE_BYTES = BM * BK * 2;          // 16 KiB per operand per stage
-constexpr int STAGE_BYTES = 2 * TILE_BYTES;      // A + W
-constexpr int SMEM_BYTES = 2 * STAGE_BYTES;      // 64 KiB
-constexpr int EPI_LD = 132;                      // fp32 staging row stride (floats) for a 64x128 half tile
+constexpr int BN = 128, BK = 64;
+constexpr int EPI_LD = 132;                      // fp32 staging row stride (floats) for a 64x128 slab
 constexpr int EPI_LD_T = 68;                     // transposed staging: 128 rows (n) x 64 (m)
 
 struct GemmK {
     const half_t* a0; const half_t* a1; const half_t* w;
     const float* bias; const half_t* rowbias; const half_t* resid; void* out;
+    float* partial;                              // split-K: fp32 [S][M][N]
     int M, N, K, Nw;
     int lda, ldw, ldo, ldr, ld_rowbias, rps;
     int C0, C1, Hin, Win, Hout, Wout, ksize, stride, upsample;
     int zdiv; long long a_bs0, a_bs1, w_bs0, w_bs1, o_bs0, o_bs1;
     float alpha; int flags;
-    int nbm, nbn;
+    int nbm, nbn, ksplit, kt_per_split;
 };
 
-__device__ __forceinline__ int swz_off(int row, int chunk) {        // byte offset inside a [128][64] half tile
+__device__ __forceinline__ int swz_off(int row, int chunk) {        // byte offset inside a [rows][64] half tile
     return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
 }
 
-template <int MODE, bool TRANS>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmK p) {
+// erf with |error| < 1.5e-7 (Abramowitz & Stegun 7.1.26): plenty for an fp16 result, ~4x cheaper than erff
+__device__ __forceinline__ float erf_fast(float x) {
+    const float ax = fabsf(x);
+    const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float y = 1.0f - p * t * __expf(-ax * ax);
+    return copysignf(y, x);
+}
+__device__ __forceinline__ float gelu_fast(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752f)); }
+
+// MODE 0: dense A [M,K] (lda);  MODE 1: conv, Cin % 64 == 0 && C0 % 64 == 0 (tap / concat source are wave-uniform
+// per k-tile and tracked in SGPRs);  MODE 2: conv, any Cin % 8 == 0 (per-lane tap tracking; reduced-width test nets).
+template <int MODE, bool TRANS, int WM, int NSTAGE>
+__global__ __launch_bounds__(WM * 128, 2) void gemm_kernel(GemmK p) {
+    constexpr int NT = WM * 128;                 // threads
+    constexpr int BM = WM * 64;
+    constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, STAGE_BYTES = A_BYTES + W_BYTES;
+    constexpr int NWJ = 1024 / NT;               // W chunks per thread per stage (A chunks per thread: always 4)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, wv = tid >> 6, l = tid & 63;
     const int wm = wv >> 1, wn = wv & 1;
@@ -60,6 +83,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmK p) {
     }
     const int mt = bid / p.nbn, nt = bid - mt * p.nbn;
     const int m0 = mt * BM, n0 = nt * BN;
+    const int split = blockIdx.y;
+    const int nk_total = (p.K + BK - 1) / BK;
+    const int kt_begin = split * p.kt_per_split;
+    const int kt_end = min(nk_total, kt_begin + p.kt_per_split);
+    const int nk = kt_end - kt_begin;            // >= 1 by construction
 
     const int z = blockIdx.z;
     const int z0 = z / p.zdiv, z1 = z - z0 * p.zdiv;
@@ -67,77 +95,135 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmK p) {
     const half_t* Wp = p.w + z0 * p.w_bs0 + z1 * p.w_bs1;
     const half_t* zero = reinterpret_cast<const half_t*>(icd_zero_page);
 
-    // ---- loader state: 4 A chunks + 4 W chunks per thread per k-tile -------------------------------------
+    // ---- loader state -----------------------------------------------------------------------------------
+    // Chunk j of this lane always lands at LDS slot (wave base + j*1024 + lane*16).  The global_load_lds immediate offset
+    // (j*1024) is added to BOTH the LDS and the global address, so pointers are kept biased by -j*512 halves and one M0
+    // value serves all chunks of an operand.  A chunk that is out of range parks on the zero page with increment 0:
+    // the steady-state loader is one 64-bit add per chunk, no selects.
     const int lrow = l >> 3, pchunk = l & 7;
-    int a_k[4];              // dense: k offset of this lane's chunk; conv: channel offset within Cin
-    int a_tap[4];            // conv: current tap
-    int a_pix[4];            // conv: b*Hin*Win ; dense: unused
-    int a_y[4], a_x[4];      // conv: output pixel coords
-    bool a_ok[4];
-    long long a_rowoff[4];   // dense: m*lda
-    int w_k[4]; bool w_ok[4]; long long w_rowoff[4];
     const int Cin = p.C0 + p.C1;
+    const int ntaps = p.ksize * p.ksize, pad = p.ksize >> 1;
+    const int Hu = p.Hin << p.upsample, Wu = p.Win << p.upsample;
+    const bool ktail = (p.K & 63) != 0;
+
+    const half_t* a_ptr[4];      // biased source pointer of chunk j
+    int a_inc[4];                // halves to advance per k-tile (BK, or 0 when parked on the zero page)
+    int a_lc[4];                 // logical chunk index within the k-tile (0..7)
+    int a_pix[4], a_y[4], a_x[4];   // conv: b*Hin*Win, output y, x
+    bool a_ok[4];                // m < M
+    int a_c[4], a_tap[4];        // MODE 2: per-lane channel / tap
+    const half_t* w_ptr[NWJ]; int w_inc[NWJ]; int w_lc[NWJ]; bool w_ok[NWJ];
+    const int k_begin = kt_begin * BK;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int r = wv * 32 + j * 8 + lrow;
         const int lc = pchunk ^ ((r >> 1) & 7);
         const int m = m0 + r;
+        a_lc[j] = lc;
         a_ok[j] = m < p.M;
+        a_ptr[j] = zero - j * 512; a_inc[j] = 0;
+        a_pix[j] = a_y[j] = a_x[j] = 0; a_c[j] = a_tap[j] = 0;
         if (MODE == 0) {
-            a_k[j] = lc * 8;
-            a_rowoff[j] = (long long)m * p.lda;
-            a_tap[j] = 0; a_pix[j] = 0; a_y[j] = 0; a_x[j] = 0;
+            if (a_ok[j]) { a_ptr[j] = A0 + (long long)m * p.lda + k_begin + lc * 8 - j * 512; a_inc[j] = BK; }
         } else {
             const int hw = p.Hout * p.Wout;
             const int b = m / hw, rem = m - b * hw;
             a_y[j] = rem / p.Wout;
             a_x[j] = rem - a_y[j] * p.Wout;
             a_pix[j] = b * p.Hin * p.Win;
-            int c = lc * 8, tap = 0;
-            while (c >= Cin) { c -= Cin; ++tap; }
-            a_k[j] = c; a_tap[j] = tap;
-            a_rowoff[j] = 0;
+            const int k = k_begin + lc * 8;
+            a_tap[j] = k / Cin;
+            a_c[j] = k - a_tap[j] * Cin;
         }
-        const int n = n0 + r;
-        w_ok[j] = n < p.Nw;
-        w_k[j] = lc * 8;
-        w_rowoff[j] = (long long)n * p.ldw;
     }
-    const int ntaps = p.ksize * p.ksize;
-    const int pad = p.ksize >> 1;
-    const int Hu = p.Hin << p.upsample, Wu = p.Win << p.upsample;
+#pragma unroll
+    for (int j = 0; j < NWJ; ++j) {
+        const int r = wv * (8 * NWJ) + j * 8 + lrow;
+        const int lc = pchunk ^ ((r >> 1) & 7);
+        const int n = n0 + r;
+        w_lc[j] = lc;
+        w_ok[j] = n < p.Nw;
+        w_ptr[j] = w_ok[j] ? Wp + (long long)n * p.ldw + k_begin + lc * 8 - j * 512 : zero - j * 512;
+        w_inc[j] = w_ok[j] ? BK : 0;
+    }
+    // wave-uniform position of the k-tile inside the im2col K axis (MODE 1)
+    int u_tap = MODE == 1 ? k_begin / Cin : 0;
+    int u_c = MODE == 1 ? k_begin - u_tap * Cin : 0;
+    bool u_recompute = true;
 
-    auto issue_stage = [&](int buf) {
-        unsigned char* sa = smem + buf * STAGE_BYTES + wv * 4096;
-        unsigned char* sw = sa + TILE_BYTES;
+    auto conv_src = [&](int j, int tap, int c, bool& ok) -> const half_t* {
+        const int dy = (tap * 11) >> 5, dx = tap - dy * 3;                  // tap / 3, tap % 3 for tap < 9
+        const int yu = a_y[j] * p.stride + (ntaps == 9 ? dy : 0) - pad;
+        const int xu = a_x[j] * p.stride + (ntaps == 9 ? dx : 0) - pad;
+        ok = a_ok[j] && tap < ntaps && (unsigned)yu < (unsigned)Hu && (unsigned)xu < (unsigned)Wu;
+        const long long pix = a_pix[j] + (yu >> p.upsample) * p.Win + (xu >> p.upsample);
+        return (c < p.C0) ? p.a0 + pix * p.C0 + c : p.a1 + pix * p.C1 + (c - p.C0);
+    };
+
+    // wave-uniform LDS bases (SGPR): one M0 per operand per stage
+    const int wave_a = __builtin_amdgcn_readfirstlane(wv * 4096);
+    const int wave_w = __builtin_amdgcn_readfirstlane(A_BYTES + wv * (1024 * NWJ));
+
+#define ICD_GLDS4(PTRS, BASE)                                                                                             \
+    do {                                                                                                                   \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(PTRS)[0],                         \
+                                         (__attribute__((address_space(3))) void*)(BASE), 16, 0, 0);                       \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(PTRS)[1],                         \
+                                         (__attribute__((address_space(3))) void*)(BASE), 16, 1024, 0);                    \
+        if (sizeof(PTRS) / sizeof((PTRS)[0]) == 4) {                                                                       \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(PTRS)[2 % (sizeof(PTRS) / sizeof((PTRS)[0]))], \
+                                             (__attribute__((address_space(3))) void*)(BASE), 16, 2048, 0);                \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(PTRS)[3 % (sizeof(PTRS) / sizeof((PTRS)[0]))], \
+                                             (__attribute__((address_space(3))) void*)(BASE), 16, 3072, 0);                \
+        }                                                                                                                  \
+    } while (0)
+
+    auto issue_stage = [&](int kt, int stage_off) {      // kt: absolute k-tile index; stage_off: byte offset of the stage
+        unsigned char* sa = smem + stage_off + wave_a;
+        unsigned char* sw = smem + stage_off + wave_w;
+        if (MODE == 1) {
+            if (u_recompute) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const half_t* src;
-            if (MODE == 0) {
-                src = (a_ok[j] && a_k[j] < p.K) ? A0 + a_rowoff[j] + a_k[j] : zero;
-                a_k[j] += BK;
-            } else {
-                const int tap = a_tap[j];
-                const int dy = (tap * 11) >> 5, dx = tap - dy * 3;      // tap / 3, tap % 3 for tap < 9
-                const int yu = a_y[j] * p.stride + (ntaps == 9 ? dy : 0) - pad;
-                const int xu = a_x[j] * p.stride + (ntaps == 9 ? dx : 0) - pad;
-                const bool ok = a_ok[j] && tap < ntaps && (unsigned)yu < (unsigned)Hu && (unsigned)xu < (unsigned)Wu;
-                const long long pix = a_pix[j] + (yu >> p.upsample) * p.Win + (xu >> p.upsample);
-                const int c = a_k[j];
-                const half_t* s0 = (c < p.C0) ? p.a0 + pix * p.C0 + c : p.a1 + pix * p.C1 + (c - p.C0);
-                src = ok ? s0 : zero;
-                int cn = c + BK, tp = tap;
-                while (cn >= Cin) { cn -= Cin; ++tp; }
-                a_k[j] = cn; a_tap[j] = tp;
+                for (int j = 0; j < 4; ++j) {
+                    bool ok;
+                    const half_t* s0 = conv_src(j, u_tap, u_c, ok) + a_lc[j] * 8;
+                    a_ptr[j] = (ok ? s0 : zero) - j * 512;
+                    a_inc[j] = ok ? BK : 0;
+                }
             }
-            glds16(src, sa + j * 1024);
+            u_c += BK;
+            u_recompute = false;
+            if (u_c == Cin) { u_c = 0; ++u_tap; u_recompute = true; }
+            else if (u_c == p.C0) u_recompute = true;
+        } else if (MODE == 2) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                bool ok;
+                const half_t* s0 = conv_src(j, a_tap[j], a_c[j], ok);
+                a_ptr[j] = (ok ? s0 : zero) - j * 512;
+                int cn = a_c[j] + BK, tp = a_tap[j];
+                while (cn >= Cin) { cn -= Cin; ++tp; }
+                a_c[j] = cn; a_tap[j] = tp;
+            }
+        }
+        if (ktail && kt == nk_total - 1) {          // ragged last k-tile (dense attention bmm): chunk-level masking
+            const half_t* ta[4]; const half_t* tw[NWJ];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ta[j] = (kt * BK + a_lc[j] * 8 < p.K) ? a_ptr[j] : zero - j * 512;
+#pragma unroll
+            for (int j = 0; j < NWJ; ++j) tw[j] = (kt * BK + w_lc[j] * 8 < p.K) ? w_ptr[j] : zero - j * 512;
+            ICD_GLDS4(ta, sa);
+            ICD_GLDS4(tw, sw);
+        } else {
+            ICD_GLDS4(a_ptr, sa);
+            ICD_GLDS4(w_ptr, sw);
+        }
+        if (MODE != 2) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a_ptr[j] += a_inc[j];
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const half_t* src = (w_ok[j] && w_k[j] < p.K) ? Wp + w_rowoff[j] + w_k[j] : zero;
-            w_k[j] += BK;
-            glds16(src, sw + j * 1024);
-        }
+        for (int j = 0; j < NWJ; ++j) w_ptr[j] += w_inc[j];
     };
 
     f32x16 acc[2][2];
@@ -148,39 +234,75 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmK p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    const int nk = (p.K + BK - 1) / BK;
-    issue_stage(0);
+    // ---- LDS read addresses: row bases + swizzled chunk offsets, precomputed (the swizzle key only depends on lane) ----
     const int lr = l & 31, lh = l >> 5;
-    for (int kt = 0; kt < nk; ++kt) {
-        __builtin_amdgcn_s_waitcnt(0x0f70 | 0);     // vmcnt(0) (expcnt/lgkmcnt untouched)
-        __syncthreads();
-        if (kt + 1 < nk) issue_stage((kt + 1) & 1);
-        const unsigned char* sa = smem + (kt & 1) * STAGE_BYTES;
-        const unsigned char* sw = sa + TILE_BYTES;
+    int rd_a[4], rd_w[4];
+    {
+        const int x = (lr >> 1) & 7;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int c = s * 2 + lh;
-            f16x8 af[2], wf[2];
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const int off = ((s4 * 2 + lh) ^ x) << 4;
+            rd_a[s4] = (wm * 64 + lr) * 128 + off;
+            rd_w[s4] = A_BYTES + (wn * 64 + lr) * 128 + off;
+        }
+    }
+
+    // ---- main loop: NSTAGE-deep LDS ring, loads of tile t+NSTAGE-1 issued before the MFMAs of tile t ----------
+    constexpr int LOADS = 4 + NWJ;               // global_load_lds per thread per stage
 #pragma unroll
-            for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const f16x8*>(sa + swz_off(wm * 64 + i * 32 + lr, c));
+    for (int s = 0; s < NSTAGE - 1; ++s)
+        if (s < nk) issue_stage(kt_begin + s, s * STAGE_BYTES);
+
+    auto k_tile = [&](auto stage_tag, int t) {
+        constexpr int S = decltype(stage_tag)::value;
+        constexpr int SN = (S + NSTAGE - 1) % NSTAGE;
+        // wait until tile t has landed: at most (NSTAGE-2) younger stages may still be in flight
+        if (NSTAGE == 2 || t + (NSTAGE - 2) >= nk) __builtin_amdgcn_s_waitcnt(0x0f70);                   // vmcnt(0)
+        else __builtin_amdgcn_s_waitcnt(0x0f70 | (LOADS * (NSTAGE - 2)));                                 // vmcnt(LOADS)
+        __builtin_amdgcn_s_barrier();
+        if (t + NSTAGE - 1 < nk && !(p.flags & 0x10000)) issue_stage(kt_begin + t + NSTAGE - 1, SN * STAGE_BYTES);
+        const unsigned char* sb = smem + S * STAGE_BYTES;
+        if (p.flags & 0x20000) return;
+        // register double-buffered fragments: the ds_reads of sub-step s+1 are in flight under the MFMAs of sub-step s
+        f16x8 af[2][2], wf[2][2];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) wf[j] = *reinterpret_cast<const f16x8*>(sw + swz_off(wn * 64 + j * 32 + lr, c));
+        for (int i = 0; i < 2; ++i) {
+            af[0][i] = *reinterpret_cast<const f16x8*>(sb + rd_a[0] + i * 4096);
+            wf[0][i] = *reinterpret_cast<const f16x8*>(sb + rd_w[0] + i * 4096);
+        }
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const int cur = s4 & 1, nxt = cur ^ 1;
+            if (s4 < 3) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    af[nxt][i] = *reinterpret_cast<const f16x8*>(sb + rd_a[s4 + 1] + i * 4096);
+                    wf[nxt][i] = *reinterpret_cast<const f16x8*>(sb + rd_w[s4 + 1] + i * 4096);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);      // keep the prefetch ahead of this sub-step's MFMAs (distinct registers)
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    if (TRANS) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], wf[j], acc[i][j], 0, 0, 0);
-                    else       acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[j], af[i], acc[i][j], 0, 0, 0);
+                    if (TRANS) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cur][i], wf[cur][j], acc[i][j], 0, 0, 0);
+                    else       acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[cur][j], af[cur][i], acc[i][j], 0, 0, 0);
                 }
         }
+    };
+    for (int t = 0; t < nk; t += NSTAGE) {
+        k_tile(std::integral_constant<int, 0>{}, t);
+        if (t + 1 < nk) k_tile(std::integral_constant<int, 1>{}, t + 1);
+        if (NSTAGE > 2 && t + 2 < nk) k_tile(std::integral_constant<int, (NSTAGE > 2 ? 2 : 0)>{}, t + 2);
     }
+#undef ICD_GLDS4
 
-    // ---- epilogue: fp32 staging through LDS, two 64-row halves -------------------------------------------
+    // ---- epilogue: fp32 staging through LDS, one 64-row slab (one wave row) at a time ----------------------
     float* stage = reinterpret_cast<float*>(smem);
     const bool geglu = p.flags & ICD_GEMM_GEGLU;
     const bool out_f32 = p.flags & ICD_GEMM_OUT_F32;
     const long long o_off = z0 * p.o_bs0 + z1 * p.o_bs1;
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < WM; ++h) {
         __syncthreads();
         if (wm == h) {
 #pragma unroll
@@ -197,11 +319,25 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmK p) {
                     }
         }
         __syncthreads();
-        if (TRANS) {
+        if (p.ksplit > 1) {
+            // split-K: raw fp32 partial tile, reduced (and bias / residual applied) by splitk_reduce_kernel
+            float* part = p.partial + (long long)split * p.M * p.N;
+#pragma unroll
+            for (int pass = 0; pass < 1024 / NT; ++pass) {
+                const int item = pass * NT + tid;
+                const int r = item >> 4, c8 = (item & 15) * 8;
+                const int m = m0 + h * 64 + r, n = n0 + c8;
+                if (m >= p.M || n >= p.N) continue;
+                const float* sp = stage + r * EPI_LD + c8;
+                float* dst = part + (long long)m * p.N + n;
+                *reinterpret_cast<f32x4*>(dst) = *reinterpret_cast<const f32x4*>(sp);
+                *reinterpret_cast<f32x4*>(dst + 4) = *reinterpret_cast<const f32x4*>(sp + 4);
+            }
+        } else if (TRANS) {
             half_t* out = reinterpret_cast<half_t*>(p.out) + o_off;
 #pragma unroll
-            for (int pass = 0; pass < 4; ++pass) {
-                const int item = pass * 256 + tid;
+            for (int pass = 0; pass < 1024 / NT; ++pass) {
+                const int item = pass * NT + tid;
                 const int nl = item >> 3, mc = (item & 7) * 8;
                 const int n = n0 + nl, m = m0 + h * 64 + mc;
                 if (n >= p.N || m >= p.M) continue;
@@ -231,8 +367,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmK p) {
         } else if (geglu) {
             half_t* out = reinterpret_cast<half_t*>(p.out) + o_off;
 #pragma unroll
-            for (int pass = 0; pass < 2; ++pass) {
-                const int r = pass * 32 + (tid >> 3), oc = (tid & 7) * 8;
+            for (int pass = 0; pass < 512 / NT; ++pass) {
+                const int item = pass * NT + tid;
+                const int r = item >> 3, oc = (item & 7) * 8;
                 const int m = m0 + h * 64 + r;
                 const int hcol = (oc >> 5) * 64 + (oc & 31);
                 if (m >= p.M || n0 + hcol >= p.N) continue;
@@ -241,19 +378,29 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmK p) {
                 f32x4 g0 = *reinterpret_cast<const f32x4*>(sp + 32), g1 = *reinterpret_cast<const f32x4*>(sp + 36);
                 float hv[8] = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
                 float gv[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
+                if (p.bias) {
+                    const float* bp = p.bias + n0 + hcol;
+                    f32x4 b0 = *reinterpret_cast<const f32x4*>(bp), b1 = *reinterpret_cast<const f32x4*>(bp + 4);
+                    f32x4 c0 = *reinterpret_cast<const f32x4*>(bp + 32), c1 = *reinterpret_cast<const f32x4*>(bp + 36);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        hv[e] = hv[e] * p.alpha + b0[e]; hv[4 + e] = hv[4 + e] * p.alpha + b1[e];
+                        gv[e] = gv[e] * p.alpha + c0[e]; gv[4 + e] = gv[4 + e] * p.alpha + c1[e];
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { hv[e] *= p.alpha; gv[e] *= p.alpha; }
+                }
                 f16x8 o;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    float hh = hv[e] * p.alpha, gg = gv[e] * p.alpha;
-                    if (p.bias) { hh += p.bias[n0 + hcol + e]; gg += p.bias[n0 + hcol + 32 + e]; }
-                    o[e] = (half_t)(hh * gelu_erf_f(gg));
-                }
+                for (int e = 0; e < 8; ++e) o[e] = (half_t)(hv[e] * gelu_fast(gv[e]));
                 *reinterpret_cast<f16x8*>(out + (long long)m * p.ldo + (n0 >> 1) + oc) = o;
             }
         } else {
 #pragma unroll
-            for (int pass = 0; pass < 4; ++pass) {
-                const int r = pass * 16 + (tid >> 4), c8 = (tid & 15) * 8;
+            for (int pass = 0; pass < 1024 / NT; ++pass) {
+                const int item = pass * NT + tid;
+                const int r = item >> 4, c8 = (item & 15) * 8;
                 const int m = m0 + h * 64 + r, n = n0 + c8;
                 if (m >= p.M || n >= p.N) continue;
                 const float* sp = stage + r * EPI_LD + c8;
@@ -291,21 +438,94 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmK p) {
     }
 }
 
-template <int MODE, bool TRANS>
+// split-K second pass: out = alpha * sum_s partial[s] + bias + rowbias + resid   (thread = 8 consecutive columns)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmK p) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int nch = p.N >> 3;
+    if (idx >= (long long)p.M * nch) return;
+    const int m = (int)(idx / nch), n = (int)(idx - (long long)m * nch) * 8;
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < p.ksplit; ++s) {
+        const float* src = p.partial + ((long long)s * p.M + m) * p.N + n;
+        f32x4 a = *reinterpret_cast<const f32x4*>(src), b = *reinterpret_cast<const f32x4*>(src + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] += a[e]; v[4 + e] += b[e]; }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] *= p.alpha;
+    if (p.bias) {
+        f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n), b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
+    }
+    if (p.rowbias) {
+        f16x8 rb = *reinterpret_cast<const f16x8*>(p.rowbias + (long long)(m / p.rps) * p.ld_rowbias + n);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += (float)rb[e];
+    }
+    if (p.resid) {
+        f16x8 rs = *reinterpret_cast<const f16x8*>(p.resid + (long long)m * p.ldr + n);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += (float)rs[e];
+    }
+    if (p.flags & ICD_GEMM_OUT_F32) {
+        float* out = reinterpret_cast<float*>(p.out) + (long long)m * p.ldo + n;
+        *reinterpret_cast<f32x4*>(out) = (f32x4){v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<f32x4*>(out + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+    } else {
+        f16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (half_t)v[e];
+        *reinterpret_cast<f16x8*>(reinterpret_cast<half_t*>(p.out) + (long long)m * p.ldo + n) = o;
+    }
+}
+
+template <int MODE, bool TRANS, int WM, int NSTAGE>
 int launch(const GemmK& k, int batch, hipStream_t st) {
+    constexpr int smem = NSTAGE * (WM * 64 + BN) * 128;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<MODE, TRANS>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<MODE, TRANS, WM, NSTAGE>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         attr_set = true;
     }
-    dim3 grid(k.nbm * k.nbn, 1, batch);
-    hipLaunchKernelGGL((gemm_kernel<MODE, TRANS>), grid, dim3(256), SMEM_BYTES, st, k);
+    dim3 grid(k.nbm * k.nbn, k.ksplit, batch);
+    hipLaunchKernelGGL((gemm_kernel<MODE, TRANS, WM, NSTAGE>), grid, dim3(WM * 128), smem, st, k);
     ICD_CHECK_LAUNCH("icd_gemm");
+    if (k.ksplit > 1) {
+        const long long items = (long long)k.M * (k.N >> 3);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, k);
+        ICD_CHECK_LAUNCH("icd_gemm(split-K reduce)");
+    }
     return ICD_OK;
 }
 
 }  // namespace
+
+// Tile / split-K plan: 256x128 tiles when they fill the chip, otherwise 128x128; split K when the grid is still small
+// and K is deep.  Pure function of the shape (bit-reproducible results for a given shape).
+static void plan_gemm(int M, int N, int K, int batch, bool allow_split, long long ws_bytes, int* wm, int* ksplit) {
+    const int nbn = (N + 127) / 128, nk = (K + 63) / 64;
+    const long long b256 = (long long)((M + 255) / 256) * nbn * batch;
+    const long long b128 = (long long)((M + 127) / 128) * nbn * batch;
+    *ksplit = 1;
+    if (b256 >= 200 || (M >= 256 && nk >= 32 && allow_split)) *wm = 4;
+    else *wm = 2;
+    const long long blocks = *wm == 4 ? b256 : b128;
+    if (allow_split && blocks < 160 && nk >= 16) {
+        int s = (int)((256 + blocks - 1) / blocks);
+        s = s > 8 ? 8 : s;
+        while (s > 1 && nk / s < 8) --s;
+        while (s > 1 && (long long)s * M * N * 4 > ws_bytes) --s;
+        *ksplit = s < 1 ? 1 : s;
+    }
+}
+
+extern "C" int64_t icd_gemm_workspace_bytes(int32_t M, int32_t N, int32_t K) {
+    int wm, ks;
+    plan_gemm(M, N, K, 1, true, 1LL << 60, &wm, &ks);
+    return ks > 1 ? (int64_t)ks * M * N * 4 : 0;
+}
 
 extern "C" int icd_gemm(const icd_gemm_desc* d, void* stream) {
     ICD_CHECK_ARG(d != nullptr, "icd_gemm: null descriptor");
@@ -324,6 +544,7 @@ extern "C" int icd_gemm(const icd_gemm_desc* d, void* stream) {
     GemmK k;
     k.a0 = (const half_t*)d->a0; k.a1 = (const half_t*)d->a1; k.w = (const half_t*)d->w;
     k.bias = d->bias; k.rowbias = (const half_t*)d->rowbias; k.resid = (const half_t*)d->resid; k.out = d->out;
+    k.partial = (float*)d->splitk_ws;
     k.M = d->M; k.N = d->N; k.K = d->K; k.Nw = d->Nw > 0 ? d->Nw : d->N;
     k.lda = d->lda; k.ldw = d->ldw; k.ldo = d->ldo; k.ldr = d->ldr; k.ld_rowbias = d->ld_rowbias;
     k.rps = d->rows_per_sample > 0 ? d->rows_per_sample : 1;
@@ -332,8 +553,16 @@ extern "C" int icd_gemm(const icd_gemm_desc* d, void* stream) {
     k.zdiv = d->zdiv > 0 ? d->zdiv : 1;
     k.a_bs0 = d->a_bs0; k.a_bs1 = d->a_bs1; k.w_bs0 = d->w_bs0; k.w_bs1 = d->w_bs1; k.o_bs0 = d->o_bs0; k.o_bs1 = d->o_bs1;
     k.alpha = d->alpha; k.flags = d->flags;
-    k.nbm = (d->M + BM - 1) / BM; k.nbn = (d->N + BN - 1) / BN;
     const int batch = d->batch > 0 ? d->batch : 1;
+    int wm = 2, ks = 1;
+    const bool allow_split = !trans && !geglu && batch == 1 && d->splitk_ws != nullptr && d->splitk_ws_bytes > 0;
+    plan_gemm(d->M, d->N, d->K, batch, allow_split, d->splitk_ws_bytes, &wm, &ks);
+    const int nk_total = (d->K + BK - 1) / BK;
+    k.ksplit = ks;
+    k.kt_per_split = (nk_total + ks - 1) / ks;
+    k.ksplit = (nk_total + k.kt_per_split - 1) / k.kt_per_split;      // no empty splits
+    k.nbm = (d->M + wm * 64 - 1) / (wm * 64); k.nbn = (d->N + BN - 1) / BN;
+    hipStream_t st = (hipStream_t)stream;
     if (d->mode == 1) {
         ICD_CHECK_ARG(d->ksize == 1 || d->ksize == 3, "icd_gemm: conv ksize must be 1 or 3");
         ICD_CHECK_ARG(d->stride == 1 || d->stride == 2, "icd_gemm: conv stride must be 1 or 2");
@@ -344,8 +573,11 @@ extern "C" int icd_gemm(const icd_gemm_desc* d, void* stream) {
         ICD_CHECK_ARG(d->Hin > 0 && d->Win > 0 && d->Hout > 0 && d->Wout > 0 && d->M % (d->Hout * d->Wout) == 0,
                       "icd_gemm: bad conv geometry");
         ICD_CHECK_ARG(batch == 1 && !trans, "icd_gemm: conv mode is not batched / transposed");
-        return launch<1, false>(k, 1, (hipStream_t)stream);
+        const bool fast = ((d->C0 + d->C1) % 64 == 0) && (d->C0 % 64 == 0);
+        if (!fast) { k.nbm = (d->M + 127) / 128; return launch<2, false, 2, 2>(k, 1, st); }
+        return wm == 4 ? launch<1, false, 4, 3>(k, 1, st) : launch<1, false, 2, 2>(k, 1, st);
     }
     ICD_CHECK_ARG(d->lda % 8 == 0, "icd_gemm: lda must be a multiple of 8");
-    return trans ? launch<0, true>(k, batch, (hipStream_t)stream) : launch<0, false>(k, batch, (hipStream_t)stream);
+    if (trans) return wm == 4 ? launch<0, true, 4, 3>(k, batch, st) : launch<0, true, 2, 2>(k, batch, st);
+    return wm == 4 ? launch<0, false, 4, 3>(k, batch, st) : launch<0, false, 2, 2>(k, batch, st);
 }

@@ -20,7 +20,7 @@ namespace {
 struct Tensor { const void* ptr; int dtype; long long numel; };
 
 // ---- per-family launch timing (HIP events on the launch stream) ------------------------------------------------
-struct ProfRec { hipEvent_t a, b; int kind; double flops, bytes; };
+struct ProfRec { hipEvent_t a, b; int kind; double flops, bytes; int M, N, K, aux; };
 bool g_prof_on = false;
 std::vector<ProfRec> g_prof;
 std::vector<hipEvent_t> g_ev_pool;
@@ -33,9 +33,10 @@ hipEvent_t prof_event() {
 }
 struct ProfScope {
     bool on; hipStream_t st; size_t idx;
-    ProfScope(bool active, hipStream_t s, int kind, double flops, double bytes) : on(active && g_prof_on), st(s), idx(0) {
+    ProfScope(bool active, hipStream_t s, int kind, double flops, double bytes, int M = 0, int N = 0, int K = 0, int aux = 0)
+        : on(active && g_prof_on), st(s), idx(0) {
         if (!on) return;
-        ProfRec r{prof_event(), prof_event(), kind, flops, bytes};
+        ProfRec r{prof_event(), prof_event(), kind, flops, bytes, M, N, K, aux};
         (void)hipEventRecord(r.a, st);
         idx = g_prof.size();
         g_prof.push_back(r);
@@ -153,10 +154,16 @@ struct Exec {
 
     // ---------------------------------------------------------------------------------------------- op wrappers
     void gemm_desc(icd_gemm_desc& d) {
+        // split-K scratch for small-M / deep-K shapes comes from the arena (accounted for in the dry run too)
+        void* ws = nullptr;
+        const bool splittable = (d.batch <= 1) && !(d.flags & (ICD_GEMM_OUT_TRANS | ICD_GEMM_GEGLU));
+        const long long need = splittable ? icd_gemm_workspace_bytes(d.M, d.N, d.K) : 0;
+        if (need > 0) { ws = alloc<char>(need); d.splitk_ws = ws; d.splitk_ws_bytes = need; }
+        struct Rel { Exec* e; void* p; ~Rel() { if (p) e->release(p); } } rel{this, ws};
         if (!ok() || dry) return;
         const int nb = d.batch > 0 ? d.batch : 1;
         ProfScope ps(true, st, d.mode == 1 ? ICD_PROF_GEMM_CONV : (nb > 1 ? ICD_PROF_GEMM_BATCHED : ICD_PROF_GEMM_DENSE),
-                     2.0 * d.M * (double)d.N * d.K * nb, 0.0);
+                     2.0 * d.M * (double)d.N * d.K * nb, 0.0, d.M, d.N, d.K, d.mode == 1 ? d.ksize * 100 + d.stride * 10 + d.upsample : d.flags);
         run(icd_gemm(&d, st));
     }
     // dense: out[M,N] (ldo) = a[M,K](lda) @ w[N,K]^T + bias + resid
@@ -242,7 +249,7 @@ struct Exec {
         }
         if (!mat) {
             if (ok() && !dry) {
-                ProfScope ps(true, st, ICD_PROF_ATTN_FUSED, 4.0 * B * heads * (double)Nq * Nk * d, 0.0);
+                ProfScope ps(true, st, ICD_PROF_ATTN_FUSED, 4.0 * B * heads * (double)Nq * Nk * d, 0.0, Nq, Nk, d, heads);
                 run(icd_attention_fused(q, k, vt, out, B, heads, Nq, Nk, d, ldq, ldk, ldv, C, scale, st));
             }
             return;
@@ -509,6 +516,17 @@ extern "C" int icd_profile_read(icd_profile_row* rows, int32_t max_rows) {
         rows[r.kind].launches += 1; rows[r.kind].ms += ms; rows[r.kind].flops += r.flops; rows[r.kind].bytes += r.bytes;
     }
     return ICD_PROF_KINDS;
+}
+
+extern "C" int icd_profile_dump(icd_profile_record* recs, int32_t max_recs) {
+    const int n = (int)std::min<size_t>(g_prof.size(), (size_t)std::max(0, max_recs));
+    for (int i = 0; i < n && recs; ++i) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, g_prof[i].a, g_prof[i].b) != hipSuccess) { icd_set_error("icd_profile_dump: events not complete"); return ICD_ERR_HIP; }
+        recs[i].kind = g_prof[i].kind; recs[i].M = g_prof[i].M; recs[i].N = g_prof[i].N; recs[i].K = g_prof[i].K; recs[i].aux = g_prof[i].aux;
+        recs[i].ms = ms; recs[i].flops = g_prof[i].flops;
+    }
+    return recs ? n : (int)g_prof.size();
 }
 
 extern "C" int icd_unet_create(const icd_unet_config* cfg, icd_unet** out) {

@@ -39,6 +39,16 @@ def geglu_perm(n_out):
 
 
 # ------------------------------------------------------------------------------------------------ operators
+def _splitk_ws(d, device):
+    """Attach split-K scratch when the shape wants it (small M, deep K); returns the tensor to keep it alive."""
+    n = _lib.load().icd_gemm_workspace_bytes(d.M, d.N, d.K)
+    if n <= 0:
+        return None
+    ws = torch.empty((n,), dtype=torch.uint8, device=device)
+    d.splitk_ws, d.splitk_ws_bytes = ws.data_ptr(), n
+    return ws
+
+
 def gemm(a, w, bias=None, resid=None, rowbias=None, rows_per_sample=0, geglu=False, out=None, alpha=1.0,
          out_f32=False):
     """out[M, N] = alpha * a[M, K] @ w[N, K]^T (+bias[N] fp32) (+rowbias[m // rps]) (+resid) ; GEGLU halves N."""
@@ -60,6 +70,7 @@ def gemm(a, w, bias=None, resid=None, rowbias=None, rows_per_sample=0, geglu=Fal
     d.rows_per_sample = rows_per_sample
     d.mode, d.batch, d.zdiv, d.alpha = 0, 1, 1, alpha
     d.flags = (ICD_GEMM_GEGLU if geglu else 0) | (ICD_GEMM_OUT_F32 if out_f32 else 0)
+    ws = _splitk_ws(d, a.device)
     _lib.check(_lib.load().icd_gemm(C.byref(d), _stream()), "icd_gemm")
     return out
 
@@ -86,6 +97,7 @@ def conv3x3(x, B, H, W, w_packed, bias=None, x2=None, stride=1, upsample=False, 
     d.mode, d.C0, d.C1 = 1, C0, C1
     d.Hin, d.Win, d.Hout, d.Wout, d.ksize, d.stride, d.upsample = H, W, Ho, Wo, ksize, stride, int(upsample)
     d.batch, d.zdiv, d.alpha, d.flags = 1, 1, 1.0, 0
+    ws = _splitk_ws(d, x.device)
     _lib.check(_lib.load().icd_gemm(C.byref(d), _stream()), "icd_gemm(conv)")
     return out
 

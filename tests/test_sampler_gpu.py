@@ -1,0 +1,275 @@
+"""End-to-end parity of the sampler paths on the GPU against the CPU oracle (UNet restatement + boundary step), including
+every attention-store tensor, plus size-independent properties at BASELINE.json's full sizes.
+
+BASELINE configs covered here (reduced widths for the oracle-checked cases, full size for the property cases):
+  cfg 2  iCD-SD1.5 4-step reverse (w-embedding, dead-uncond elimination on/off)
+  cfg 3  iCD-SD1.5 4-step forward inversion + 4-step reverse edit with p2p controllers (AttentionStore / AttentionReplace)
+  cfg 4  iCD-SDXL 4-step reverse
+  cfg 5  iCD-SDXL 3-step forward + 3-step reverse with dynamic guidance (tau < 1)
+Tolerances: rel-L2 <= 5e-3 on latents after 4-8 chained UNet evaluations (each evaluation is ~1.1e-3 from fp32, the
+boundary step at t=999 amplifies eps errors by sigma_t/alpha_t ~ 15), <= 2e-3 on attention-store tensors.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+REV_T, REV_S = [999, 779, 519, 259], [779, 519, 259, 0]
+FWD_T, FWD_S = [19, 259, 519, 779], [259, 519, 779, 999]
+
+
+def _env():
+    from invertible_cd_amd import generation, generation_sdxl, p2p, synthetic, unet
+    from invertible_cd_amd.pipelines import StableDiffusionPipeline, StableDiffusionXLImg2ImgPipeline, StableDiffusionXLPipeline
+    from invertible_cd_amd.schedulers import DDIMScheduler
+    from invertible_cd_amd.unet_config import SD15, SDXL
+    from oracle import sched_ref, unet_ref
+    return locals()
+
+
+def _ocfg(unet_ref, cfg):
+    o = dict(unet_ref.SD15 if cfg.addition_time_embed_dim == 0 else unet_ref.SDXL)
+    o.update(block_out_channels=cfg.block_out_channels, cross_dim=cfg.cross_dim, num_heads=cfg.num_heads)
+    if cfg.addition_time_embed_dim:
+        o["add_in_dim"] = cfg.add_in_dim
+    return o
+
+
+def _tables(sched_ref):
+    ac = sched_ref.alphas_cumprod()
+    return np.sqrt(ac), np.sqrt(1 - ac)
+
+
+def _sd15_setup(E, B, H, W, seed):
+    cfg = E["SD15"].scaled((64, 128, 256, 256), cross_dim=64)
+    sd = {k: v.half().float() for k, v in E["synthetic"].synthetic_state_dict(cfg, seed=seed).items()}
+    inp = E["synthetic"].synthetic_inputs(cfg, B, H, W, seed=seed)
+    lat, ctx = inp["latents"].half().float(), inp["context"].half().float()
+    model = E["StableDiffusionPipeline"](E["unet"].UNet2DConditionModel(cfg, sd, dtype=torch.float16), E["DDIMScheduler"].sd15(),
+                                         tokenizer=E["synthetic"].SyntheticTokenizer(), device="cuda", dtype=torch.float16)
+    solver = E["generation"].Generator(model, 50, E["DDIMScheduler"].sd15(), forward_cons_model=model, reverse_cons_model=model,
+                                       reverse_timesteps=[259, 519, 779, 999], forward_timesteps=[19, 259, 519, 779])
+    solver.context = torch.cat([torch.zeros_like(ctx), ctx]).cuda().half()
+    return cfg, sd, lat, ctx, model, solver
+
+
+def _oracle_loop(E, sd, cfg, x, ctx, pairs, w_vals, controller=None, added=None):
+    """cond rows only (the unconditional rows never influence the output when w_embed_dim > 0)."""
+    S, U = E["sched_ref"], E["unet_ref"]
+    alpha, sigma = _tables(S)
+    ocfg = _ocfg(U, cfg)
+    B = x.shape[0]
+    hook = None
+    if controller is not None:
+        hook = lambda p, is_cross, place: controller.call_cond_only(p, is_cross, place)
+    for (t, s), w in zip(pairs, w_vals):
+        wemb = torch.from_numpy(S.guidance_scale_embedding(w, 512)).half().float()
+        eps = U.unet_forward(sd, ocfg, x.half().float(), t, ctx, timestep_cond=wemb, added_cond=added, hook=hook).half().float()
+        x = torch.from_numpy(S.predicted_origin(eps.numpy(), [t] * B, [s] * B, x.numpy(), alpha, sigma))
+        if controller is not None:
+            x = controller.step_callback(x)
+    return x
+
+
+@pytest.mark.parametrize("eliminate", [True, False])
+def test_sd15_reverse_with_attention_store(eliminate):
+    """cfg 2/3: 4-step reverse, AttentionStore registered; latents AND every stored probability tensor vs the oracle."""
+    E = _env()
+    p2p = E["p2p"]
+    B, H, W, gs = 3, 32, 32, 7.0
+    cfg, sd, lat, ctx, model, solver = _sd15_setup(E, B, H, W, seed=11)
+    solver.eliminate_dead_uncond = eliminate
+    store = p2p.AttentionStore()
+    p2p.register_attention_control(model, store)
+    assert store.num_att_layers == 32
+    outs = solver.cons_generation(lat.cuda(), guidance_scale=gs, w_embed_dim=512, dynamic_guidance=False, tau1=1.0, tau2=1.0,
+                                  controller=store)
+    assert len(outs) == 5 and outs[-1].dtype == torch.float32          # fp32 latent chain, as in the reference
+    ref_store = p2p.AttentionStore()
+    ref_store.num_att_layers = 32
+    ref = _oracle_loop(E, sd, cfg, lat.clone(), ctx, list(zip(REV_T, REV_S)), [[gs] * B] * 4, controller=ref_store)
+    err = rel_l2(outs[-1], ref)
+    print(f"[sd15 reverse, eliminate={eliminate}] rel-L2(latents) = {err:.3e}")
+    assert err < 5e-3
+    assert store.cur_step == ref_store.cur_step == 4
+    n_checked = 0
+    for key, refs in ref_store.attention_store.items():
+        got = store.attention_store[key]
+        assert len(got) == len(refs), key
+        for g, r in zip(got, refs):
+            gc = g                                   # both modes store the conditional rows only (utils/p2p.py:106-107)
+            assert tuple(gc.shape) == tuple(r.shape), (key, gc.shape, r.shape)
+            e = rel_l2(gc, r)
+            assert e < 2e-3, (key, e)
+            n_checked += 1
+    # latent 32x32 -> query counts 1024,1024,256,256,64,64 down; 16 mid; up 64x3,256x3,1024x3: all <= 32^2 -> all 32 stored
+    assert n_checked == 32
+
+
+def test_sd15_inversion_then_replace_edit():
+    """cfg 3: consistency inversion (forward model, w = 0) then a 2-prompt AttentionReplace edit on the reverse model."""
+    E = _env()
+    p2p = E["p2p"]
+    B, H, W = 2, 32, 32
+    cfg, sd, lat, ctx, model, solver = _sd15_setup(E, B, H, W, seed=12)
+    # ---- inversion: 4D latents pass straight through image2latent; add_noise at t=19 with the CPU generator(seed)
+    solver.latent2image = lambda z, return_type="np": np.zeros((1,))
+    img = lat.cuda()
+    _, inv = solver.cons_inversion(img, guidance_scale=0.0, w_embed_dim=512, seed=5)
+    S = E["sched_ref"]
+    alpha, sigma = _tables(S)
+    noise = torch.randn(lat.shape, generator=torch.Generator().manual_seed(5))
+    x0 = float(alpha[19]) * lat + float(sigma[19]) * noise
+    # B == 2 -> CFG-doubled batch of 4 -> w vector [0,0,0,gs] with gs = 0 -> all zeros
+    ref_inv = _oracle_loop(E, sd, cfg, x0.clone(), ctx, list(zip(FWD_T, FWD_S)), [[0.0, 0.0]] * 4)
+    e_inv = rel_l2(inv[0], ref_inv)
+    print(f"[sd15 inversion] rel-L2 = {e_inv:.3e}")
+    assert e_inv < 5e-3
+    # ---- edit: replace controller (cross 0.5 / self 0.5), dynamic guidance tau = 0.8, gs = 19
+    p2p.tokenizer = E["synthetic"].SyntheticTokenizer()
+    p2p.NUM_DDIM_STEPS = 4
+    prompts = ["a cat sitting on a bench", "a dog sitting on a bench"]
+    p2p.device = "cuda"
+    ctrl = p2p.make_controller(prompts, True, 0.5, 0.5)
+    p2p.device = "cpu"
+    ref_ctrl = p2p.make_controller(prompts, True, 0.5, 0.5)
+    ref_ctrl.num_att_layers = 32
+    p2p.register_attention_control(model, ctrl)
+    start = ref_inv.clone()                         # same starting latents on both sides
+    outs = solver.cons_generation(start.cuda(), guidance_scale=19.0, w_embed_dim=512, dynamic_guidance=True, tau1=0.8, tau2=0.8,
+                                  controller=ctrl)
+    # w: 0 at t=999 (> tau), then [0, gs] for the cond half of the 4-row doubled batch (utils/generation.py:232-233 quirk)
+    ws = [[0.0, 0.0]] + [[0.0, 19.0]] * 3
+    ref = _oracle_loop(E, sd, cfg, start.clone(), ctx, list(zip(REV_T, REV_S)), ws, controller=ref_ctrl)
+    e = rel_l2(outs[-1], ref)
+    print(f"[sd15 replace edit] rel-L2 = {e:.3e}")
+    assert e < 8e-3
+    assert ctrl.cur_step == 4
+    for key, refs in ref_ctrl.attention_store.items():
+        for g, r in zip(ctrl.attention_store[key], refs):
+            assert rel_l2(g, r) < 3e-3, key
+
+
+def test_sdxl_reverse_and_dynamic_edit_pipeline():
+    """cfg 4 + cfg 5: SDXL 4-step reverse; 3-step forward + 3-step reverse with dynamic guidance (tau = 0.7)."""
+    E = _env()
+    X = E["generation_sdxl"]
+    cfg = E["SDXL"].scaled((64, 128, 256), cross_dim=128, heads=(2, 4, 8))
+    sd = {k: v.half().float() for k, v in E["synthetic"].synthetic_state_dict(cfg, seed=21).items()}
+    B, H, W = 2, 32, 32
+    inp = E["synthetic"].synthetic_inputs(cfg, B, H, W, seed=21)
+    lat, ctx = inp["latents"].half().float(), inp["context"].half().float()
+    added = {"text_embeds": inp["text_embeds"].half().float(), "time_ids": inp["time_ids"]}
+    u = E["unet"].UNet2DConditionModel(cfg, sd, dtype=torch.float16)
+    pipe = E["StableDiffusionXLPipeline"](u, E["DDIMScheduler"].sdxl())
+    fpipe = E["StableDiffusionXLImg2ImgPipeline"](u, E["DDIMScheduler"].sdxl())
+    emb = lambda p, o, c: {"prompt_embeds": ctx.cuda().half(), "text_embeds": added["text_embeds"].cuda().half(),
+                           "time_ids": added["time_ids"].cuda()}
+    # cfg 4
+    _, out = X.sample_deterministic(pipe, ["x"] * B, latents=lat.cuda().half(), num_inference_steps=4, guidance_scale=7.0, is_sdxl=True,
+                                    timesteps=[249, 499, 699, 999], compute_embeddings_fn=emb, return_latent=True)
+    assert out.dtype == torch.float16
+    pairs = list(zip([999, 699, 499, 249], [699, 499, 249, 0]))
+    ref = _oracle_loop_xl(E, sd, cfg, lat.clone(), ctx, pairs, [[7.0] * B] * 4, added)
+    e4 = rel_l2(out, ref)
+    print(f"[sdxl reverse] rel-L2 = {e4:.3e}")
+    assert e4 < 5e-3
+    # cfg 5: forward 3 steps (w = 0) from noised latents at t = 19, then reverse 3 steps with tau = 0.7, gs = 19
+    fwd, start = X.inverse_sample_deterministic(fpipe, lat.cuda().half(), ["x"] * B, num_inference_steps=3, timesteps=[19, 339, 699],
+                                                guidance_scale=0.0, is_sdxl=True, compute_embeddings_fn=emb, seed=3,
+                                                return_start_latent=True)
+    S = E["sched_ref"]
+    alpha, sigma = _tables(S)
+    noise = torch.randn(lat.shape, generator=torch.Generator().manual_seed(3), dtype=torch.float16).float()
+    x0 = start.float().cpu()                         # add_noise at t = 19 is scheduler plumbing (fp16 arithmetic as in diffusers)
+    assert rel_l2(x0, float(alpha[19]) * lat + float(sigma[19]) * noise) < 2e-3
+    ref_f = _oracle_loop_xl(E, sd, cfg, x0, ctx, list(zip([19, 339, 699], [339, 699, 999])), [[0.0] * B] * 3, added)
+    e5f = rel_l2(fwd, ref_f)
+    print(f"[sdxl forward] rel-L2 = {e5f:.3e}")
+    assert e5f < 5e-3
+    _, rev = X.sample_deterministic(pipe, ["x"] * B, latents=ref_f.cuda().half(), num_inference_steps=3, guidance_scale=19.0,
+                                    is_sdxl=True, timesteps=[339, 699, 999], compute_embeddings_fn=emb, return_latent=True,
+                                    use_dynamic_guidance=True, tau1=0.7, tau2=0.7)
+    ws = [[S.linear_schedule_old(t, 19.0, 0.7, 0.7)] * B for t in (999, 699, 339)]
+    assert [w[0] for w in ws] == [0.0, 19.0, 19.0]
+    ref_r = _oracle_loop_xl(E, sd, cfg, ref_f.half().float(), ctx, list(zip([999, 699, 339], [699, 339, 0])), ws, added)
+    e5r = rel_l2(rev, ref_r)
+    print(f"[sdxl dynamic reverse] rel-L2 = {e5r:.3e}")
+    assert e5r < 5e-3
+
+
+def _oracle_loop_xl(E, sd, cfg, x, ctx, pairs, w_vals, added):
+    """SDXL keeps fp16 latents between steps (utils/generation_sdxl.py:463)."""
+    S, U = E["sched_ref"], E["unet_ref"]
+    alpha, sigma = _tables(S)
+    ocfg = _ocfg(U, cfg)
+    B = x.shape[0]
+    for (t, s), w in zip(pairs, w_vals):
+        wemb = torch.from_numpy(S.guidance_scale_embedding(w, 512)).half().float()
+        eps = U.unet_forward(sd, ocfg, x, t, ctx, timestep_cond=wemb, added_cond=added).half().float()
+        x = torch.from_numpy(S.predicted_origin(eps.numpy(), [t] * B, [s] * B, x.numpy(), alpha, sigma)).half().float()
+    return x
+
+
+# ------------------------------------------------------------------------------------------ full-size properties
+@pytest.mark.slow
+def test_full_size_sd15_properties():
+    """BASELINE cfg 2 shape (SD1.5, B=32, 64x64 latents, 4 steps): determinism, batch independence, store structure."""
+    E = _env()
+    p2p, cfg = E["p2p"], E["SD15"]
+    sd = E["synthetic"].synthetic_state_dict(cfg, seed=0, device="cuda", dtype=torch.float16)
+    model = E["StableDiffusionPipeline"](E["unet"].UNet2DConditionModel(cfg, sd), E["DDIMScheduler"].sd15(),
+                                         tokenizer=E["synthetic"].SyntheticTokenizer(), device="cuda", dtype=torch.float16)
+    del sd
+    solver = E["generation"].Generator(model, 50, E["DDIMScheduler"].sd15(), forward_cons_model=model, reverse_cons_model=model,
+                                       reverse_timesteps=[259, 519, 779, 999], forward_timesteps=[19, 259, 519, 779])
+    B = 32
+    g = torch.Generator().manual_seed(453645634)
+    lat = torch.randn(B, 4, 64, 64, generator=g).cuda()
+    ctx = torch.randn(2 * B, 77, 768, generator=g).cuda().half()
+    solver.context = ctx
+    run = lambda l: solver.cons_generation(l, guidance_scale=7.0, w_embed_dim=512, dynamic_guidance=False, tau1=1.0, tau2=1.0)[-1]
+    a, b = run(lat), run(lat)
+    assert torch.isfinite(a).all() and torch.equal(a, b)                      # run-to-run bit reproducibility
+    # sample i does not depend on the rest of the batch (data-parallel sharding is exact): rerun rows 8..15 alone
+    solver.context = torch.cat([ctx[8:16], ctx[B + 8:B + 16]])
+    sub = run(lat[8:16].contiguous())
+    assert rel_l2(sub, a[8:16]) < 2e-3                                        # different tile plans -> fp rounding only
+    # cfg 3 shape: B = 8 with AttentionStore: 11 cross + 11 self stored per step with the reference's query counts
+    solver.context = torch.cat([ctx[:8], ctx[B:B + 8]])
+    store = p2p.AttentionStore()
+    p2p.register_attention_control(model, store)
+    solver.cons_generation(lat[:8].contiguous(), guidance_scale=7.0, w_embed_dim=512, dynamic_guidance=False, tau1=1.0, tau2=1.0,
+                           controller=store)
+    assert store.cur_step == 4
+    q = {k: [t.shape[1] for t in v] for k, v in store.attention_store.items()}
+    assert q["down_cross"] == q["down_self"] == [1024, 1024, 256, 256]
+    assert q["mid_cross"] == q["mid_self"] == [64]
+    assert q["up_cross"] == q["up_self"] == [256, 256, 256, 1024, 1024, 1024]
+    for k, v in store.attention_store.items():
+        for t in v:
+            assert t.shape[0] == 8 * 8 and t.shape[2] == (77 if "cross" in k else t.shape[1])
+            rows = (t.float() / 4).sum(-1)                                    # accumulated over 4 steps; each row a softmax
+            assert float((rows - 1).abs().max()) < 5e-3
+    p2p.register_attention_control(model, None)
+
+
+def test_boundary_step_round_trip_full_size():
+    """predicted_origin(t -> s) followed by (s -> t) with the same eps is the identity (B=32 x 4x64x64, and 128x128)."""
+    from invertible_cd_amd import ops
+    from oracle import sched_ref
+    ac = sched_ref.alphas_cumprod()
+    al, si = np.sqrt(ac), np.sqrt(1 - ac)
+    for shape in ((32, 4, 64, 64), (8, 4, 128, 128)):
+        g = torch.Generator().manual_seed(1)
+        x, eps = torch.randn(shape, generator=g).cuda(), torch.randn(shape, generator=g).cuda()
+        B = shape[0]
+        for t, s in ((999, 779), (519, 259), (19, 259)):
+            fwd = torch.tensor([[al[t], si[t], al[s], si[s]]] * B, dtype=torch.float32)
+            bwd = torch.tensor([[al[s], si[s], al[t], si[t]]] * B, dtype=torch.float32)
+            y = ops.x0_step(x, eps, fwd)
+            back = ops.x0_step(y, eps, bwd)
+            assert rel_l2(back, x) < 1e-5

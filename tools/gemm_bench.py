@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""GEMM / conv / attention microbenchmark through the C ABI (for A/B tuning and rocprofv3 --pmc runs).
+
+    python tools/gemm_bench.py conv 32 64 64 320 320        # B H W Cin Cout (3x3, stride 1)
+    python tools/gemm_bench.py dense 131072 320 320          # M N K
+    python tools/gemm_bench.py geglu 131072 2560 320
+    python tools/gemm_bench.py attn 32 8 4096 4096 40        # B H Nq Nk d
+"""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from invertible_cd_amd import ops
+
+kind = sys.argv[1]
+a = [int(x) for x in sys.argv[2:]]
+iters = int(os.environ.get("ITERS", "20"))
+dev = "cuda"
+g = torch.Generator(device=dev).manual_seed(0)
+rnd = lambda *s: torch.randn(*s, device=dev, generator=g).half()
+if kind == "conv":
+    B, H, W, Ci, Co = a
+    x, w, b = rnd(B * H * W, Ci), rnd(Co, 9 * Ci) * (9 * Ci) ** -0.5, torch.zeros(Co, device=dev)
+    import ctypes as C
+    from invertible_cd_amd import _lib
+    dbg = int(os.environ.get("DBGFLAGS", "0"), 0)
+    def fn():
+        out = torch.empty((B * H * W, Co), device=dev, dtype=torch.float16)
+        d = _lib.GemmDesc()
+        d.a0, d.w, d.out, d.bias = x.data_ptr(), w.data_ptr(), out.data_ptr(), b.data_ptr()
+        d.M, d.N, d.K, d.Nw, d.ldw, d.ldo = B * H * W, Co, 9 * Ci, Co, 9 * Ci, Co
+        d.rows_per_sample, d.mode, d.C0, d.Hin, d.Win, d.Hout, d.Wout, d.ksize, d.stride = H * W, 1, Ci, H, W, H, W, 3, 1
+        d.batch, d.zdiv, d.alpha, d.flags = 1, 1, 1.0, dbg
+        _lib.check(_lib.load().icd_gemm(C.byref(d), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        return out
+    flops = 2.0 * B * H * W * Co * 9 * Ci
+elif kind in ("dense", "geglu"):
+    M, N, K = a
+    x, w, b = rnd(M, K), rnd(N, K) * K ** -0.5, torch.zeros(N, device=dev)
+    res = None if kind == "geglu" else rnd(M, N)
+    fn = lambda: ops.gemm(x, w, bias=b, resid=res, geglu=kind == "geglu")
+    flops = 2.0 * M * N * K
+else:
+    B, H, Nq, Nk, d = a
+    q, k, v = rnd(B * Nq, H * d), rnd(B * Nk, H * d), rnd(B * Nk, H * d)
+    vt = v.reshape(B, Nk, H * d).transpose(1, 2).contiguous()
+    fn = lambda: ops.attention_fused(q, k, vt, B, H, Nq, Nk, d, d ** -0.5)
+    flops = 4.0 * B * H * Nq * Nk * d
+for _ in range(3):
+    fn()
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(iters):
+    fn()
+e1.record()
+torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / iters
+print(f"{kind} {a}: {ms * 1e3:.1f} us/call  {flops / ms / 1e9:.1f} TFLOP/s")

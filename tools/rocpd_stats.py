@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Summarise a rocprofv3 (rocpd sqlite) kernel trace: per-kernel calls / total / average / % - the `--stats` table.
+
+    python tools/rocpd_stats.py gpurun_out/prof/run_results.db > profiles/<name>.txt
+"""
+import re
+import sqlite3
+import sys
+
+
+def short(name):
+    name = re.sub(r"\(anonymous namespace\)::", "", name)
+    name = re.sub(r"\(.*\)$", "", name)
+    return name[:110]
+
+
+def main(path):
+    db = sqlite3.connect(path)
+    cols = [r[1] for r in db.execute("pragma table_info(kernels)")]
+    name_col = "name" if "name" in cols else [c for c in cols if "name" in c][0]
+    rows = db.execute(f"select {name_col}, start, end from kernels").fetchall()
+    agg = {}
+    for n, s, e in rows:
+        a = agg.setdefault(short(n), [0, 0, 1 << 62, 0])
+        d = e - s
+        a[0] += 1; a[1] += d; a[2] = min(a[2], d); a[3] = max(a[3], d)
+    total = sum(a[1] for a in agg.values())
+    span = max(r[2] for r in rows) - min(r[1] for r in rows)
+    print(f"# rocprofv3 --kernel-trace summary of {path}")
+    print(f"# {len(rows)} dispatches, sum of kernel durations {total / 1e6:.3f} ms, first-start..last-end span {span / 1e6:.3f} ms")
+    print(f"{'kernel':110s} {'calls':>7s} {'total_ms':>10s} {'avg_us':>10s} {'min_us':>9s} {'max_us':>9s} {'pct':>6s}")
+    for n, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        print(f"{n:110s} {a[0]:7d} {a[1] / 1e6:10.3f} {a[1] / a[0] / 1e3:10.2f} {a[2] / 1e3:9.2f} {a[3] / 1e3:9.2f} {100 * a[1] / total:6.2f}")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])

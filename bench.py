@@ -39,6 +39,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default 32 for sd15, 8 for sdxl)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
+    ap.add_argument("--no-ref-batching", action="store_true",
+                    help="skip the extra CFG-doubled measurement (use under rocprofv3 so kernel stats match the timed region)")
     return ap.parse_args()
 
 
@@ -169,7 +171,7 @@ def main():
 
     # the same loop with the reference's CFG-doubled batching (uncond rows computed and discarded), for the record
     ref_batching = None
-    if solver is not None and rank == 0:
+    if solver is not None and rank == 0 and not a.no_ref_batching:
         solver.eliminate_dead_uncond = False
         step(); torch.cuda.synchronize()
         t1 = time.perf_counter()

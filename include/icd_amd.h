@@ -216,8 +216,9 @@ typedef struct {
     double flops;     /* ALGORITHMIC flops (2*M*N*K incl. zero-padded taps; 4*B*H*Nq*Nk*d for attention) */
     double bytes;     /* ALGORITHMIC HBM bytes for the bandwidth-bound families */
 } icd_profile_row;
-/* enable != 0: start a fresh recording; enable == 0: stop.  While enabled every executor launch is bracketed by two
- * hipEventRecord calls on its stream. */
+/* enable > 0: start a fresh recording of every family; enable < 0: record only the families whose bit is set in
+ * (-enable) (bit k = family k; keeps the event overhead out of a timed region); enable == 0: stop.  While enabled every
+ * selected executor launch is bracketed by two hipEventRecord calls on its stream. */
 int icd_profile_enable(int32_t enable);
 /* After the stream has been synchronised: fills rows[0..ICD_PROF_KINDS) and returns the number of rows. */
 int icd_profile_read(icd_profile_row* rows, int32_t max_rows);

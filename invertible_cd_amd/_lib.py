@@ -128,8 +128,12 @@ def check(status, what=""):
         raise RuntimeError(f"libicd_amd {what} failed (status {status}): {msg}")
 
 
-def profile_enable(on=True):
-    check(load().icd_profile_enable(int(on)), "icd_profile_enable")
+def profile_enable(on=True, only=None):
+    """on: record every family; only=[family names]: record just those (less event overhead in a timed region)."""
+    arg = int(bool(on))
+    if on and only:
+        arg = -sum(1 << PROF_KINDS.index(k) for k in only)
+    check(load().icd_profile_enable(arg), "icd_profile_enable")
 
 
 def profile_read():

@@ -17,6 +17,8 @@ LIB = os.path.join(LIBDIR, "libicd_amd.so")
 SOURCES = ["gemm.hip", "norm.hip", "attention.hip", "elementwise.hip", "runtime.hip", "error.cpp"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
+# attention.hip: softmax max-chains need no NaN canonicalisation (infinities are still honoured for the key mask)
+EXTRA_FLAGS = {"attention.hip": ["-fno-honor-nans"]}
 
 
 def _deps():
@@ -30,7 +32,7 @@ def _compile(src, force):
     path = os.path.join(CSRC, src)
     if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(path), _deps()):
         return obj, False
-    cmd = [HIPCC] + FLAGS + (["-x", "hip"] if src.endswith(".hip") else []) + ["-c", path, "-o", obj]
+    cmd = [HIPCC] + FLAGS + EXTRA_FLAGS.get(src, []) + (["-x", "hip"] if src.endswith(".hip") else []) + ["-c", path, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")

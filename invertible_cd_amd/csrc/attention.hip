@@ -17,7 +17,13 @@
 //   * XCD-aware block order: the q-tiles of one (b, h) run on one XCD so its K/V stay in that XCD's L2.
 #include "common.h"
 
+#include <type_traits>
+
 namespace {
+
+__device__ const half_t icd_ones_page[64] = {
+    1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1,
+    1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
 
 template <int NCH>
 __device__ __forceinline__ int k_swz(int row, int chunk) {
@@ -38,6 +44,9 @@ struct AttnK {
 template <int KS, int DT>
 __global__ __launch_bounds__(256, 2) void attn_fused_kernel(AttnK p) {
     constexpr int NCH = 2 * KS;                       // 16-B chunks per K row
+    // when the padded head dim leaves a free V^T row (d = 40, 80, ...), that row is loaded with ones and the MFMA itself
+    // accumulates the softmax denominator (with exactly the fp16-rounded P the numerator uses): no VALU row sums
+    constexpr bool ONES = KS * 16 < DT * 32;
     constexpr int KT_BYTES = 64 * NCH * 16;           // K tile
     constexpr int VT_BYTES = DT * 32 * 128;           // V^T tile, 64 keys = 128 B per row
     constexpr int STAGE = KT_BYTES + VT_BYTES;
@@ -95,6 +104,7 @@ __global__ __launch_bounds__(256, 2) void attn_fused_kernel(AttnK p) {
             const int lc = pc ^ ((row >> 1) & 7);
             const int key = kv0 + lc * 8;
             const half_t* src = (row < p.d && key < p.ldvt) ? Vb + (long long)row * p.ldvt + key : zero;
+            if (ONES && row == DT * 32 - 1) src = icd_ones_page;
             glds16(src, sv + g * 1024);
         }
     };
@@ -104,61 +114,61 @@ __global__ __launch_bounds__(256, 2) void attn_fused_kernel(AttnK p) {
     for (int i = 0; i < DT; ++i)
 #pragma unroll
         for (int e = 0; e < 16; ++e) o[i][e] = 0.f;
+    // running max in RAW score units (the softmax scale is folded into the exp2 argument); running sum only when the
+    // MFMA cannot produce it (see ONES)
     float m_run = -INFINITY, l_run = 0.f;
+    const float c = p.scale_log2;
+    f32x16 zero16;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) zero16[e] = 0.f;
+    asm volatile("" : "+v"(zero16));          // keep it in registers: do not re-materialise 16 zeros per tile
 
-    const int nt = (p.Nk + 63) >> 6;
-    issue(0, 0);
-    for (int t = 0; t < nt; ++t) {
-        __builtin_amdgcn_s_waitcnt(0x0f70);
-        __syncthreads();
-        if (t + 1 < nt) issue(t + 1, (t + 1) & 1);
+    auto tile = [&](auto ragged_tag, int t) {
+        constexpr bool RAGGED = decltype(ragged_tag)::value;
         const unsigned char* sk = smem + (t & 1) * STAGE;
         const unsigned char* sv = sk + KT_BYTES;
-
         // ---- S^T[key][q] for two 32-key tiles ----
         f32x16 s[2];
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) s[kt][e] = 0.f;
             const int row = kt * 32 + lr;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                const int c = ks * 2 + lh;
-                f16x8 kf = *reinterpret_cast<const f16x8*>(sk + (row * NCH + k_swz<NCH>(row, c)) * 16);
-                s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s[kt], 0, 0, 0);
+                const int cc = ks * 2 + lh;
+                f16x8 kf = *reinterpret_cast<const f16x8*>(sk + (row * NCH + k_swz<NCH>(row, cc)) * 16);
+                // first k-step accumulates onto a persistent zero register block (no per-tile v_mov zeroing)
+                s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], ks == 0 ? zero16 : s[kt], 0, 0, 0);
             }
         }
         // ---- online softmax (lane owns query column lr; keys 32kt + 8g + 4lh + i) ----
-        const bool ragged = (t + 1) * 64 > p.Nk;
-        float mx = -INFINITY;
+        if (RAGGED) {
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
+            for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                float v = s[kt][e] * p.scale_log2;
-                if (ragged) {
+                for (int e = 0; e < 16; ++e) {
                     const int key = t * 64 + kt * 32 + 8 * (e >> 2) + 4 * lh + (e & 3);
-                    if (key >= p.Nk) v = -INFINITY;
+                    if (key >= p.Nk) s[kt][e] = -INFINITY;
                 }
-                s[kt][e] = v;
-                mx = fmaxf(mx, v);
-            }
+        }
+        float mx = fmaxf(s[0][0], s[1][0]);
+#pragma unroll
+        for (int e = 1; e < 16; ++e) mx = fmaxf(mx, fmaxf(s[0][e], s[1][e]));
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         const float m_new = fmaxf(m_run, mx);
-        const float alpha = exp2f(m_run - m_new);
-        float rs = 0.f;
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+        const float nmc = -m_new * c;
+        m_run = m_new;
         f16x8 pf[4];
+        float rs = 0.f;
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const float pv = exp2f(s[kt][e] - m_new);
-                rs += pv;
+                const float pv = __builtin_amdgcn_exp2f(fmaf(s[kt][e], c, nmc));
+                if (!ONES) rs += pv;
                 pf[kt * 2 + (e >> 3)][e & 7] = (half_t)pv;
             }
-        l_run = l_run * alpha + rs;
-        m_run = m_new;
+        if (!ONES) l_run = l_run * alpha + rs;
 #pragma unroll
         for (int i = 0; i < DT; ++i)
 #pragma unroll
@@ -178,9 +188,22 @@ __global__ __launch_bounds__(256, 2) void attn_fused_kernel(AttnK p) {
                 o[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[st], o[i], 0, 0, 0);
             }
         }
+    };
+
+    const int nt = (p.Nk + 63) >> 6;
+    const bool last_ragged = (p.Nk & 63) != 0;
+    issue(0, 0);
+    for (int t = 0; t < nt; ++t) {
+        __builtin_amdgcn_s_waitcnt(0x0f70);
+        __syncthreads();
+        if (t + 1 < nt) issue(t + 1, (t + 1) & 1);
+        if (last_ragged && t == nt - 1) tile(std::true_type{}, t);
+        else tile(std::false_type{}, t);
     }
     // ---- normalise and store: lane holds 4 consecutive head-dim columns of query row q0+lr ----
-    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    float l_tot;
+    if (ONES) l_tot = __shfl(o[DT - 1][15], lr + 32);      // row DT*32-1 of O^T = sum_k P (the V^T ones-row), held by the upper half
+    else l_tot = l_run + __shfl_xor(l_run, 32);
     const float inv = 1.0f / l_tot;
     const int qrow = q0 + lr;
     if (qrow < p.Nq) {

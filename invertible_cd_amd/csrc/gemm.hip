@@ -557,6 +557,8 @@ extern "C" int icd_gemm(const icd_gemm_desc* d, void* stream) {
     int wm = 2, ks = 1;
     const bool allow_split = !trans && !geglu && batch == 1 && d->splitk_ws != nullptr && d->splitk_ws_bytes > 0;
     plan_gemm(d->M, d->N, d->K, batch, allow_split, d->splitk_ws_bytes, &wm, &ks);
+    if (d->flags & 0x40000) { wm = 2; ks = 1; }          // tuning overrides (tools/gemm_bench.py)
+    if (d->flags & 0x80000) { wm = 4; ks = 1; }
     const int nk_total = (d->K + BK - 1) / BK;
     k.ksplit = ks;
     k.kt_per_split = (nk_total + ks - 1) / ks;

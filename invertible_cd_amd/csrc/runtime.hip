@@ -22,6 +22,7 @@ struct Tensor { const void* ptr; int dtype; long long numel; };
 // ---- per-family launch timing (HIP events on the launch stream) ------------------------------------------------
 struct ProfRec { hipEvent_t a, b; int kind; double flops, bytes; int M, N, K, aux; };
 bool g_prof_on = false;
+unsigned g_prof_mask = 0xffffffffu;     // bit k: record launches of family k
 std::vector<ProfRec> g_prof;
 std::vector<hipEvent_t> g_ev_pool;
 
@@ -34,7 +35,7 @@ hipEvent_t prof_event() {
 struct ProfScope {
     bool on; hipStream_t st; size_t idx;
     ProfScope(bool active, hipStream_t s, int kind, double flops, double bytes, int M = 0, int N = 0, int K = 0, int aux = 0)
-        : on(active && g_prof_on), st(s), idx(0) {
+        : on(active && g_prof_on && ((g_prof_mask >> kind) & 1u)), st(s), idx(0) {
         if (!on) return;
         ProfRec r{prof_event(), prof_event(), kind, flops, bytes, M, N, K, aux};
         (void)hipEventRecord(r.a, st);
@@ -504,6 +505,7 @@ extern "C" int icd_profile_enable(int32_t enable) {
     for (auto& r : g_prof) { g_ev_pool.push_back(r.a); g_ev_pool.push_back(r.b); }
     g_prof.clear();
     g_prof_on = enable != 0;
+    g_prof_mask = enable > 0 ? 0xffffffffu : (unsigned)(-enable);     // enable < 0: bit mask of the families to record
     return ICD_OK;
 }
 

@@ -37,7 +37,18 @@ elif kind in ("dense", "geglu"):
     M, N, K = a
     x, w, b = rnd(M, K), rnd(N, K) * K ** -0.5, torch.zeros(N, device=dev)
     res = None if kind == "geglu" else rnd(M, N)
-    fn = lambda: ops.gemm(x, w, bias=b, resid=res, geglu=kind == "geglu")
+    import ctypes as C
+    from invertible_cd_amd import _lib
+    dbg = int(os.environ.get("DBGFLAGS", "0"), 0)
+    def fn():
+        out = torch.empty((M, N // 2 if kind == "geglu" else N), device=dev, dtype=torch.float16)
+        d = _lib.GemmDesc()
+        d.a0, d.w, d.out, d.bias = x.data_ptr(), w.data_ptr(), out.data_ptr(), b.data_ptr()
+        d.resid = res.data_ptr() if res is not None else None
+        d.M, d.N, d.K, d.Nw, d.lda, d.ldw, d.ldo, d.ldr = M, N, K, N, K, K, out.stride(0), N
+        d.mode, d.batch, d.zdiv, d.alpha, d.flags = 0, 1, 1, 1.0, dbg | (1 if kind == "geglu" else 0)
+        _lib.check(_lib.load().icd_gemm(C.byref(d), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        return out
     flops = 2.0 * M * N * K
 else:
     B, H, Nq, Nk, d = a

@@ -1,4 +1,3 @@
-python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-ref-batching --no-profile 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('no-profile', d['value'], d['ms_per_step'])"
-python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-ref-batching 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('profile', d['value'], d['ms_per_step'], d['gpu_busy_ms_in_profiled_kernels']/5)"
-python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-ref-batching --no-profile --batch 4 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('B=4 no-profile', d['value'], d['ms_per_step'])"
-python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-ref-batching --batch 4 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('B=4 profile', d['value'], d['ms_per_step'], d['gpu_busy_ms_in_profiled_kernels']/5)"
+python -m pytest tests -m gpu -q --timeout 900 -x 2>&1 | tail -4
+python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-ref-batching 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('SD15', d['value'], d['ms_per_step'], d['roofline']); [print('  ',k, v) for k,v in d['kernel_families'].items()]"
+python bench.py --arch sdxl --steps 2 --warmup 2 --no-cpu-baseline 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('SDXL', d['value'], d['ms_per_step'], d['roofline']); [print('  ',k, v) for k,v in d['kernel_families'].items()]"

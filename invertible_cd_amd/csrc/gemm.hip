@@ -24,43 +24,15 @@
 //     stores, with bias / time-bias / residual / GEGLU applied once, in fp32, before the single fp16 rounding.
 //   * blockIdx -> tile mapping is XCD-aware (block b runs on XCD b%8): every XCD gets a contiguous range of tiles
 //     so the n-tiles that share an activation tile hit the same private L2.
+#include <algorithm>
 #include <type_traits>
-#include "common.h"
+#include "gemm_common.h"
+
+using namespace icd_gemm_detail;
 
 namespace {
 
-constexpr int BN = 128, BK = 64;
-constexpr int EPI_LD = 132;                      // fp32 staging row stride (floats) for a 64x128 slab
-constexpr int EPI_LD_T = 68;                     // transposed staging: 128 rows (n) x 64 (m)
-
-struct GemmK {
-    const half_t* a0; const half_t* a1; const half_t* w;
-    const float* bias; const half_t* rowbias; const half_t* resid; void* out;
-    float* partial;                              // split-K: fp32 [S][M][N]
-    int M, N, K, Nw;
-    int lda, ldw, ldo, ldr, ld_rowbias, rps;
-    int C0, C1, Hin, Win, Hout, Wout, ksize, stride, upsample;
-    int zdiv; long long a_bs0, a_bs1, w_bs0, w_bs1, o_bs0, o_bs1;
-    float alpha; int flags;
-    int nbm, nbn, ksplit, kt_per_split;
-};
-
-__device__ __forceinline__ int swz_off(int row, int chunk) {        // byte offset inside a [rows][64] half tile
-    return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
-}
-
-// erf with |error| < 1.5e-7 (Abramowitz & Stegun 7.1.26): plenty for an fp16 result, ~4x cheaper than erff
-__device__ __forceinline__ float erf_fast(float x) {
-    const float ax = fabsf(x);
-    const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
-    float p = fmaf(1.061405429f, t, -1.453152027f);
-    p = fmaf(p, t, 1.421413741f);
-    p = fmaf(p, t, -0.284496736f);
-    p = fmaf(p, t, 0.254829592f);
-    const float y = 1.0f - p * t * __expf(-ax * ax);
-    return copysignf(y, x);
-}
-__device__ __forceinline__ float gelu_fast(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752f)); }
+constexpr int BN = 128;
 
 // MODE 0: dense A [M,K] (lda);  MODE 1: conv, Cin % 64 == 0 && C0 % 64 == 0 (tap / concat source are wave-uniform
 // per k-tile and tracked in SGPRs);  MODE 2: conv, any Cin % 8 == 0 (per-lane tap tracking; reduced-width test nets).
@@ -480,6 +452,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmK p) {
     }
 }
 
+int launch_reduce(const GemmK& k, hipStream_t st) {
+    const long long items = (long long)k.M * (k.N >> 3);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, k);
+    ICD_CHECK_LAUNCH("icd_gemm(split-K reduce)");
+    return ICD_OK;
+}
+
 template <int MODE, bool TRANS, int WM, int NSTAGE>
 int launch(const GemmK& k, int batch, hipStream_t st) {
     constexpr int smem = NSTAGE * (WM * 64 + BN) * 128;
@@ -492,11 +471,7 @@ int launch(const GemmK& k, int batch, hipStream_t st) {
     dim3 grid(k.nbm * k.nbn, k.ksplit, batch);
     hipLaunchKernelGGL((gemm_kernel<MODE, TRANS, WM, NSTAGE>), grid, dim3(WM * 128), smem, st, k);
     ICD_CHECK_LAUNCH("icd_gemm");
-    if (k.ksplit > 1) {
-        const long long items = (long long)k.M * (k.N >> 3);
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, k);
-        ICD_CHECK_LAUNCH("icd_gemm(split-K reduce)");
-    }
+    if (k.ksplit > 1) return launch_reduce(k, st);
     return ICD_OK;
 }
 
@@ -524,7 +499,19 @@ static void plan_gemm(int M, int N, int K, int batch, bool allow_split, long lon
 extern "C" int64_t icd_gemm_workspace_bytes(int32_t M, int32_t N, int32_t K) {
     int wm, ks;
     plan_gemm(M, N, K, 1, true, 1LL << 60, &wm, &ks);
-    return ks > 1 ? (int64_t)ks * M * N * 4 : 0;
+    int64_t need = ks > 1 ? (int64_t)ks * M * N * 4 : 0;
+    const int nk = (K + 63) / 64;
+    for (int tn = 4; tn <= 5; ++tn) {                                         // the big-tile plans may split deeper
+        if ((tn == 5 && N % 320 != 0) || (tn == 4 && N % 256 != 0) || M < 256 || K % 64 != 0) continue;
+        const long long blocks = (long long)((M + 255) / 256) * (N / (64 * tn));
+        if (blocks < 192 && nk >= 16) {
+            int s = (int)((256 + blocks - 1) / blocks);
+            s = s > 8 ? 8 : s;
+            while (s > 1 && nk / s < 8) --s;
+            if (s > 1) need = std::max<int64_t>(need, (int64_t)s * M * N * 4);
+        }
+    }
+    return need;
 }
 
 extern "C" int icd_gemm(const icd_gemm_desc* d, void* stream) {
@@ -556,15 +543,64 @@ extern "C" int icd_gemm(const icd_gemm_desc* d, void* stream) {
     const int batch = d->batch > 0 ? d->batch : 1;
     int wm = 2, ks = 1;
     const bool allow_split = !trans && !geglu && batch == 1 && d->splitk_ws != nullptr && d->splitk_ws_bytes > 0;
+    const int nk_total = (d->K + BK - 1) / BK;
+    hipStream_t st = (hipStream_t)stream;
+    // ---- high-intensity tiles (gemm_big.hip): 256x320 when N % 320 == 0, 256x256 for GEGLU / N % 256 == 0 -------------
+    {
+        const bool conv_fast = d->mode == 1 && ((d->C0 + d->C1) % 64 == 0) && (d->C0 % 64 == 0);
+        // candidates: 256x320 tiles (N % 320 == 0; TN = 5 cannot pair GEGLU columns) and 256x256 tiles (N % 256 == 0).
+        // Pick the one that fills the 256 CUs best (whole rounds); ties go to the larger tile.
+        const bool base_ok = batch == 1 && !trans && (d->mode == 0 || conv_fast) && d->M >= 256 && (d->Nw <= 0 || d->Nw >= d->N) &&
+                             (d->K % 64 == 0) && !(d->flags & 0x200000);
+        int tn = 0, s = 1;
+        long long blocks = 0;
+        double best = 0.0;
+        const int cand[2] = {5, 4};
+        for (int ci = 0; ci < 2 && base_ok; ++ci) {
+            const int c = cand[ci];
+            if (c == 5 && (geglu || d->N % 320 != 0 || (d->flags & 0x400000))) continue;
+            if (c == 4 && d->N % 256 != 0) continue;
+            const long long b0 = (long long)((d->M + 255) / 256) * (d->N / (64 * c));
+            int sc = 1;
+            if (allow_split && b0 < 192 && nk_total >= 16) {
+                sc = (int)((256 + b0 - 1) / b0);
+                sc = sc > 8 ? 8 : sc;
+                while (sc > 1 && nk_total / sc < 8) --sc;
+                while (sc > 1 && (long long)sc * d->M * d->N * 4 > d->splitk_ws_bytes) --sc;
+            }
+            const long long bt = b0 * sc;
+            double eff = (double)bt / (double)(((bt + 255) / 256) * 256);
+            if (sc > 1) eff *= 0.85;                    // fp32 partial round trip
+            if (eff > best + 1e-9) { best = eff; tn = c; s = sc; blocks = b0; }
+        }
+        const bool eligible = tn != 0;
+        if (eligible) {
+            if (best >= 0.6 || (d->flags & 0x100000)) {
+                k.nbm = (d->M + 255) / 256; k.nbn = d->N / (64 * tn);
+                k.kt_per_split = (nk_total + s - 1) / s;
+                k.ksplit = (nk_total + k.kt_per_split - 1) / k.kt_per_split;
+                if (d->mode == 1) {
+                    ICD_CHECK_ARG(d->ksize == 1 || d->ksize == 3, "icd_gemm: conv ksize must be 1 or 3");
+                    ICD_CHECK_ARG(d->K == d->ksize * d->ksize * (d->C0 + d->C1), "icd_gemm: K != taps*Cin");
+                    ICD_CHECK_ARG((d->C1 == 0) == (d->a1 == nullptr), "icd_gemm: a1/C1 mismatch");
+                } else {
+                    k.ksize = 0; k.Hout = 0;
+                    ICD_CHECK_ARG(d->lda % 8 == 0, "icd_gemm: lda must be a multiple of 8");
+                }
+                const int rc = launch_big(k, tn, st);
+                if (rc != ICD_OK) return rc;
+                if (k.ksplit > 1) return launch_reduce(k, st);
+                return ICD_OK;
+            }
+        }
+    }
     plan_gemm(d->M, d->N, d->K, batch, allow_split, d->splitk_ws_bytes, &wm, &ks);
     if (d->flags & 0x40000) { wm = 2; ks = 1; }          // tuning overrides (tools/gemm_bench.py)
     if (d->flags & 0x80000) { wm = 4; ks = 1; }
-    const int nk_total = (d->K + BK - 1) / BK;
     k.ksplit = ks;
     k.kt_per_split = (nk_total + ks - 1) / ks;
     k.ksplit = (nk_total + k.kt_per_split - 1) / k.kt_per_split;      // no empty splits
     k.nbm = (d->M + wm * 64 - 1) / (wm * 64); k.nbn = (d->N + BN - 1) / BN;
-    hipStream_t st = (hipStream_t)stream;
     if (d->mode == 1) {
         ICD_CHECK_ARG(d->ksize == 1 || d->ksize == 3, "icd_gemm: conv ksize must be 1 or 3");
         ICD_CHECK_ARG(d->stride == 1 || d->stride == 2, "icd_gemm: conv stride must be 1 or 2");

@@ -1,0 +1,374 @@
+// gemm_big.hip - high-arithmetic-intensity GEMM / implicit-GEMM conv tiles for the large layers of the UNets.
+//
+// Why a second tile family: with 128-wide tiles the main loop is bound by the LDS ports (fragment reads + the
+// global_load_lds DMA writes) and by global->LDS bandwidth (1/64..1/85 B per flop), see DESIGN.md section 4.  Here:
+//   * block tile 256 x 256 x 64, 8 waves (2 x 4), wave tile 128 x 64 = 4 x 2 v_mfma_f32_32x32x16_f16 (128 accumulator
+//     registers): 6 ds_read_b128 per 8 MFMAs (0.75 vs 1.0 for the 64 x 64 wave tile), 1/128 B of DMA per flop (vs 1/64).
+//     (A one-wave-per-SIMD variant with 128 x 160 wave tiles in the 512-entry register file was tried: hipcc spills
+//     hundreds of registers once the accumulators exceed the 256 AGPRs - that form needs hand-written asm.)
+//   * serves every layer with N % 256 == 0: the GEGLU projections (N = 8C) and the 1280-channel convs / Linears.
+//   * 2 LDS stages of 64 KiB.  The barrier of k-tile t+1 is taken in the shadow of the last sub-step's 8 queued MFMAs of
+//     k-tile t: wait vmcnt -> s_barrier -> issue the loads of t+2 -> prefetch the first fragments of t+1.
+//   * Loader, swizzle, epilogue and split-K are those of gemm.hip (same LDS image, same epilogue arithmetic).
+#include <type_traits>
+#include "gemm_common.h"
+
+using namespace icd_gemm_detail;
+
+namespace {
+
+constexpr int enc_vmcnt(int n) { return ((n >> 4) << 14) | 0x0F70 | (n & 15); }
+
+template <int MODE, int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(WM * WN * 64, 2) void gemm_big_kernel(GemmK p) {
+    constexpr int NT = WM * WN * 64;
+    constexpr int BM = WM * TM * 32, BNt = WN * TN * 32;
+    constexpr int A_BYTES = BM * 128, W_BYTES = BNt * 128, STAGE_BYTES = A_BYTES + W_BYTES;
+    constexpr int NAJ = BM * 8 / NT, NWJ = BNt * 8 / NT;        // 16-B chunks per thread per stage
+    constexpr int LOADS = NAJ + NWJ;
+    constexpr int LD = BNt + 4;                                  // fp32 staging row stride (floats)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, wv = tid >> 6, l = tid & 63;
+    const int wm = wv / WN, wn = wv - wm * WN;
+
+    const int nblk = p.nbm * p.nbn;
+    int bid = blockIdx.x;
+    {
+        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int mt = bid / p.nbn, nt = bid - mt * p.nbn;
+    const int m0 = mt * BM, n0 = nt * BNt;
+    const int split = blockIdx.y;
+    const int nk_total = (p.K + BK - 1) / BK;
+    const int kt_begin = split * p.kt_per_split;
+    const int nk = min(nk_total, kt_begin + p.kt_per_split) - kt_begin;
+    const half_t* zero = reinterpret_cast<const half_t*>(icd_zero_page);
+
+    // ---- loader state (see gemm.hip: biased pointers, zero-page parking, one M0 per group of 4 chunks) ----------
+    const int lrow = l >> 3, pchunk = l & 7;
+    const int Cin = p.C0 + p.C1;
+    const int ntaps = p.ksize * p.ksize, pad = p.ksize >> 1;
+    const int Hu = p.Hin << p.upsample, Wu = p.Win << p.upsample;
+    const int k_begin = kt_begin * BK;
+
+    const half_t* a_ptr[NAJ]; int a_inc[NAJ];
+    int a_pix[NAJ], a_yx[NAJ];                   // conv: b*Hin*Win (or -1 when the row is >= M), (y << 16) | x
+    const half_t* w_ptr[NWJ]; int w_inc[NWJ];
+#pragma unroll
+    for (int j = 0; j < NAJ; ++j) {
+        const int r = (wv * NAJ + j) * 8 + lrow;
+        const int lc = pchunk ^ ((r >> 1) & 7);
+        const int m = m0 + r;
+        const int boff = (j & 3) * 512;          // bias for the instruction's immediate offset (halves)
+        a_ptr[j] = zero - boff; a_inc[j] = 0; a_pix[j] = -1; a_yx[j] = 0;
+        if (m < p.M) {
+            if (MODE == 0) {
+                a_ptr[j] = p.a0 + (long long)m * p.lda + k_begin + lc * 8 - boff; a_inc[j] = BK;
+            } else {
+                const int hw = p.Hout * p.Wout;
+                const int b = m / hw, rem = m - b * hw;
+                const int y = rem / p.Wout;
+                a_yx[j] = (y << 16) | (rem - y * p.Wout);
+                a_pix[j] = b * p.Hin * p.Win;
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NWJ; ++j) {
+        const int r = (wv * NWJ + j) * 8 + lrow;
+        const int lc = pchunk ^ ((r >> 1) & 7);
+        const int n = n0 + r;
+        const bool ok = n < p.Nw;
+        const int boff = (j & 3) * 512;
+        w_ptr[j] = ok ? p.w + (long long)n * p.ldw + k_begin + lc * 8 - boff : zero - boff;
+        w_inc[j] = ok ? BK : 0;
+    }
+    int u_tap = MODE == 1 ? k_begin / Cin : 0;
+    int u_c = MODE == 1 ? k_begin - u_tap * Cin : 0;
+    bool u_recompute = true;
+
+    const int wave_a = __builtin_amdgcn_readfirstlane(wv * NAJ * 1024);
+    const int wave_w = __builtin_amdgcn_readfirstlane(A_BYTES + wv * NWJ * 1024);
+
+#define GLDS(PTR, BASE, IMM)                                                                              \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(PTR),                \
+                                     (__attribute__((address_space(3))) void*)(BASE), 16, IMM, 0)
+
+    auto issue_stage = [&](int stage_off) {
+        unsigned char* sa = smem + stage_off + wave_a;
+        unsigned char* sw = smem + stage_off + wave_w;
+        if (MODE == 1) {
+            if (u_recompute) {
+                const int dy = (u_tap * 11) >> 5, dx = u_tap - dy * 3;
+                const int oy = (ntaps == 9 ? dy : 0) - pad, ox = (ntaps == 9 ? dx : 0) - pad;
+                const bool first = u_c < p.C0;
+#pragma unroll
+                for (int j = 0; j < NAJ; ++j) {
+                    const int r = (wv * NAJ + j) * 8 + lrow;
+                    const int lc = pchunk ^ ((r >> 1) & 7);
+                    const int yu = (a_yx[j] >> 16) * p.stride + oy, xu = (a_yx[j] & 0xffff) * p.stride + ox;
+                    const bool ok = a_pix[j] >= 0 && (unsigned)yu < (unsigned)Hu && (unsigned)xu < (unsigned)Wu;
+                    const long long pix = a_pix[j] + (yu >> p.upsample) * p.Win + (xu >> p.upsample);
+                    const half_t* s0 = first ? p.a0 + pix * p.C0 + u_c : p.a1 + pix * p.C1 + (u_c - p.C0);
+                    a_ptr[j] = (ok ? s0 + lc * 8 : zero) - (j & 3) * 512;
+                    a_inc[j] = ok ? BK : 0;
+                }
+            }
+            u_c += BK;
+            u_recompute = false;
+            if (u_c == Cin) { u_c = 0; ++u_tap; u_recompute = true; }
+            else if (u_c == p.C0) u_recompute = true;
+        }
+#pragma unroll
+        for (int j = 0; j < NAJ; ++j) {
+            unsigned char* base = sa + (j >> 2) * 4096;
+            if ((j & 3) == 0) GLDS(a_ptr[j], base, 0);
+            else if ((j & 3) == 1) GLDS(a_ptr[j], base, 1024);
+            else if ((j & 3) == 2) GLDS(a_ptr[j], base, 2048);
+            else GLDS(a_ptr[j], base, 3072);
+            a_ptr[j] += a_inc[j];
+        }
+#pragma unroll
+        for (int j = 0; j < NWJ; ++j) {
+            unsigned char* base = sw + (j >> 2) * 4096;
+            if ((j & 3) == 0) GLDS(w_ptr[j], base, 0);
+            else if ((j & 3) == 1) GLDS(w_ptr[j], base, 1024);
+            else if ((j & 3) == 2) GLDS(w_ptr[j], base, 2048);
+            else GLDS(w_ptr[j], base, 3072);
+            w_ptr[j] += w_inc[j];
+        }
+    };
+#undef GLDS
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // ---- LDS read addresses per stage -----------------------------------------------------------------------
+    const int lr = l & 31, lh = l >> 5;
+    int rd_a[2][4], rd_w[2][4];
+    {
+        const int x = (lr >> 1) & 7;
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const int off = ((s4 * 2 + lh) ^ x) << 4;
+                rd_a[st][s4] = st * STAGE_BYTES + (wm * TM * 32 + lr) * 128 + off;
+                rd_w[st][s4] = st * STAGE_BYTES + A_BYTES + (wn * TN * 32 + lr) * 128 + off;
+            }
+    }
+    f16x8 af[2][TM], wf[2][TN];               // set 1 is unused (and dead-code eliminated) without DBUF
+    auto load_frags = [&](auto st_tag, auto s_tag, auto set_tag) {
+        constexpr int ST = decltype(st_tag)::value, S4 = decltype(s_tag)::value, SET = decltype(set_tag)::value;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[SET][i] = *reinterpret_cast<const f16x8*>(smem + rd_a[ST][S4] + i * 4096);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) wf[SET][j] = *reinterpret_cast<const f16x8*>(smem + rd_w[ST][S4] + j * 4096);
+    };
+    auto mfmas = [&](auto set_tag) {
+        constexpr int SET = decltype(set_tag)::value;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[SET][j], af[SET][i], acc[i][j], 0, 0, 0);
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>;
+
+    // ---- prologue: tiles 0 and 1 in flight, wait for tile 0 ------------------------------------------------------
+    issue_stage(0);
+    if (nk > 1) { issue_stage(STAGE_BYTES); __builtin_amdgcn_s_waitcnt(enc_vmcnt(LOADS)); }
+    else __builtin_amdgcn_s_waitcnt(enc_vmcnt(0));
+    __builtin_amdgcn_s_barrier();
+    load_frags(I0{}, I0{}, I0{});
+
+    // register double-buffering of the fragments only where the accumulators leave room (128 x 64 wave tile)
+    constexpr bool DBUF = TM * TN <= 8;
+    auto k_tile = [&](auto st_tag, int t) {
+        constexpr int ST = decltype(st_tag)::value;
+        using STt = std::integral_constant<int, ST>;
+        using SNt = std::integral_constant<int, ST ^ 1>;
+        if (DBUF) {
+            load_frags(STt{}, I1{}, I1{});
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(I0{});
+            load_frags(STt{}, I2{}, I0{});
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(I1{});
+            load_frags(STt{}, I3{}, I1{});
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(I0{});
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(I1{});                         // last sub-step: its MFMAs are queued on the matrix pipe ...
+        } else {
+            mfmas(I0{});
+            load_frags(STt{}, I1{}, I0{});
+            mfmas(I0{});
+            load_frags(STt{}, I2{}, I0{});
+            mfmas(I0{});
+            load_frags(STt{}, I3{}, I0{});
+            mfmas(I0{});
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 1 < nk) {                        // ... and in their shadow: hand over to the next k-tile
+            __builtin_amdgcn_s_waitcnt(enc_vmcnt(0));          // tile t+1 has landed (this wave's part)
+            __builtin_amdgcn_s_barrier();                      // everybody's part landed; everybody done reading stage ST
+            if (t + 2 < nk) issue_stage(ST * STAGE_BYTES);     // tile t+2 -> the stage just released
+            load_frags(SNt{}, I0{}, I0{});
+        }
+    };
+    for (int t = 0; t < nk; t += 2) {
+        k_tile(I0{}, t);
+        if (t + 1 < nk) k_tile(I1{}, t + 1);
+    }
+
+    // ---- epilogue: 4 slabs of 64 rows, fp32 staging through LDS --------------------------------------------------
+    float* stage = reinterpret_cast<float*>(smem);
+    const bool geglu = p.flags & ICD_GEMM_GEGLU;
+    const bool out_f32 = p.flags & ICD_GEMM_OUT_F32;
+    constexpr int SLABS = BM / 64;
+#pragma unroll
+    for (int slab = 0; slab < SLABS; ++slab) {
+        __syncthreads();
+        constexpr int SPW = SLABS / WM;                  // slabs per wave row
+        constexpr int IPW = TM / SPW;                    // i-tiles of one wave per slab (2)
+        if (wm == slab / SPW) {
+#pragma unroll
+            for (int ii = 0; ii < IPW; ++ii)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x16& a = acc[(slab % SPW) * IPW + ii][j];
+                        f32x4 v = {a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]};
+                        *reinterpret_cast<f32x4*>(stage + (ii * 32 + lr) * LD + wn * TN * 32 + j * 32 + 8 * g + 4 * lh) = v;
+                    }
+        }
+        __syncthreads();
+        const int mbase = m0 + slab * 64;
+        if (p.ksplit > 1) {
+            float* part = p.partial + (long long)split * p.M * p.N;
+            constexpr int CH = BNt / 8;
+#pragma unroll
+            for (int pass = 0; pass < 64 * CH / NT; ++pass) {
+                const int item = pass * NT + tid;
+                const int r = item / CH, c8 = (item - r * CH) * 8;
+                const int m = mbase + r, n = n0 + c8;
+                if (m >= p.M || n >= p.N) continue;
+                const float* sp = stage + r * LD + c8;
+                float* dst = part + (long long)m * p.N + n;
+                *reinterpret_cast<f32x4*>(dst) = *reinterpret_cast<const f32x4*>(sp);
+                *reinterpret_cast<f32x4*>(dst + 4) = *reinterpret_cast<const f32x4*>(sp + 4);
+            }
+        } else if (geglu) {
+            half_t* out = reinterpret_cast<half_t*>(p.out);
+            constexpr int CH = BNt / 16;                 // 8-wide output chunks per row (BNt/2 output columns)
+#pragma unroll
+            for (int pass = 0; pass < 64 * CH / NT; ++pass) {
+                const int item = pass * NT + tid;
+                const int r = item / CH, oc = (item - r * CH) * 8;
+                const int m = mbase + r;
+                const int hcol = (oc >> 5) * 64 + (oc & 31);
+                if (m >= p.M || n0 + hcol >= p.N) continue;
+                const float* sp = stage + r * LD + hcol;
+                f32x4 h0 = *reinterpret_cast<const f32x4*>(sp), h1 = *reinterpret_cast<const f32x4*>(sp + 4);
+                f32x4 g0 = *reinterpret_cast<const f32x4*>(sp + 32), g1 = *reinterpret_cast<const f32x4*>(sp + 36);
+                float hv[8] = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+                float gv[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
+                if (p.bias) {
+                    const float* bp = p.bias + n0 + hcol;
+                    f32x4 b0 = *reinterpret_cast<const f32x4*>(bp), b1 = *reinterpret_cast<const f32x4*>(bp + 4);
+                    f32x4 c0 = *reinterpret_cast<const f32x4*>(bp + 32), c1 = *reinterpret_cast<const f32x4*>(bp + 36);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        hv[e] = hv[e] * p.alpha + b0[e]; hv[4 + e] = hv[4 + e] * p.alpha + b1[e];
+                        gv[e] = gv[e] * p.alpha + c0[e]; gv[4 + e] = gv[4 + e] * p.alpha + c1[e];
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { hv[e] *= p.alpha; gv[e] *= p.alpha; }
+                }
+                f16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (half_t)(hv[e] * gelu_fast(gv[e]));
+                *reinterpret_cast<f16x8*>(out + (long long)m * p.ldo + (n0 >> 1) + oc) = o;
+            }
+        } else {
+            constexpr int CH = BNt / 8;
+#pragma unroll
+            for (int pass = 0; pass < 64 * CH / NT; ++pass) {
+                const int item = pass * NT + tid;
+                const int r = item / CH, c8 = (item - r * CH) * 8;
+                const int m = mbase + r, n = n0 + c8;
+                if (m >= p.M || n >= p.N) continue;
+                const float* sp = stage + r * LD + c8;
+                f32x4 v0 = *reinterpret_cast<const f32x4*>(sp), v1 = *reinterpret_cast<const f32x4*>(sp + 4);
+                float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] *= p.alpha;
+                if (p.bias) {
+                    f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n), b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
+                }
+                if (p.rowbias) {
+                    f16x8 rb = *reinterpret_cast<const f16x8*>(p.rowbias + (long long)(m / p.rps) * p.ld_rowbias + n);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += (float)rb[e];
+                }
+                if (p.resid) {
+                    f16x8 rs = *reinterpret_cast<const f16x8*>(p.resid + (long long)m * p.ldr + n);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += (float)rs[e];
+                }
+                if (out_f32) {
+                    float* out = reinterpret_cast<float*>(p.out) + (long long)m * p.ldo + n;
+                    *reinterpret_cast<f32x4*>(out) = (f32x4){v[0], v[1], v[2], v[3]};
+                    *reinterpret_cast<f32x4*>(out + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+                } else {
+                    f16x8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = (half_t)v[e];
+                    *reinterpret_cast<f16x8*>(reinterpret_cast<half_t*>(p.out) + (long long)m * p.ldo + n) = o;
+                }
+            }
+        }
+    }
+}
+
+template <int MODE, int WM, int WN, int TM, int TN>
+int launch_one(const GemmK& k, hipStream_t st) {
+    constexpr int smem = 2 * (WM * TM * 32 + WN * TN * 32) * 128;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_big_kernel<MODE, WM, WN, TM, TN>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_big_kernel<MODE, WM, WN, TM, TN>), dim3(k.nbm * k.nbn, k.ksplit, 1), dim3(WM * WN * 64), smem, st, k);
+    ICD_CHECK_LAUNCH("icd_gemm(big tile)");
+    return ICD_OK;
+}
+
+}  // namespace
+
+namespace icd_gemm_detail {
+
+// k.nbm / k.nbn / k.ksplit / k.kt_per_split are set by the caller for BM = 256, BN = 64 * tn
+int launch_big(const GemmK& k, int tn, hipStream_t st) {
+    const bool conv = k.ksize > 0 && k.Hout > 0;
+    if (tn == 5)                                 // 256 x 320: 8 waves (4 x 2), wave tile 64 x 160 (N % 320 == 0, no GEGLU)
+        return conv ? launch_one<1, 4, 2, 2, 5>(k, st) : launch_one<0, 4, 2, 2, 5>(k, st);
+    return conv ? launch_one<1, 2, 4, 4, 2>(k, st) : launch_one<0, 2, 4, 4, 2>(k, st);   // 256 x 256: 2 x 4 waves of 128 x 64
+}
+
+}  // namespace icd_gemm_detail

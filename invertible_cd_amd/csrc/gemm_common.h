@@ -1,0 +1,43 @@
+// Shared declarations of the GEMM kernels (gemm.hip: 128x128 / 256x128 tiles; gemm_big.hip: 256x320 / 256x256 tiles).
+#pragma once
+#include "common.h"
+
+namespace icd_gemm_detail {
+
+constexpr int BK = 64;
+constexpr int EPI_LD = 132;                      // fp32 staging row stride (floats) for a 64x128 slab
+constexpr int EPI_LD_T = 68;                     // transposed staging: 128 rows (n) x 64 (m)
+
+struct GemmK {
+    const half_t* a0; const half_t* a1; const half_t* w;
+    const float* bias; const half_t* rowbias; const half_t* resid; void* out;
+    float* partial;                              // split-K: fp32 [S][M][N]
+    int M, N, K, Nw;
+    int lda, ldw, ldo, ldr, ld_rowbias, rps;
+    int C0, C1, Hin, Win, Hout, Wout, ksize, stride, upsample;
+    int zdiv; long long a_bs0, a_bs1, w_bs0, w_bs1, o_bs0, o_bs1;
+    float alpha; int flags;
+    int nbm, nbn, ksplit, kt_per_split;
+};
+
+__device__ __forceinline__ int swz_off(int row, int chunk) {        // byte offset inside a [rows][64] half tile
+    return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+}
+
+// erf with |error| < 1.5e-7 (Abramowitz & Stegun 7.1.26): plenty for an fp16 result, ~4x cheaper than erff
+__device__ __forceinline__ float erf_fast(float x) {
+    const float ax = fabsf(x);
+    const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float y = 1.0f - p * t * __expf(-ax * ax);
+    return copysignf(y, x);
+}
+__device__ __forceinline__ float gelu_fast(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752f)); }
+
+
+int launch_big(const GemmK& k, int tn, hipStream_t st);      // gemm_big.hip; tn = 5 (BN 320) or 4 (BN 256, GEGLU capable)
+
+}  // namespace icd_gemm_detail

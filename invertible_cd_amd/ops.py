@@ -49,8 +49,12 @@ def _splitk_ws(d, device):
     return ws
 
 
+FORCE_BIG_TILE = 0x100000      # tuning / test override understood by icd_gemm: take the 256x256 tile path regardless of size
+FORBID_BIG_TILE = 0x200000
+
+
 def gemm(a, w, bias=None, resid=None, rowbias=None, rows_per_sample=0, geglu=False, out=None, alpha=1.0,
-         out_f32=False):
+         out_f32=False, debug_flags=0):
     """out[M, N] = alpha * a[M, K] @ w[N, K]^T (+bias[N] fp32) (+rowbias[m // rps]) (+resid) ; GEGLU halves N."""
     _chk16(a, "a"); _chk16(w, "w")
     M, K = a.shape
@@ -69,13 +73,14 @@ def gemm(a, w, bias=None, resid=None, rowbias=None, rows_per_sample=0, geglu=Fal
     d.ld_rowbias = rowbias.stride(0) if rowbias is not None else 0
     d.rows_per_sample = rows_per_sample
     d.mode, d.batch, d.zdiv, d.alpha = 0, 1, 1, alpha
-    d.flags = (ICD_GEMM_GEGLU if geglu else 0) | (ICD_GEMM_OUT_F32 if out_f32 else 0)
+    d.flags = (ICD_GEMM_GEGLU if geglu else 0) | (ICD_GEMM_OUT_F32 if out_f32 else 0) | debug_flags
     ws = _splitk_ws(d, a.device)
     _lib.check(_lib.load().icd_gemm(C.byref(d), _stream()), "icd_gemm")
     return out
 
 
-def conv3x3(x, B, H, W, w_packed, bias=None, x2=None, stride=1, upsample=False, resid=None, rowbias=None, ksize=3):
+def conv3x3(x, B, H, W, w_packed, bias=None, x2=None, stride=1, upsample=False, resid=None, rowbias=None, ksize=3,
+            debug_flags=0):
     """Implicit-GEMM conv over NHWC x [B*H*W, C0] (optionally cat with x2 [.., C1]); returns [B*Ho*Wo, Cout]."""
     _chk16(x, "x"); _chk16(w_packed, "w")
     C0 = x.shape[-1]
@@ -96,7 +101,7 @@ def conv3x3(x, B, H, W, w_packed, bias=None, x2=None, stride=1, upsample=False, 
     d.rows_per_sample = Ho * Wo
     d.mode, d.C0, d.C1 = 1, C0, C1
     d.Hin, d.Win, d.Hout, d.Wout, d.ksize, d.stride, d.upsample = H, W, Ho, Wo, ksize, stride, int(upsample)
-    d.batch, d.zdiv, d.alpha, d.flags = 1, 1, 1.0, 0
+    d.batch, d.zdiv, d.alpha, d.flags = 1, 1, 1.0, debug_flags
     ws = _splitk_ws(d, x.device)
     _lib.check(_lib.load().icd_gemm(C.byref(d), _stream()), "icd_gemm(conv)")
     return out

@@ -76,6 +76,51 @@ def test_conv3x3_split_k_8x8_level():
     assert rel_l2(out, ref) < TOL
 
 
+@pytest.mark.parametrize("M,N,K", [(512, 256, 320), (300, 512, 64), (1024, 1280, 1280), (256, 256, 4096)])
+def test_gemm_big_tile_dense(M, N, K):
+    """256x256 / 8-wave tile family (gemm_big.hip), forced so that small shapes exercise it too (incl. ragged M, split-K)."""
+    ops = _ops()
+    a, w = r16(M, K, seed=61), r16(N, K, seed=62, scale=K ** -0.5)
+    bias = torch.randn(N, generator=torch.Generator().manual_seed(63))
+    res = r16(M, N, seed=64)
+    out = ops.gemm(a.cuda(), w.cuda(), bias=bias.cuda(), resid=res.cuda(), debug_flags=ops.FORCE_BIG_TILE)
+    assert rel_l2(out, a.float() @ w.float().t() + bias + res.float()) < TOL
+    perm = ops.geglu_perm(N // 2)
+    outg = ops.gemm(a.cuda(), w[perm].contiguous().cuda(), bias=bias[perm].contiguous().cuda(), geglu=True,
+                    debug_flags=ops.FORCE_BIG_TILE)
+    g = a.float() @ w.float().t() + bias
+    val, gate = g.chunk(2, dim=-1)
+    assert rel_l2(outg, val * F.gelu(gate)) < TOL
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(B=1, H=16, W=16, C0=128, C1=0, Co=256, stride=1, up=False),
+    dict(B=2, H=16, W=16, C0=64, C1=64, Co=256, stride=1, up=False),
+    dict(B=2, H=16, W=16, C0=128, C1=0, Co=256, stride=2, up=False),
+    dict(B=1, H=8, W=8, C0=128, C1=0, Co=512, stride=1, up=True),
+    dict(B=4, H=8, W=8, C0=1280, C1=0, Co=1280, stride=1, up=False),
+])
+def test_conv_big_tile(cfg):
+    ops = _ops()
+    B, H, W, C0, C1, Co = cfg["B"], cfg["H"], cfg["W"], cfg["C0"], cfg["C1"], cfg["Co"]
+    x = r16(B, C0, H, W, seed=65)
+    x2 = r16(B, C1, H, W, seed=66) if C1 else None
+    Cin = C0 + C1
+    w = r16(Co, Cin, 3, 3, seed=67, scale=(9 * Cin) ** -0.5)
+    bias = torch.randn(Co, generator=torch.Generator().manual_seed(68)) * 0.1
+    xin = x.float() if x2 is None else torch.cat([x.float(), x2.float()], 1)
+    if cfg["up"]:
+        xin = F.interpolate(xin, scale_factor=2.0, mode="nearest")
+    ref = F.conv2d(xin, w.float(), bias, stride=cfg["stride"], padding=1)
+    Ho, Wo = ref.shape[2:]
+    rb = r16(B, Co, seed=69)
+    res = r16(B * Ho * Wo, Co, seed=70)
+    out = ops.conv3x3(to_nhwc(x).cuda(), B, H, W, ops.pack_conv_weight(w).cuda(), bias.cuda(),
+                      x2=None if x2 is None else to_nhwc(x2).cuda(), stride=cfg["stride"], upsample=cfg["up"],
+                      resid=res.cuda(), rowbias=rb.cuda(), debug_flags=ops.FORCE_BIG_TILE)
+    assert rel_l2(out, to_nhwc(ref + rb.float()[:, :, None, None]) + res.float()) < TOL
+
+
 def test_gemm_rowbias_alpha_f32():
     ops = _ops()
     B, HW, K, N = 3, 64, 128, 192

@@ -122,6 +122,10 @@ int icd_silu(const void* x, int64_t n, void* out, void* stream);
 int icd_conv_in(const void* x_nchw, int32_t x_is_f32, int32_t B, int32_t H, int32_t W, const void* w,
                 const float* bias, int32_t Cout, void* out, void* stream);
 
+/* NCHW [B,4,HW] latents (fp16 or fp32) -> token-major [B*HW, 8] fp16 with channels 4..7 zero: lets conv_in run as an
+ * implicit GEMM (icd_gemm mode 1, C0 = 8, K = 72, weights [Cout, 3,3,8]) on the matrix cores - what the executor does. */
+int icd_pack_latent(const void* x_nchw, int32_t x_is_f32, int32_t B, int32_t HW, void* out, void* stream);
+
 /* conv_out: 3x3 pad 1 over NHWC fp16 [B,H*W,Cin] -> NCHW eps [B,4,H,W] (fp16 or fp32).  w: fp16 [4, 3,3,Cin]. */
 int icd_conv_out(const void* x, int32_t B, int32_t H, int32_t W, int32_t Cin, const void* w, const float* bias,
                  void* eps_nchw, int32_t out_is_f32, void* stream);

@@ -5,19 +5,23 @@
 // when no controller is registered, e.g. the whole SDXL path utils/generation_sdxl.py:445-453).
 //
 // CDNA4 design:
-//   * one workgroup = 4 waves = 128 query rows of one (batch, head); KV tiles of 64 keys, double-buffered in LDS via
+//   * one workgroup = 4 waves; each wave owns QT x 32 query rows of one (batch, head) (QT = 2 for the long-sequence
+//     head dims 40 / 64: every K / V^T fragment read from LDS feeds two query tiles, and the scheduler gets two
+//     independent softmax / MFMA streams to interleave).  KV tiles of 64 keys, double-buffered in LDS via
 //     global_load_lds (K tile [64][dpad16], V^T tile [dpad32][64]; V arrives already transposed from the to_v GEMM
 //     epilogue, so both MFMA operands are K-contiguous and no transposing LDS read is needed).
 //   * S^T = K.Q^T with v_mfma_f32_32x32x16_f16 (K as A operand, Q fragments held in registers as B operand): each lane
 //     owns ONE query column and 32 of the tile's 64 keys, so the online-softmax row reductions are in-lane plus one
-//     cross-half shuffle.
+//     cross-half shuffle.  The softmax scale is folded into the exp2 argument (one FMA + one v_exp_f32 per score);
+//     key masking exists only in a peeled instantiation for a ragged last tile.
 //   * O^T += V^T.P^T reuses the S^T accumulator registers directly as the B operand: the k-index <-> key permutation is
 //     chosen to match the 32x32 accumulator layout (keys 16s+4h+{0..3,8..11}), V^T fragments are fetched with two
 //     ds_read_b64 in the same permutation.  P never leaves registers.
+//   * when the padded head dim leaves a free V^T row (d = 40, 80, ...) that row is loaded with ones and the MFMA itself
+//     accumulates the softmax denominator (with exactly the fp16-rounded P the numerator uses): no VALU row sums.
 //   * XCD-aware block order: the q-tiles of one (b, h) run on one XCD so its K/V stay in that XCD's L2.
-#include "common.h"
-
 #include <type_traits>
+#include "common.h"
 
 namespace {
 
@@ -40,13 +44,11 @@ struct AttnK {
     int nqt;
 };
 
-// KS = number of 16-wide k-steps over the head dim (dpad16 = 16*KS); DT = number of 32-row tiles of the head dim.
-template <int KS, int DT>
+// KS = 16-wide k-steps over the head dim (dpad16 = 16*KS); DT = 32-row tiles of the head dim; QT = query tiles per wave
+template <int KS, int DT, int QT>
 __global__ __launch_bounds__(256, 2) void attn_fused_kernel(AttnK p) {
     constexpr int NCH = 2 * KS;                       // 16-B chunks per K row
-    // when the padded head dim leaves a free V^T row (d = 40, 80, ...), that row is loaded with ones and the MFMA itself
-    // accumulates the softmax denominator (with exactly the fp16-rounded P the numerator uses): no VALU row sums
-    constexpr bool ONES = KS * 16 < DT * 32;
+    constexpr bool ONES = KS * 16 < DT * 32;          // a free padded V^T row exists: MFMA computes the denominator
     constexpr int KT_BYTES = 64 * NCH * 16;           // K tile
     constexpr int VT_BYTES = DT * 32 * 128;           // V^T tile, 64 keys = 128 B per row
     constexpr int STAGE = KT_BYTES + VT_BYTES;
@@ -61,24 +63,25 @@ __global__ __launch_bounds__(256, 2) void attn_fused_kernel(AttnK p) {
     }
     const int qt = bid % p.nqt, bh = bid / p.nqt;
     const int b = bh / p.H, h = bh - b * p.H;
-    const int q0 = qt * 128 + wv * 32;
+    const int q0 = qt * (128 * QT) + wv * (32 * QT);
     const half_t* zero = reinterpret_cast<const half_t*>(icd_zero_page);
 
     const half_t* Kb = p.k + (long long)b * p.Nk * p.ldk + h * p.d;
     const half_t* Vb = p.vt + ((long long)b * p.H * p.d + (long long)h * p.d) * p.ldvt;
 
-    // Q fragments: lane = query row q0+lr, head-dim offset ks*16 + lh*8
-    f16x8 qf[KS];
-    {
-        const int qrow = q0 + lr;
+    // Q fragments: lane = query row q0 + 32u + lr, head-dim offset ks*16 + lh*8
+    f16x8 qf[QT][KS];
+#pragma unroll
+    for (int u = 0; u < QT; ++u) {
+        const int qrow = q0 + u * 32 + lr;
         const half_t* qp = p.q + ((long long)b * p.Nq + qrow) * p.ldq + h * p.d;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const int dd = ks * 16 + lh * 8;
-            if (qrow < p.Nq && dd < p.d) qf[ks] = *reinterpret_cast<const f16x8*>(qp + dd);
+            if (qrow < p.Nq && dd < p.d) qf[u][ks] = *reinterpret_cast<const f16x8*>(qp + dd);
             else
 #pragma unroll
-                for (int e = 0; e < 8; ++e) qf[ks][e] = (half_t)0.f;
+                for (int e = 0; e < 8; ++e) qf[u][ks][e] = (half_t)0.f;
         }
     }
 
@@ -86,9 +89,8 @@ __global__ __launch_bounds__(256, 2) void attn_fused_kernel(AttnK p) {
         unsigned char* sk = smem + buf * STAGE;
         unsigned char* sv = sk + KT_BYTES;
         const int kv0 = t * 64;
-        // K tile: 64 rows x NCH chunks = 2*KS groups of 64 chunks
 #pragma unroll
-        for (int g = wv; g < 2 * KS; g += 4) {
+        for (int g = wv; g < 2 * KS; g += 4) {          // K tile: 64 rows x NCH chunks = 2*KS groups of 64 chunks
             const int cid = g * 64 + l;
             const int row = cid / NCH, pc = cid - row * NCH;
             const int lc = k_swz<NCH>(row, pc);
@@ -96,9 +98,8 @@ __global__ __launch_bounds__(256, 2) void attn_fused_kernel(AttnK p) {
             const half_t* src = (key < p.Nk && dd < p.d) ? Kb + (long long)key * p.ldk + dd : zero;
             glds16(src, sk + g * 1024);
         }
-        // V^T tile: DT*32 rows x 8 chunks = 4*DT groups
 #pragma unroll
-        for (int g = wv; g < 4 * DT; g += 4) {
+        for (int g = wv; g < 4 * DT; g += 4) {          // V^T tile: DT*32 rows x 8 chunks = 4*DT groups
             const int cid = g * 64 + l;
             const int row = cid >> 3, pc = cid & 7;
             const int lc = pc ^ ((row >> 1) & 7);
@@ -109,14 +110,18 @@ __global__ __launch_bounds__(256, 2) void attn_fused_kernel(AttnK p) {
         }
     };
 
-    f32x16 o[DT];
+    f32x16 o[QT][DT];
 #pragma unroll
-    for (int i = 0; i < DT; ++i)
+    for (int u = 0; u < QT; ++u)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) o[i][e] = 0.f;
+        for (int i = 0; i < DT; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) o[u][i][e] = 0.f;
     // running max in RAW score units (the softmax scale is folded into the exp2 argument); running sum only when the
     // MFMA cannot produce it (see ONES)
-    float m_run = -INFINITY, l_run = 0.f;
+    float m_run[QT], l_run[QT];
+#pragma unroll
+    for (int u = 0; u < QT; ++u) { m_run[u] = -INFINITY; l_run[u] = 0.f; }
     const float c = p.scale_log2;
     f32x16 zero16;
 #pragma unroll
@@ -127,8 +132,8 @@ __global__ __launch_bounds__(256, 2) void attn_fused_kernel(AttnK p) {
         constexpr bool RAGGED = decltype(ragged_tag)::value;
         const unsigned char* sk = smem + (t & 1) * STAGE;
         const unsigned char* sv = sk + KT_BYTES;
-        // ---- S^T[key][q] for two 32-key tiles ----
-        f32x16 s[2];
+        // ---- S^T[key][q] for two 32-key tiles (x QT query tiles: each K fragment is read once) ----
+        f32x16 s[QT][2];
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
             const int row = kt * 32 + lr;
@@ -136,44 +141,48 @@ __global__ __launch_bounds__(256, 2) void attn_fused_kernel(AttnK p) {
             for (int ks = 0; ks < KS; ++ks) {
                 const int cc = ks * 2 + lh;
                 f16x8 kf = *reinterpret_cast<const f16x8*>(sk + (row * NCH + k_swz<NCH>(row, cc)) * 16);
-                // first k-step accumulates onto a persistent zero register block (no per-tile v_mov zeroing)
-                s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], ks == 0 ? zero16 : s[kt], 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < QT; ++u)
+                    s[u][kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[u][ks], ks == 0 ? zero16 : s[u][kt], 0, 0, 0);
             }
         }
         // ---- online softmax (lane owns query column lr; keys 32kt + 8g + 4lh + i) ----
-        if (RAGGED) {
+        f16x8 pf[QT][4];
+#pragma unroll
+        for (int u = 0; u < QT; ++u) {
+            if (RAGGED) {
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int key = t * 64 + kt * 32 + 8 * (e >> 2) + 4 * lh + (e & 3);
+                        if (key >= p.Nk) s[u][kt][e] = -INFINITY;
+                    }
+            }
+            float mx = fmaxf(s[u][0][0], s[u][1][0]);
+#pragma unroll
+            for (int e = 1; e < 16; ++e) mx = fmaxf(mx, fmaxf(s[u][0][e], s[u][1][e]));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float m_new = fmaxf(m_run[u], mx);
+            const float alpha = __builtin_amdgcn_exp2f((m_run[u] - m_new) * c);
+            const float nmc = -m_new * c;
+            m_run[u] = m_new;
+            float rs = 0.f;
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const int key = t * 64 + kt * 32 + 8 * (e >> 2) + 4 * lh + (e & 3);
-                    if (key >= p.Nk) s[kt][e] = -INFINITY;
+                    const float pv = __builtin_amdgcn_exp2f(fmaf(s[u][kt][e], c, nmc));
+                    if (!ONES) rs += pv;
+                    pf[u][kt * 2 + (e >> 3)][e & 7] = (half_t)pv;
                 }
+            if (!ONES) l_run[u] = l_run[u] * alpha + rs;
+#pragma unroll
+            for (int i = 0; i < DT; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) o[u][i][e] *= alpha;
         }
-        float mx = fmaxf(s[0][0], s[1][0]);
-#pragma unroll
-        for (int e = 1; e < 16; ++e) mx = fmaxf(mx, fmaxf(s[0][e], s[1][e]));
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
-        const float nmc = -m_new * c;
-        m_run = m_new;
-        f16x8 pf[4];
-        float rs = 0.f;
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const float pv = __builtin_amdgcn_exp2f(fmaf(s[kt][e], c, nmc));
-                if (!ONES) rs += pv;
-                pf[kt * 2 + (e >> 3)][e & 7] = (half_t)pv;
-            }
-        if (!ONES) l_run = l_run * alpha + rs;
-#pragma unroll
-        for (int i = 0; i < DT; ++i)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) o[i][e] *= alpha;
-        // ---- O^T[dcol][q] += V^T[dcol][keys] . P^T[keys][q] ----
+        // ---- O^T[dcol][q] += V^T[dcol][keys] . P^T[keys][q]  (each V^T fragment read once for the QT query tiles) ----
 #pragma unroll
         for (int st = 0; st < 4; ++st) {
             const int c0 = st * 2;                      // keys 16st + 4lh + {0..3} and +8
@@ -185,7 +194,8 @@ __global__ __launch_bounds__(256, 2) void attn_fused_kernel(AttnK p) {
                 f16x4 v0 = *reinterpret_cast<const f16x4*>(rp + ((c0 ^ x) << 4));
                 f16x4 v1 = *reinterpret_cast<const f16x4*>(rp + (((c0 + 1) ^ x) << 4));
                 f16x8 vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-                o[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[st], o[i], 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < QT; ++u) o[u][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[u][st], o[u][i], 0, 0, 0);
             }
         }
     };
@@ -200,38 +210,42 @@ __global__ __launch_bounds__(256, 2) void attn_fused_kernel(AttnK p) {
         if (last_ragged && t == nt - 1) tile(std::true_type{}, t);
         else tile(std::false_type{}, t);
     }
-    // ---- normalise and store: lane holds 4 consecutive head-dim columns of query row q0+lr ----
-    float l_tot;
-    if (ONES) l_tot = __shfl(o[DT - 1][15], lr + 32);      // row DT*32-1 of O^T = sum_k P (the V^T ones-row), held by the upper half
-    else l_tot = l_run + __shfl_xor(l_run, 32);
-    const float inv = 1.0f / l_tot;
-    const int qrow = q0 + lr;
-    if (qrow < p.Nq) {
-        half_t* op = p.out + ((long long)b * p.Nq + qrow) * p.ldo + h * p.d;
+    // ---- normalise and store: lane holds 4 consecutive head-dim columns of query row q0 + 32u + lr ----
 #pragma unroll
-        for (int i = 0; i < DT; ++i)
+    for (int u = 0; u < QT; ++u) {
+        float l_tot;
+        if (ONES) l_tot = __shfl(o[u][DT - 1][15], lr + 32);   // row DT*32-1 of O^T = sum_k P (the V^T ones-row), upper half-wave
+        else l_tot = l_run[u] + __shfl_xor(l_run[u], 32);
+        const float inv = 1.0f / l_tot;
+        const int qrow = q0 + u * 32 + lr;
+        if (qrow < p.Nq) {
+            half_t* op = p.out + ((long long)b * p.Nq + qrow) * p.ldo + h * p.d;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int dc = i * 32 + 8 * g + 4 * lh;
-                if (dc < p.d) {
-                    f16x4 v = {(half_t)(o[i][4 * g] * inv), (half_t)(o[i][4 * g + 1] * inv),
-                               (half_t)(o[i][4 * g + 2] * inv), (half_t)(o[i][4 * g + 3] * inv)};
-                    *reinterpret_cast<f16x4*>(op + dc) = v;
+            for (int i = 0; i < DT; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int dc = i * 32 + 8 * g + 4 * lh;
+                    if (dc < p.d) {
+                        f16x4 v = {(half_t)(o[u][i][4 * g] * inv), (half_t)(o[u][i][4 * g + 1] * inv),
+                                   (half_t)(o[u][i][4 * g + 2] * inv), (half_t)(o[u][i][4 * g + 3] * inv)};
+                        *reinterpret_cast<f16x4*>(op + dc) = v;
+                    }
                 }
-            }
+        }
     }
 }
 
-template <int KS, int DT>
-int launch_attn(const AttnK& k, hipStream_t st) {
+template <int KS, int DT, int QT>
+int launch_attn(AttnK k, hipStream_t st) {
     constexpr int smem = 2 * (64 * 2 * KS * 16 + DT * 32 * 128);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fused_kernel<KS, DT>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fused_kernel<KS, DT, QT>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         attr_set = true;
     }
-    hipLaunchKernelGGL((attn_fused_kernel<KS, DT>), dim3(k.nqt * k.B * k.H), dim3(256), smem, st, k);
+    k.nqt = (k.Nq + 128 * QT - 1) / (128 * QT);
+    hipLaunchKernelGGL((attn_fused_kernel<KS, DT, QT>), dim3(k.nqt * k.B * k.H), dim3(256), smem, st, k);
     ICD_CHECK_LAUNCH("icd_attention_fused");
     return ICD_OK;
 }
@@ -250,14 +264,16 @@ extern "C" int icd_attention_fused(const void* q, const void* k, const void* vt,
     a.q = (const half_t*)q; a.k = (const half_t*)k; a.vt = (const half_t*)vt; a.out = (half_t*)out;
     a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.d = d; a.ldq = ldq; a.ldk = ldk; a.ldvt = ldvt; a.ldo = ldo;
     a.scale_log2 = scale * 1.4426950408889634f;
-    a.nqt = (Nq + 127) / 128;
+    a.nqt = 0;
     hipStream_t st = (hipStream_t)stream;
-    if (d <= 16) return launch_attn<1, 1>(a, st);
-    if (d <= 32) return launch_attn<2, 1>(a, st);
-    if (d <= 48) return launch_attn<3, 2>(a, st);
-    if (d <= 64) return launch_attn<4, 2>(a, st);
-    if (d <= 80) return launch_attn<5, 3>(a, st);
-    if (d <= 96) return launch_attn<6, 3>(a, st);
-    if (d <= 128) return launch_attn<8, 4>(a, st);
-    return launch_attn<10, 5>(a, st);
+    // two query tiles per wave when the sequence is long enough to still fill the chip with 256-row workgroups
+    const bool wide = (long long)((Nq + 255) / 256) * B * H >= 512 && Nk >= 256;
+    if (d <= 16) return launch_attn<1, 1, 1>(a, st);
+    if (d <= 32) return launch_attn<2, 1, 1>(a, st);
+    if (d <= 48) return wide ? launch_attn<3, 2, 2>(a, st) : launch_attn<3, 2, 1>(a, st);
+    if (d <= 64) return launch_attn<4, 2, 1>(a, st);      // QT = 2 measured slower at d = 64 (256 VGPRs, spills)
+    if (d <= 80) return launch_attn<5, 3, 1>(a, st);
+    if (d <= 96) return launch_attn<6, 3, 1>(a, st);
+    if (d <= 128) return launch_attn<8, 4, 1>(a, st);
+    return launch_attn<10, 5, 1>(a, st);
 }

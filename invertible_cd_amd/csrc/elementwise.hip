@@ -76,6 +76,21 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const TIn* __restrict__ x,
     *reinterpret_cast<f16x8*>(out + pix * Cout + oc) = o;
 }
 
+// NCHW [B,4,H,W] latents -> token-major [B*H*W, 8] fp16 (channels 4..7 zero) so that conv_in can run on the MFMA
+// implicit-GEMM path (K = 9 * 8 = 72).
+template <typename TIn>
+__global__ void pack_latent_kernel(const TIn* __restrict__ x, int B, int HW, half_t* __restrict__ out) {
+    const long long pix = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= (long long)B * HW) return;
+    const int b = (int)(pix / HW), r = (int)(pix - (long long)b * HW);
+    f16x8 o;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) o[c] = (half_t)(float)x[((long long)b * 4 + c) * HW + r];
+#pragma unroll
+    for (int c = 4; c < 8; ++c) o[c] = (half_t)0.f;
+    *reinterpret_cast<f16x8*>(out + pix * 8) = o;
+}
+
 // conv_out: one wave per output pixel; lanes stride over 8-channel chunks; 4 output channels.  w: [4][3][3][Cin].
 template <typename TOut>
 __global__ __launch_bounds__(256) void conv_out_kernel(const half_t* __restrict__ x, int B, int H, int W, int Cin,
@@ -165,6 +180,18 @@ extern "C" int icd_conv_in(const void* x_nchw, int32_t x_is_f32, int32_t B, int3
         hipLaunchKernelGGL(conv_in_kernel<half_t>, grid, dim3(256), 0, (hipStream_t)stream, (const half_t*)x_nchw, B, H,
                            W, (const half_t*)w, bias, Cout, (half_t*)out);
     ICD_CHECK_LAUNCH("icd_conv_in");
+    return ICD_OK;
+}
+
+extern "C" int icd_pack_latent(const void* x_nchw, int32_t x_is_f32, int32_t B, int32_t HW, void* out, void* stream) {
+    ICD_CHECK_ARG(x_nchw && out && B > 0 && HW > 0, "icd_pack_latent: bad arguments");
+    const long long pixels = (long long)B * HW;
+    dim3 grid((unsigned)((pixels + 255) / 256));
+    if (x_is_f32)
+        hipLaunchKernelGGL(pack_latent_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x_nchw, B, HW, (half_t*)out);
+    else
+        hipLaunchKernelGGL(pack_latent_kernel<half_t>, grid, dim3(256), 0, (hipStream_t)stream, (const half_t*)x_nchw, B, HW, (half_t*)out);
+    ICD_CHECK_LAUNCH("icd_pack_latent");
     return ICD_OK;
 }
 

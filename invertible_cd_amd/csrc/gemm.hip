@@ -570,7 +570,7 @@ extern "C" int icd_gemm(const icd_gemm_desc* d, void* stream) {
             }
             const long long bt = b0 * sc;
             double eff = (double)bt / (double)(((bt + 255) / 256) * 256);
-            if (sc > 1) eff *= 0.85;                    // fp32 partial round trip
+            if (sc > 1) eff *= (nk_total / sc >= 32) ? 0.85 : 0.55;   // fp32 partial round trip: dear when K is short
             if (eff > best + 1e-9) { best = eff; tn = c; s = sc; blocks = b0; }
         }
         const bool eligible = tn != 0;

@@ -36,7 +36,21 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const half_t* __re
         const bool first = ch < C0;
         const half_t* base = first ? x0 + (long long)b * HW * C0 + ch : x1 + (long long)b * HW * C1 + (ch - C0);
         const int cs = first ? C0 : C1;
-        for (int p = p_begin + rsub; p < p_end; p += rpi) {
+        // 4 independent 16-B loads in flight per thread per iteration (HBM-bound: keep the memory pipe full)
+        int p = p_begin + rsub;
+        for (; p + 3 * rpi < p_end; p += 4 * rpi) {
+            f16x8 v0 = __builtin_nontemporal_load(reinterpret_cast<const f16x8*>(base + (long long)p * cs));
+            f16x8 v1 = __builtin_nontemporal_load(reinterpret_cast<const f16x8*>(base + (long long)(p + rpi) * cs));
+            f16x8 v2 = __builtin_nontemporal_load(reinterpret_cast<const f16x8*>(base + (long long)(p + 2 * rpi) * cs));
+            f16x8 v3 = __builtin_nontemporal_load(reinterpret_cast<const f16x8*>(base + (long long)(p + 3 * rpi) * cs));
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float f0 = (float)v0[e], f1 = (float)v1[e], f2 = (float)v2[e], f3 = (float)v3[e];
+                s[e] += (f0 + f1) + (f2 + f3);
+                q[e] += (f0 * f0 + f1 * f1) + (f2 * f2 + f3 * f3);
+            }
+        }
+        for (; p < p_end; p += rpi) {
             f16x8 v = *reinterpret_cast<const f16x8*>(base + (long long)p * cs);
 #pragma unroll
             for (int e = 0; e < 8; ++e) { const float f = (float)v[e]; s[e] += f; q[e] += f * f; }
@@ -104,8 +118,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const half_t* __re
     half_t* ob = out + (long long)b * HW * C + ch;
     const int p_begin = blockIdx.x * pix_per_block;
     const int p_end = min(HW, p_begin + pix_per_block);
-    for (int p = p_begin + rsub; p < p_end; p += rpi) {
-        f16x8 v = *reinterpret_cast<const f16x8*>(base + (long long)p * cs);
+    auto norm8 = [&](const f16x8& v) {
         f16x8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -113,8 +126,21 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const half_t* __re
             if (silu) f = silu_f(f);
             o[e] = (half_t)f;
         }
-        *reinterpret_cast<f16x8*>(ob + (long long)p * C) = o;
+        return o;
+    };
+    int p = p_begin + rsub;
+    for (; p + 3 * rpi < p_end; p += 4 * rpi) {          // 4 loads in flight per thread
+        f16x8 v0 = *reinterpret_cast<const f16x8*>(base + (long long)p * cs);
+        f16x8 v1 = *reinterpret_cast<const f16x8*>(base + (long long)(p + rpi) * cs);
+        f16x8 v2 = *reinterpret_cast<const f16x8*>(base + (long long)(p + 2 * rpi) * cs);
+        f16x8 v3 = *reinterpret_cast<const f16x8*>(base + (long long)(p + 3 * rpi) * cs);
+        *reinterpret_cast<f16x8*>(ob + (long long)p * C) = norm8(v0);
+        *reinterpret_cast<f16x8*>(ob + (long long)(p + rpi) * C) = norm8(v1);
+        *reinterpret_cast<f16x8*>(ob + (long long)(p + 2 * rpi) * C) = norm8(v2);
+        *reinterpret_cast<f16x8*>(ob + (long long)(p + 3 * rpi) * C) = norm8(v3);
     }
+    for (; p < p_end; p += rpi)
+        *reinterpret_cast<f16x8*>(ob + (long long)p * C) = norm8(*reinterpret_cast<const f16x8*>(base + (long long)p * cs));
 }
 
 // ---------------------------------------------------------------------------------------------------------------

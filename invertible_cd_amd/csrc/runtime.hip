@@ -397,11 +397,17 @@ struct Exec {
         std::vector<Act> skips;
         std::vector<int> skipH;
         Act h{alloc<half_t>((long long)B * HW0 * ch0), ch0};
-        if (ok() && !dry) {
-            ProfScope ps(true, st, ICD_PROF_MISC, 2.0 * B * (double)HW0 * 36 * ch0, 0.0);
-            run(icd_conv_in(io->sample, io->sample_is_f32, B, H0, W0, Wh("conv_in.weight", 36LL * ch0), Wf("conv_in.bias", ch0), ch0, h.p, st));
+        {
+            // conv_in on the matrix cores: pack the 4-channel NCHW latent to [B*HW, 8] and run the implicit GEMM (K = 72)
+            half_t* lat8 = alloc<half_t>((long long)B * HW0 * 8);
+            if (ok() && !dry) {
+                ProfScope ps(true, st, ICD_PROF_MISC, 0.0, (double)B * HW0 * 24.0);
+                run(icd_pack_latent(io->sample, io->sample_is_f32, B, HW0, lat8, st));
+            }
+            Act l8{lat8, 8};
+            conv(l8, nullptr, H0, W0, 3, 1, 0, Wh("conv_in.weight8", 72LL * ch0), ch0, Wf("conv_in.bias", ch0), nullptr, 0, nullptr, h.p);
+            release(lat8);
         }
-        else { Wh("conv_in.weight", 36LL * ch0); Wf("conv_in.bias", ch0); }
         skips.push_back(h);
         int Hh = H0, Ww = W0;
         // ---------------- down

@@ -74,6 +74,10 @@ def pack_state_dict(cfg: UNetConfig, sd, device):
         packed[name + ".bias"] = f32(take(name + ".bias"))
 
     conv("conv_in")
+    w_in = sd["conv_in.weight"].to(device)                       # [C0, 4, 3, 3] -> [C0, 3,3, 8] (channels 4..7 zero): GEMM path
+    w8 = torch.zeros((w_in.shape[0], 3, 3, 8), device=device, dtype=torch.float32)
+    w8[..., :4] = w_in.permute(0, 2, 3, 1).float()
+    packed["conv_in.weight8"] = w16(w8.reshape(w_in.shape[0], 72))
     dense("time_embedding.linear_1")
     dense("time_embedding.linear_2")
     if cfg.time_cond_proj_dim:

@@ -49,10 +49,10 @@ def build_sd15(batch, device):
     from invertible_cd_amd.pipelines import StableDiffusionPipeline
     from invertible_cd_amd.schedulers import DDIMScheduler
     from invertible_cd_amd.unet_config import SD15
-    sd = synthetic.synthetic_state_dict(SD15, seed=0)                     # CPU fp32 (shared with the cpu_baseline leg)
-    lora = synthetic.synthetic_lora(SD15, seed=1)
     from invertible_cd_amd.loading import fuse_lora
-    sd = fuse_lora(sd, lora, lora_dtype=torch.float16)                    # LoRA (rank 64, alpha 8) fused at load
+    # synthetic weights generated directly on this rank's GPU (seeded per tensor), LoRA (rank 64, alpha 8) fused at load
+    sd = synthetic.synthetic_state_dict(SD15, seed=0, device=device)
+    sd = fuse_lora(sd, synthetic.synthetic_lora(SD15, seed=1, device=device), lora_dtype=torch.float16)
     model = StableDiffusionPipeline(unet.UNet2DConditionModel(SD15, sd, device=device, dtype=torch.float16), DDIMScheduler.sd15(),
                                     tokenizer=synthetic.SyntheticTokenizer(), device=device, dtype=torch.float16)
     solver = generation.Generator(model, 50, DDIMScheduler.sd15(), forward_cons_model=model, reverse_cons_model=model,
@@ -64,7 +64,8 @@ def build_sd15(batch, device):
 
     def step():
         return solver.cons_generation(latents, guidance_scale=7.0, w_embed_dim=512, dynamic_guidance=False, tau1=1.0, tau2=1.0)[-1]
-    return step, solver, sd, SD15
+    del sd
+    return step, solver, None, SD15
 
 
 def build_sdxl(batch, device):
@@ -72,7 +73,7 @@ def build_sdxl(batch, device):
     from invertible_cd_amd.pipelines import StableDiffusionXLPipeline
     from invertible_cd_amd.schedulers import DDIMScheduler
     from invertible_cd_amd.unet_config import SDXL
-    sd = synthetic.synthetic_state_dict(SDXL, seed=0)
+    sd = synthetic.synthetic_state_dict(SDXL, seed=0, device=device, dtype=torch.float16)
     pipe = StableDiffusionXLPipeline(unet.UNet2DConditionModel(SDXL, sd, device=device, dtype=torch.float16), DDIMScheduler.sdxl(),
                                      device=device)
     inp = synthetic.synthetic_inputs(SDXL, batch, 128, 128, seed=0, device="cpu")
@@ -86,14 +87,18 @@ def build_sdxl(batch, device):
                                                     is_sdxl=True, timesteps=[249, 499, 699, 999],
                                                     compute_embeddings_fn=lambda p, o, c: dict(emb), return_latent=True)[1]
     pipe.vae = None
-    return step, None, sd, SDXL
+    del sd
+    return step, None, None, SDXL
 
 
 def cpu_baseline(arch, sd, cfg):
     """The reference's CPU path restated (oracle): config[0] = SD1.5, B=1, 4 steps, CFG-doubled UNet batch of 2, fp32."""
     import numpy as np
+    from invertible_cd_amd import synthetic
     from oracle import sched_ref, unet_ref
     ocfg = unet_ref.SD15 if arch == "sd15" else unet_ref.SDXL
+    if sd is None:                                   # fp32 CPU weights of the same architecture (seeded synthetic)
+        sd = synthetic.synthetic_state_dict(cfg, seed=0)
     torch.manual_seed(0)
     ac = sched_ref.alphas_cumprod()
     alpha, sigma = np.sqrt(ac), np.sqrt(1 - ac)

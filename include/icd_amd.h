@@ -104,11 +104,13 @@ int icd_softmax_rows(const float* s, int64_t rows, int32_t cols, int32_t ld_s, f
 /* Fused attention without materialised probabilities (flash style):
  *   out[b, n, h*d:(h+1)*d] = softmax(scale * q[b,n,h,:] . k[b,:,h,:]) @ v
  * q: [B, Nq, ldq] (head h at column h*d), k: [B, Nk, ldk], vt: V TRANSPOSED [B, H*d, ldvt] (keys contiguous),
- * out: [B, Nq, ldo].  d in {40, 64, 80, 160} (any multiple of 8 up to 160).
+ * out: [B, Nq, ldo].  d in {40, 64, 80, 160} (any multiple of 8 up to 160).  vt_batch_stride: elements between the V^T
+ * blocks of consecutive samples (0 = H*d*ldvt; larger when vt is a row slice of a wider [B, sum(C), ldvt] buffer that
+ * holds the V^T of every cross-attention layer).
  * Used on layers whose controller does not need P (utils/p2p.py:147,184-188: N > 32^2, or no controller). */
 int icd_attention_fused(const void* q, const void* k, const void* vt, void* out, int32_t B, int32_t H, int32_t Nq,
-                        int32_t Nk, int32_t d, int32_t ldq, int32_t ldk, int32_t ldvt, int32_t ldo, float scale,
-                        void* stream);
+                        int32_t Nk, int32_t d, int32_t ldq, int32_t ldk, int32_t ldvt, int32_t ldo,
+                        int64_t vt_batch_stride, float scale, void* stream);
 
 /* Sinusoidal embeddings.  kind 0: diffusers Timesteps(dim, flip_sin_to_cos=True, shift=0) -> [cos || sin];
  * kind 1: guidance_scale_embedding (utils/generation.py:96-122) -> [sin || cos] of 1000*w, denominator half-1.

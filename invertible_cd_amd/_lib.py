@@ -79,8 +79,8 @@ SIGNATURES = {
     "icd_softmax_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_int32,
                                    C.c_void_p]),
     "icd_attention_fused": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
-                                      C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float,
-                                      C.c_void_p]),
+                                      C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64,
+                                      C.c_float, C.c_void_p]),
     "icd_sinusoid": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "icd_silu": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "icd_conv_in": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,

@@ -40,6 +40,7 @@ __device__ __forceinline__ int k_swz(int row, int chunk) {
 struct AttnK {
     const half_t* q; const half_t* k; const half_t* vt; half_t* out;
     int B, H, Nq, Nk, d, ldq, ldk, ldvt, ldo;
+    long long vt_bs;              // elements between the V^T blocks of consecutive samples
     float scale_log2;
     int nqt;
 };
@@ -67,7 +68,7 @@ __global__ __launch_bounds__(256, 2) void attn_fused_kernel(AttnK p) {
     const half_t* zero = reinterpret_cast<const half_t*>(icd_zero_page);
 
     const half_t* Kb = p.k + (long long)b * p.Nk * p.ldk + h * p.d;
-    const half_t* Vb = p.vt + ((long long)b * p.H * p.d + (long long)h * p.d) * p.ldvt;
+    const half_t* Vb = p.vt + (long long)b * p.vt_bs + (long long)h * p.d * p.ldvt;
 
     // Q fragments: lane = query row q0 + 32u + lr, head-dim offset ks*16 + lh*8
     f16x8 qf[QT][KS];
@@ -254,7 +255,7 @@ int launch_attn(AttnK k, hipStream_t st) {
 
 extern "C" int icd_attention_fused(const void* q, const void* k, const void* vt, void* out, int32_t B, int32_t H,
                                    int32_t Nq, int32_t Nk, int32_t d, int32_t ldq, int32_t ldk, int32_t ldvt,
-                                   int32_t ldo, float scale, void* stream) {
+                                   int32_t ldo, int64_t vt_batch_stride, float scale, void* stream) {
     ICD_CHECK_ARG(q && k && vt && out, "icd_attention_fused: null pointer");
     ICD_CHECK_ARG(B > 0 && H > 0 && Nq > 0 && Nk > 0, "icd_attention_fused: empty shape");
     ICD_CHECK_ARG(d > 0 && d % 8 == 0 && d <= 160, "icd_attention_fused: head dim must be a multiple of 8, <= 160 (got %d)", d);
@@ -263,6 +264,7 @@ extern "C" int icd_attention_fused(const void* q, const void* k, const void* vt,
     AttnK a;
     a.q = (const half_t*)q; a.k = (const half_t*)k; a.vt = (const half_t*)vt; a.out = (half_t*)out;
     a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.d = d; a.ldq = ldq; a.ldk = ldk; a.ldvt = ldvt; a.ldo = ldo;
+    a.vt_bs = vt_batch_stride > 0 ? vt_batch_stride : (long long)H * d * ldvt;
     a.scale_log2 = scale * 1.4426950408889634f;
     a.nqt = 0;
     hipStream_t st = (hipStream_t)stream;

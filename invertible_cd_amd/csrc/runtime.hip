@@ -101,6 +101,7 @@ struct icd_unet {
     bool finalized = false;
     int n_attn = 0;
     int temb_total = 0;
+    int kv_total = 0;               // sum of C over every transformer block (cross-attention K / V columns)
 };
 
 namespace {
@@ -120,6 +121,9 @@ struct Exec {
     float* gn_ws = nullptr;
     half_t* temb_all = nullptr;
     int temb_off = 0;
+    half_t* k_all = nullptr;                 // [B*nctx, kv_total]: K of every cross-attention layer
+    half_t* vt_all = nullptr;                // [B, kv_total, ldv_cross]: V^T of every cross-attention layer
+    int kv_off = 0;
     int status = ICD_OK;
 
     const void* T(const std::string& name, int dtype, long long numel) {
@@ -235,7 +239,7 @@ struct Exec {
 
     // one attention module: q [B*Nq, ldq] (head h at col h*d), k [B*Nk, ldk], vt [B, C, ldv]; out [B*Nq, C]
     void attention(bool is_cross, int place, const half_t* q, int ldq, const half_t* k, int ldk, const half_t* vt, int ldv,
-                   int heads, int Nq, int Nk, int d, half_t* out, int C) {
+                   long long vt_bs, int heads, int Nq, int Nk, int d, half_t* out, int C) {
         const int my_layer = layer++;
         const long long ldp = (Nk + 7) / 8 * 8;
         const float scale = 1.0f / sqrtf((float)d);
@@ -251,7 +255,7 @@ struct Exec {
         if (!mat) {
             if (ok() && !dry) {
                 ProfScope ps(true, st, ICD_PROF_ATTN_FUSED, 4.0 * B * heads * (double)Nq * Nk * d, 0.0, Nq, Nk, d, heads);
-                run(icd_attention_fused(q, k, vt, out, B, heads, Nq, Nk, d, ldq, ldk, ldv, C, scale, st));
+                run(icd_attention_fused(q, k, vt, out, B, heads, Nq, Nk, d, ldq, ldk, ldv, C, vt_bs, scale, st));
             }
             return;
         }
@@ -284,7 +288,7 @@ struct Exec {
         g.a0 = probs; g.w = vt; g.out = out;
         g.M = Nq; g.N = d; g.K = (int)ldp; g.Nw = d; g.lda = (int)ldp; g.ldw = ldv; g.ldo = C;
         g.mode = 0; g.batch = B * heads; g.zdiv = heads;
-        g.a_bs0 = per_b; g.a_bs1 = (long long)Nq * ldp; g.w_bs0 = (long long)C * ldv; g.w_bs1 = (long long)d * ldv;
+        g.a_bs0 = per_b; g.a_bs1 = (long long)Nq * ldp; g.w_bs0 = vt_bs; g.w_bs1 = (long long)d * ldv;
         g.o_bs0 = (long long)Nq * C; g.o_bs1 = d;
         g.alpha = 1.f;
         gemm_desc(g);
@@ -293,7 +297,6 @@ struct Exec {
     Act transformer(const std::string& p, const Act& x, int Hh, int Ww, int depth, int heads, int place) {
         const int HW = Hh * Ww, C = x.C, d = C / heads, X = u->cfg.cross_dim;
         const long long M = (long long)B * HW;
-        const int Mc = B * nctx;
         const int ldv_self = (HW + 7) / 8 * 8, ldv_cross = (nctx + 7) / 8 * 8;
         half_t* n = alloc<half_t>(M * C);
         groupnorm(x, nullptr, HW, Wf(p + ".norm.weight", C), Wf(p + ".norm.bias", C), 1e-6f, 0, n);
@@ -311,20 +314,18 @@ struct Exec {
             linear(ln, C, (int)M, C, Wh(b + ".attn1.to_v.weight", (long long)C * C), C, nullptr, nullptr, 0, vt, ldv_self,
                    ICD_GEMM_OUT_TRANS, HW);
             half_t* ao = ln;     // ln is dead once q/k/v^T are enqueued: reuse it for the attention output
-            attention(false, place, qk, 2 * C, qk + C, 2 * C, vt, ldv_self, heads, HW, HW, d, ao, C);
+            attention(false, place, qk, 2 * C, qk + C, 2 * C, vt, ldv_self, (long long)C * ldv_self, heads, HW, HW, d, ao, C);
             release(qk); release(vt);
             linear(ao, C, (int)M, C, Wh(b + ".attn1.to_out.0.weight", (long long)C * C), C, Wf(b + ".attn1.to_out.0.bias", C), h, C, h, C);
             // ---- cross attention ----
             layernorm(h, M, C, Wf(b + ".norm2.weight", C), Wf(b + ".norm2.bias", C), ln);
             half_t* q2 = alloc<half_t>(M * C);
             linear(ln, C, (int)M, C, Wh(b + ".attn2.to_q.weight", (long long)C * C), C, nullptr, nullptr, 0, q2, C);
-            half_t* k2 = alloc<half_t>((long long)Mc * C);
-            linear((const half_t*)io->context, X, Mc, X, Wh(b + ".attn2.to_k.weight", (long long)C * X), C, nullptr, nullptr, 0, k2, C);
-            half_t* vt2 = alloc<half_t>((long long)B * C * ldv_cross);
-            linear((const half_t*)io->context, X, Mc, X, Wh(b + ".attn2.to_v.weight", (long long)C * X), C, nullptr, nullptr, 0, vt2,
-                   ldv_cross, ICD_GEMM_OUT_TRANS, nctx);
-            attention(true, place, q2, C, k2, C, vt2, ldv_cross, heads, HW, nctx, d, ln, C);
-            release(q2); release(k2); release(vt2);
+            // K and V^T of this layer are column / row slices of the per-forward batched projections
+            attention(true, place, q2, C, k_all + kv_off, u->kv_total, vt_all + (long long)kv_off * ldv_cross, ldv_cross,
+                      (long long)u->kv_total * ldv_cross, heads, HW, nctx, d, ln, C);
+            kv_off += C;
+            release(q2);
             linear(ln, C, (int)M, C, Wh(b + ".attn2.to_out.0.weight", (long long)C * C), C, Wf(b + ".attn2.to_out.0.bias", C), h, C, h, C);
             // ---- GEGLU feed-forward ----
             layernorm(h, M, C, Wf(b + ".norm3.weight", C), Wf(b + ".norm3.bias", C), ln);
@@ -391,6 +392,17 @@ struct Exec {
         linear(e1, temb, B, temb, Wh("time_emb_proj_cat.weight", (long long)u->temb_total * temb), u->temb_total,
                Wf("time_emb_proj_cat.bias", u->temb_total), nullptr, 0, temb_all, u->temb_total);
         temb_off = 0;
+        // every cross-attention K / V projection depends on the context only: two GEMMs for the whole forward
+        {
+            const int X = c.cross_dim, Mc = B * nctx, ldvc = (nctx + 7) / 8 * 8;
+            k_all = alloc<half_t>((long long)Mc * u->kv_total);
+            vt_all = alloc<half_t>((long long)B * u->kv_total * ldvc);
+            linear((const half_t*)io->context, X, Mc, X, Wh("attn2_k_cat.weight", (long long)u->kv_total * X), u->kv_total, nullptr,
+                   nullptr, 0, k_all, u->kv_total);
+            linear((const half_t*)io->context, X, Mc, X, Wh("attn2_v_cat.weight", (long long)u->kv_total * X), u->kv_total, nullptr,
+                   nullptr, 0, vt_all, ldvc, ICD_GEMM_OUT_TRANS, nctx);
+            kv_off = 0;
+        }
         release(e1); release(emb); if (tin != tsin) release(tin); release(tsin);
 
         // ---------------- conv_in
@@ -482,7 +494,7 @@ struct Exec {
             run(icd_conv_out(n, B, H0, W0, ch0, wo, bo, io->eps, io->sample_is_f32, st));
         }
         release(n);
-        release(temb_all);
+        release(temb_all); release(k_all); release(vt_all);
         return status;
     }
 };
@@ -554,6 +566,14 @@ extern "C" int icd_unet_create(const icd_unet_config* cfg, icd_unet** out) {
     u->cfg = *cfg;
     u->n_attn = count_attn(*cfg);
     u->temb_total = temb_total(*cfg);
+    {
+        const int L = cfg->num_levels;
+        int t = 0;
+        for (int i = 0; i < L; ++i) if (cfg->down_has_attn[i]) t += cfg->layers_per_block * cfg->transformer_layers[i] * cfg->block_out_channels[i];
+        t += cfg->transformer_layers[L - 1] * cfg->block_out_channels[L - 1];
+        for (int i = 0; i < L; ++i) if (cfg->up_has_attn[i]) t += (cfg->layers_per_block + 1) * cfg->transformer_layers[L - 1 - i] * cfg->block_out_channels[L - 1 - i];
+        u->kv_total = t;
+    }
     *out = u;
     return ICD_OK;
 }

@@ -156,7 +156,8 @@ def attention_fused(q, k, vt, B, H, Nq, Nk, d, scale):
     _chk16(q, "q"); _chk16(k, "k"); _chk16(vt, "vt")
     out = torch.empty_like(q)
     _lib.check(_lib.load().icd_attention_fused(_p(q), _p(k), _p(vt), _p(out), B, H, Nq, Nk, d, q.stride(0), k.stride(0),
-                                               vt.stride(1), out.stride(0), scale, _stream()), "icd_attention_fused")
+                                               vt.stride(1), out.stride(0), vt.stride(0), scale, _stream()),
+               "icd_attention_fused")
     return out
 
 

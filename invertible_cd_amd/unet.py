@@ -43,6 +43,7 @@ def pack_state_dict(cfg: UNetConfig, sd, device):
       attn1.to_q/to_k     -> attn1.to_qk [2C, C]   (one GEMM, q|k column blocks)
       ff.net.0.proj       -> rows interleaved 32 value / 32 gate so GEGLU is applied in the GEMM epilogue
       *.time_emb_proj     -> ONE [sum(Cout), 4*ch0] matrix in execution order (all resnets' time biases in one GEMM)
+      attn2.to_k / to_v   -> attn2_k_cat / attn2_v_cat [sum(C), cross_dim] in execution order (two GEMMs per forward)
     """
     packed = {}
 
@@ -97,6 +98,7 @@ def pack_state_dict(cfg: UNetConfig, sd, device):
         tb.append(take(p + ".time_emb_proj.bias"))
     packed["time_emb_proj_cat.weight"] = w16(torch.cat([t.to(device) for t in tw], 0))
     packed["time_emb_proj_cat.bias"] = f32(torch.cat([t.to(device) for t in tb], 0))
+    kcat, vcat = [], []
     for p, c, depth, _, _ in cfg.transformer_names():
         affine(p + ".norm")
         dense(p + ".proj_in")
@@ -111,12 +113,14 @@ def pack_state_dict(cfg: UNetConfig, sd, device):
             dense(f"{b}.attn1.to_v", bias=False)
             dense(f"{b}.attn1.to_out.0")
             dense(f"{b}.attn2.to_q", bias=False)
-            dense(f"{b}.attn2.to_k", bias=False)
-            dense(f"{b}.attn2.to_v", bias=False)
+            kcat.append(take(f"{b}.attn2.to_k.weight"))        # every cross-attention K / V projection of the UNet
+            vcat.append(take(f"{b}.attn2.to_v.weight"))        # is batched into one GEMM per forward (context-only)
             dense(f"{b}.attn2.to_out.0")
             packed[f"{b}.ff.net.0.proj.weight"] = w16(take(f"{b}.ff.net.0.proj.weight").to(device)[perm])
             packed[f"{b}.ff.net.0.proj.bias"] = f32(take(f"{b}.ff.net.0.proj.bias").to(device)[perm])
             dense(f"{b}.ff.net.2")
+    packed["attn2_k_cat.weight"] = w16(torch.cat([t.to(device) for t in kcat], 0))
+    packed["attn2_v_cat.weight"] = w16(torch.cat([t.to(device) for t in vcat], 0))
     for i in range(cfg.num_levels - 1):
         conv(f"down_blocks.{i}.downsamplers.0.conv")
         conv(f"up_blocks.{i}.upsamplers.0.conv")

@@ -162,7 +162,9 @@ def main():
         else:
             step()
     sync_all()
-    dominant = max(fam_table, key=lambda k: fam_table[k]["ms"]) if fam_table else None
+    # dominant family = the one carrying the most algorithmic work (stable from run to run, unlike a max over times
+    # when two families are within a few per cent of each other)
+    dominant = max(fam_table, key=lambda k: (fam_table[k]["flops"], fam_table[k]["ms"])) if fam_table else None
     if not a.no_profile:
         # timed region: HIP events only around the dominant kernel family (keeps event overhead out of `value`)
         _lib.profile_enable(True, only=[dominant] if dominant else None)

@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libicd_amd.so")
+# ICD_AMD_LIB selects another build of the same library (A/B kernel tuning on one GPU box); never a fallback.
+LIB_PATH = os.environ.get("ICD_AMD_LIB") or os.path.join(_HERE, "lib", "libicd_amd.so")
 
 ICD_GEMM_GEGLU = 1
 ICD_GEMM_OUT_F32 = 2

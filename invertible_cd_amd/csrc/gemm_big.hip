@@ -26,7 +26,6 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_big_kernel(GemmK p) {
     constexpr int A_BYTES = BM * 128, W_BYTES = BNt * 128, STAGE_BYTES = A_BYTES + W_BYTES;
     constexpr int NAJ = BM * 8 / NT, NWJ = BNt * 8 / NT;        // 16-B chunks per thread per stage
     constexpr int LOADS = NAJ + NWJ;
-    constexpr int LD = BNt + 4;                                  // fp32 staging row stride (floats)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, wv = tid >> 6, l = tid & 63;
     const int wm = wv / WN, wn = wv - wm * WN;
@@ -231,114 +230,111 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_big_kernel(GemmK p) {
         if (t + 1 < nk) k_tile(I1{}, t + 1);
     }
 
-    // ---- epilogue: 4 slabs of 64 rows, fp32 staging through LDS --------------------------------------------------
-    float* stage = reinterpret_cast<float*>(smem);
+    // ---- epilogue: every wave transposes its own accumulators through a private LDS patch ----------------------------
+    // A block owns its CU alone (128+ KiB of LDS), so nothing overlaps the epilogue: it has to be short.  No block-wide
+    // slabs / barriers: after one barrier (all fragment reads done) each wave stages 32 rows x 64 columns of fp32 at a
+    // time in its own 8.5 KiB patch and streams them out as 128-B row segments; the 8 waves hide each other's
+    // residual-load / store latency.
     const bool geglu = p.flags & ICD_GEMM_GEGLU;
     const bool out_f32 = p.flags & ICD_GEMM_OUT_F32;
-    constexpr int SLABS = BM / 64;
+    constexpr int LDW = 68;                                      // floats per staged row (64 + 4: conflict-free b128 writes)
+    __syncthreads();
+    float* wst = reinterpret_cast<float*>(smem) + wv * (32 * LDW);
+    float* part = p.ksplit > 1 ? p.partial + (long long)split * p.M * p.N : nullptr;
 #pragma unroll
-    for (int slab = 0; slab < SLABS; ++slab) {
-        __syncthreads();
-        constexpr int SPW = SLABS / WM;                  // slabs per wave row
-        constexpr int IPW = TM / SPW;                    // i-tiles of one wave per slab (2)
-        if (wm == slab / SPW) {
+    for (int i = 0; i < TM; ++i) {
+        const int mrow0 = m0 + (wm * TM + i) * 32;
 #pragma unroll
-            for (int ii = 0; ii < IPW; ++ii)
+        for (int j0 = 0; j0 < TN; j0 += 2) {
+            const int jn = (TN - j0) >= 2 ? 2 : 1;               // j-tiles in this group (compile-time after unrolling)
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
+            for (int jj = 0; jj < 2; ++jj) {
+                if (jj >= jn) break;
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const f32x16& a = acc[(slab % SPW) * IPW + ii][j];
-                        f32x4 v = {a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]};
-                        *reinterpret_cast<f32x4*>(stage + (ii * 32 + lr) * LD + wn * TN * 32 + j * 32 + 8 * g + 4 * lh) = v;
-                    }
-        }
-        __syncthreads();
-        const int mbase = m0 + slab * 64;
-        if (p.ksplit > 1) {
-            float* part = p.partial + (long long)split * p.M * p.N;
-            constexpr int CH = BNt / 8;
-#pragma unroll
-            for (int pass = 0; pass < 64 * CH / NT; ++pass) {
-                const int item = pass * NT + tid;
-                const int r = item / CH, c8 = (item - r * CH) * 8;
-                const int m = mbase + r, n = n0 + c8;
-                if (m >= p.M || n >= p.N) continue;
-                const float* sp = stage + r * LD + c8;
-                float* dst = part + (long long)m * p.N + n;
-                *reinterpret_cast<f32x4*>(dst) = *reinterpret_cast<const f32x4*>(sp);
-                *reinterpret_cast<f32x4*>(dst + 4) = *reinterpret_cast<const f32x4*>(sp + 4);
+                for (int g = 0; g < 4; ++g) {
+                    const f32x16& a = acc[i][j0 + jj];
+                    f32x4 v = {a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]};
+                    *reinterpret_cast<f32x4*>(wst + lr * LDW + jj * 32 + 8 * g + 4 * lh) = v;
+                }
             }
-        } else if (geglu) {
-            half_t* out = reinterpret_cast<half_t*>(p.out);
-            constexpr int CH = BNt / 16;                 // 8-wide output chunks per row (BNt/2 output columns)
+            const int ncol0 = n0 + (wn * TN + j0) * 32;
+            if (geglu) {                                         // 64 staged columns = [32 h | 32 gate] -> 32 outputs
+                half_t* out = reinterpret_cast<half_t*>(p.out);
 #pragma unroll
-            for (int pass = 0; pass < 64 * CH / NT; ++pass) {
-                const int item = pass * NT + tid;
-                const int r = item / CH, oc = (item - r * CH) * 8;
-                const int m = mbase + r;
-                const int hcol = (oc >> 5) * 64 + (oc & 31);
-                if (m >= p.M || n0 + hcol >= p.N) continue;
-                const float* sp = stage + r * LD + hcol;
-                f32x4 h0 = *reinterpret_cast<const f32x4*>(sp), h1 = *reinterpret_cast<const f32x4*>(sp + 4);
-                f32x4 g0 = *reinterpret_cast<const f32x4*>(sp + 32), g1 = *reinterpret_cast<const f32x4*>(sp + 36);
-                float hv[8] = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
-                float gv[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
-                if (p.bias) {
-                    const float* bp = p.bias + n0 + hcol;
-                    f32x4 b0 = *reinterpret_cast<const f32x4*>(bp), b1 = *reinterpret_cast<const f32x4*>(bp + 4);
-                    f32x4 c0 = *reinterpret_cast<const f32x4*>(bp + 32), c1 = *reinterpret_cast<const f32x4*>(bp + 36);
+                for (int pass = 0; pass < 2; ++pass) {           // 32 rows x 4 chunks of 8 outputs
+                    const int item = pass * 64 + l;
+                    const int r = item >> 2, oc = (item & 3) * 8;
+                    const int m = mrow0 + r;
+                    if (m >= p.M || ncol0 + oc >= p.N) continue;
+                    const float* sp = wst + r * LDW + oc;
+                    f32x4 h0 = *reinterpret_cast<const f32x4*>(sp), h1 = *reinterpret_cast<const f32x4*>(sp + 4);
+                    f32x4 g0 = *reinterpret_cast<const f32x4*>(sp + 32), g1 = *reinterpret_cast<const f32x4*>(sp + 36);
+                    float hv[8] = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+                    float gv[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
+                    if (p.bias) {
+                        const float* bp = p.bias + ncol0 + oc;
+                        f32x4 b0 = *reinterpret_cast<const f32x4*>(bp), b1 = *reinterpret_cast<const f32x4*>(bp + 4);
+                        f32x4 c0 = *reinterpret_cast<const f32x4*>(bp + 32), c1 = *reinterpret_cast<const f32x4*>(bp + 36);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        hv[e] = hv[e] * p.alpha + b0[e]; hv[4 + e] = hv[4 + e] * p.alpha + b1[e];
-                        gv[e] = gv[e] * p.alpha + c0[e]; gv[4 + e] = gv[4 + e] * p.alpha + c1[e];
+                        for (int e = 0; e < 4; ++e) {
+                            hv[e] = hv[e] * p.alpha + b0[e]; hv[4 + e] = hv[4 + e] * p.alpha + b1[e];
+                            gv[e] = gv[e] * p.alpha + c0[e]; gv[4 + e] = gv[4 + e] * p.alpha + c1[e];
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { hv[e] *= p.alpha; gv[e] *= p.alpha; }
                     }
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) { hv[e] *= p.alpha; gv[e] *= p.alpha; }
-                }
-                f16x8 o;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = (half_t)(hv[e] * gelu_fast(gv[e]));
-                *reinterpret_cast<f16x8*>(out + (long long)m * p.ldo + (n0 >> 1) + oc) = o;
-            }
-        } else {
-            constexpr int CH = BNt / 8;
-#pragma unroll
-            for (int pass = 0; pass < 64 * CH / NT; ++pass) {
-                const int item = pass * NT + tid;
-                const int r = item / CH, c8 = (item - r * CH) * 8;
-                const int m = mbase + r, n = n0 + c8;
-                if (m >= p.M || n >= p.N) continue;
-                const float* sp = stage + r * LD + c8;
-                f32x4 v0 = *reinterpret_cast<const f32x4*>(sp), v1 = *reinterpret_cast<const f32x4*>(sp + 4);
-                float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] *= p.alpha;
-                if (p.bias) {
-                    f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n), b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
-                }
-                if (p.rowbias) {
-                    f16x8 rb = *reinterpret_cast<const f16x8*>(p.rowbias + (long long)(m / p.rps) * p.ld_rowbias + n);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] += (float)rb[e];
-                }
-                if (p.resid) {
-                    f16x8 rs = *reinterpret_cast<const f16x8*>(p.resid + (long long)m * p.ldr + n);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] += (float)rs[e];
-                }
-                if (out_f32) {
-                    float* out = reinterpret_cast<float*>(p.out) + (long long)m * p.ldo + n;
-                    *reinterpret_cast<f32x4*>(out) = (f32x4){v[0], v[1], v[2], v[3]};
-                    *reinterpret_cast<f32x4*>(out + 4) = (f32x4){v[4], v[5], v[6], v[7]};
-                } else {
                     f16x8 o;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] = (half_t)v[e];
-                    *reinterpret_cast<f16x8*>(reinterpret_cast<half_t*>(p.out) + (long long)m * p.ldo + n) = o;
+                    for (int e = 0; e < 8; ++e) o[e] = (half_t)(hv[e] * gelu_fast(gv[e]));
+                    *reinterpret_cast<f16x8*>(out + (long long)m * p.ldo + (ncol0 >> 1) + oc) = o;
+                }
+            } else {
+                const int chs = jn == 2 ? 3 : 2;                 // log2(8-wide chunks per staged row)
+                const int npass = jn == 2 ? 4 : 2;
+#pragma unroll
+                for (int pass = 0; pass < 4; ++pass) {
+                    if (pass >= npass) break;
+                    const int item = pass * 64 + l;
+                    const int r = item >> chs, c8 = (item & ((1 << chs) - 1)) * 8;
+                    const int m = mrow0 + r, n = ncol0 + c8;
+                    if (m >= p.M || n >= p.N) continue;
+                    const float* sp = wst + r * LDW + c8;
+                    f32x4 v0 = *reinterpret_cast<const f32x4*>(sp), v1 = *reinterpret_cast<const f32x4*>(sp + 4);
+                    if (part) {
+                        float* dst = part + (long long)m * p.N + n;
+                        *reinterpret_cast<f32x4*>(dst) = v0;
+                        *reinterpret_cast<f32x4*>(dst + 4) = v1;
+                        continue;
+                    }
+                    float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] *= p.alpha;
+                    if (p.bias) {
+                        f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n), b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
+                    }
+                    if (p.rowbias) {
+                        f16x8 rb = *reinterpret_cast<const f16x8*>(p.rowbias + (long long)(m / p.rps) * p.ld_rowbias + n);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += (float)rb[e];
+                    }
+                    if (p.resid) {
+                        f16x8 rs = *reinterpret_cast<const f16x8*>(p.resid + (long long)m * p.ldr + n);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += (float)rs[e];
+                    }
+                    if (out_f32) {
+                        float* out = reinterpret_cast<float*>(p.out) + (long long)m * p.ldo + n;
+                        *reinterpret_cast<f32x4*>(out) = (f32x4){v[0], v[1], v[2], v[3]};
+                        *reinterpret_cast<f32x4*>(out + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+                    } else {
+                        f16x8 o;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o[e] = (half_t)v[e];
+                        *reinterpret_cast<f16x8*>(reinterpret_cast<half_t*>(p.out) + (long long)m * p.ldo + n) = o;
+                    }
                 }
             }
         }

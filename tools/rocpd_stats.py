@@ -31,6 +31,28 @@ def main(path):
     print(f"{'kernel':110s} {'calls':>7s} {'total_ms':>10s} {'avg_us':>10s} {'min_us':>9s} {'max_us':>9s} {'pct':>6s}")
     for n, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         print(f"{n:110s} {a[0]:7d} {a[1] / 1e6:10.3f} {a[1] / a[0] / 1e3:10.2f} {a[2] / 1e3:9.2f} {a[3] / 1e3:9.2f} {100 * a[1] / total:6.2f}")
+    # roll-up into the families bench.py's in-process profiler reports ("roofline.kernel" / "kernel_families")
+    fam = {}
+    for n, a in agg.items():
+        m = re.search(r"gemm(?:_big)?_kernel<(\d)", n)
+        if m:
+            f = "gemm_dense" if m.group(1) == "0" else "gemm_conv"
+        elif "splitk_reduce" in n:
+            f = "splitk_reduce (bench.py counts it inside the GEMM family that launched it)"
+        elif "attn_fused" in n:
+            f = "attn_fused"
+        elif "gn_" in n:
+            f = "groupnorm"
+        elif "layernorm" in n:
+            f = "layernorm"
+        else:
+            f = "other (elementwise, torch)"
+        x = fam.setdefault(f, [0, 0])
+        x[0] += a[0]; x[1] += a[1]
+    print()
+    print(f"{'family':110s} {'calls':>7s} {'total_ms':>10s} {'avg_us':>10s} {'pct':>6s}")
+    for f, x in sorted(fam.items(), key=lambda kv: -kv[1][1]):
+        print(f"{f:110s} {x[0]:7d} {x[1] / 1e6:10.3f} {x[1] / x[0] / 1e3:10.2f} {100 * x[1] / total:6.2f}")
 
 
 if __name__ == "__main__":

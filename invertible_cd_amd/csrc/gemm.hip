@@ -545,53 +545,58 @@ extern "C" int icd_gemm(const icd_gemm_desc* d, void* stream) {
     const bool allow_split = !trans && !geglu && batch == 1 && d->splitk_ws != nullptr && d->splitk_ws_bytes > 0;
     const int nk_total = (d->K + BK - 1) / BK;
     hipStream_t st = (hipStream_t)stream;
-    // ---- high-intensity tiles (gemm_big.hip): 256x320 when N % 320 == 0, 256x256 for GEGLU / N % 256 == 0 -------------
+    // ---- high-intensity tiles (gemm_big.hip), chosen from BIG_TILES by the cost model below ------------------------
     {
         const bool conv_fast = d->mode == 1 && ((d->C0 + d->C1) % 64 == 0) && (d->C0 % 64 == 0);
-        // candidates: 256x320 tiles (N % 320 == 0; TN = 5 cannot pair GEGLU columns) and 256x256 tiles (N % 256 == 0).
-        // Pick the one that fills the 256 CUs best (whole rounds); ties go to the larger tile.
         const bool base_ok = batch == 1 && !trans && (d->mode == 0 || conv_fast) && d->M >= 256 && (d->Nw <= 0 || d->Nw >= d->N) &&
                              (d->K % 64 == 0) && !(d->flags & 0x200000);
-        int tn = 0, s = 1;
-        long long blocks = 0;
-        double best = 0.0;
-        const int cand[2] = {5, 4};
-        for (int ci = 0; ci < 2 && base_ok; ++ci) {
-            const int c = cand[ci];
-            if (c == 5 && (geglu || d->N % 320 != 0 || (d->flags & 0x400000))) continue;
-            if (c == 4 && d->N % 256 != 0) continue;
-            const long long b0 = (long long)((d->M + 255) / 256) * (d->N / (64 * c));
-            int sc = 1;
+        // Cost model in units of "one k-tile of a 256x256 block" (calibrated with tools/gemm_bench.py, same-box A/B):
+        // a block owns its CU, so a launch costs rounds x (k-tiles x tk + fixed), fixed = prologue + exposed epilogue.
+        int cfg = -1, s = 1;
+        double best = 1e30, best_fill = 0.0;
+        const int forced = ((d->flags >> 24) & 15) - 1;          // tuning override: flags bits 24..27 = cfg + 1
+        for (int ci = 0; ci < NUM_BIG_TILES && base_ok; ++ci) {
+            const BigTile& c = BIG_TILES[ci];
+            if (forced >= 0 && ci != forced) continue;
+            if (d->N % c.bn != 0 || (geglu && !c.geglu_ok) || ((d->flags & 0x400000) && c.bn != 256)) continue;
+            const long long b0 = (long long)((d->M + c.bm - 1) / c.bm) * (d->N / c.bn);
+            int smax = 1;
             if (allow_split && b0 < 192 && nk_total >= 16) {
-                sc = (int)((256 + b0 - 1) / b0);
-                sc = sc > 8 ? 8 : sc;
-                while (sc > 1 && nk_total / sc < 8) --sc;
-                while (sc > 1 && (long long)sc * d->M * d->N * 4 > d->splitk_ws_bytes) --sc;
+                smax = 8;
+                while (smax > 1 && nk_total / smax < 8) --smax;
+                while (smax > 1 && (long long)smax * d->M * d->N * 4 > d->splitk_ws_bytes) --smax;
             }
-            const long long bt = b0 * sc;
-            double eff = (double)bt / (double)(((bt + 255) / 256) * 256);
-            if (sc > 1) eff *= (nk_total / sc >= 32) ? 0.85 : 0.55;   // fp32 partial round trip: dear when K is short
-            if (eff > best + 1e-9) { best = eff; tn = c; s = sc; blocks = b0; }
+            for (int sx = 1; sx <= smax; ++sx) {
+                const long long bt = b0 * sx;
+                const long long full = bt / 256, rem = bt % 256;
+                // rounds are strict for the first two (all blocks in lockstep), later ones desynchronise
+                const double rounds = bt <= 512 ? (double)((bt + 255) / 256) : (double)full + (rem ? 0.3 + 0.7 * rem / 256.0 : 0.0);
+                const double act = bt >= 256 ? 256.0 : (double)bt;
+                const double w = act <= 160 ? 0.0 : act >= 200 ? 1.0 : (act - 160) / 40.0;
+                const double tk = c.tk_part + w * (c.tk_full - c.tk_part);
+                const int kps = (nk_total + sx - 1) / sx;
+                double cost = rounds * (kps * tk + c.fixed);
+                if (sx > 1) cost += (double)(sx + 1) * d->M * d->N * 4.0 / 3.5e12 / 1.5e-6 + 4.0;   // fp32 partials + reduce launch
+                if (cost < best) { best = cost; cfg = ci; s = sx; best_fill = (double)bt / (double)(((bt + 255) / 256) * 256); }
+            }
         }
-        const bool eligible = tn != 0;
-        if (eligible) {
-            if (best >= 0.6 || (d->flags & 0x100000)) {
-                k.nbm = (d->M + 255) / 256; k.nbn = d->N / (64 * tn);
-                k.kt_per_split = (nk_total + s - 1) / s;
-                k.ksplit = (nk_total + k.kt_per_split - 1) / k.kt_per_split;
-                if (d->mode == 1) {
-                    ICD_CHECK_ARG(d->ksize == 1 || d->ksize == 3, "icd_gemm: conv ksize must be 1 or 3");
-                    ICD_CHECK_ARG(d->K == d->ksize * d->ksize * (d->C0 + d->C1), "icd_gemm: K != taps*Cin");
-                    ICD_CHECK_ARG((d->C1 == 0) == (d->a1 == nullptr), "icd_gemm: a1/C1 mismatch");
-                } else {
-                    k.ksize = 0; k.Hout = 0;
-                    ICD_CHECK_ARG(d->lda % 8 == 0, "icd_gemm: lda must be a multiple of 8");
-                }
-                const int rc = launch_big(k, tn, st);
-                if (rc != ICD_OK) return rc;
-                if (k.ksplit > 1) return launch_reduce(k, st);
-                return ICD_OK;
+        if (cfg >= 0 && (best_fill >= 0.45 || forced >= 0 || (d->flags & 0x100000))) {
+            const BigTile& c = BIG_TILES[cfg];
+            k.nbm = (d->M + c.bm - 1) / c.bm; k.nbn = d->N / c.bn;
+            k.kt_per_split = (nk_total + s - 1) / s;
+            k.ksplit = (nk_total + k.kt_per_split - 1) / k.kt_per_split;
+            if (d->mode == 1) {
+                ICD_CHECK_ARG(d->ksize == 1 || d->ksize == 3, "icd_gemm: conv ksize must be 1 or 3");
+                ICD_CHECK_ARG(d->K == d->ksize * d->ksize * (d->C0 + d->C1), "icd_gemm: K != taps*Cin");
+                ICD_CHECK_ARG((d->C1 == 0) == (d->a1 == nullptr), "icd_gemm: a1/C1 mismatch");
+            } else {
+                k.ksize = 0; k.Hout = 0;
+                ICD_CHECK_ARG(d->lda % 8 == 0, "icd_gemm: lda must be a multiple of 8");
             }
+            const int rc = launch_big(k, cfg, st);
+            if (rc != ICD_OK) return rc;
+            if (k.ksplit > 1) return launch_reduce(k, st);
+            return ICD_OK;
         }
     }
     plan_gemm(d->M, d->N, d->K, batch, allow_split, d->splitk_ws_bytes, &wm, &ks);

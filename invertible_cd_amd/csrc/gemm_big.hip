@@ -359,12 +359,21 @@ int launch_one(const GemmK& k, hipStream_t st) {
 
 namespace icd_gemm_detail {
 
-// k.nbm / k.nbn / k.ksplit / k.kt_per_split are set by the caller for BM = 256, BN = 64 * tn
-int launch_big(const GemmK& k, int tn, hipStream_t st) {
+// k.nbm / k.nbn / k.ksplit / k.kt_per_split are set by the caller for the tile of configuration `cfg` (BIG_TILES[])
+int launch_big(const GemmK& k, int cfg, hipStream_t st) {
     const bool conv = k.ksize > 0 && k.Hout > 0;
-    if (tn == 5)                                 // 256 x 320: 8 waves (4 x 2), wave tile 64 x 160 (N % 320 == 0, no GEGLU)
+    switch (cfg) {
+    case 0:   // 256 x 256: 2 x 4 waves of 128 x 64 (GEGLU capable)
+        return conv ? launch_one<1, 2, 4, 4, 2>(k, st) : launch_one<0, 2, 4, 4, 2>(k, st);
+    case 1:   // 256 x 320: 4 x 2 waves of 64 x 160
         return conv ? launch_one<1, 4, 2, 2, 5>(k, st) : launch_one<0, 4, 2, 2, 5>(k, st);
-    return conv ? launch_one<1, 2, 4, 4, 2>(k, st) : launch_one<0, 2, 4, 4, 2>(k, st);   // 256 x 256: 2 x 4 waves of 128 x 64
+    case 2:   // 192 x 256: 2 x 4 waves of 96 x 64 (GEGLU capable) - chip fill for M = 8192-class layers
+        return conv ? launch_one<1, 2, 4, 3, 2>(k, st) : launch_one<0, 2, 4, 3, 2>(k, st);
+    case 3:   // 128 x 320: 4 x 2 waves of 32 x 160
+        return conv ? launch_one<1, 4, 2, 1, 5>(k, st) : launch_one<0, 4, 2, 1, 5>(k, st);
+    }
+    icd_set_error("icd_gemm: unknown big-tile configuration %d", cfg);
+    return ICD_ERR_INVALID_ARG;
 }
 
 }  // namespace icd_gemm_detail

@@ -38,6 +38,19 @@ __device__ __forceinline__ float erf_fast(float x) {
 __device__ __forceinline__ float gelu_fast(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752f)); }
 
 
-int launch_big(const GemmK& k, int tn, hipStream_t st);      // gemm_big.hip; tn = 5 (BN 320) or 4 (BN 256, GEGLU capable)
+// gemm_big.hip tile configurations and their measured cost (tools/gemm_bench.py with forced configurations, one box):
+// one launch costs rounds x (k-tiles x tk + fixed) where a block owns its CU (1 block / CU), tk = one k-tile of one
+// block and fixed = prologue + exposed epilogue, both in units of one k-tile of a 256 x 256 block on a partly filled
+// chip (about 1.3 - 1.7 us depending on the box's clocks).  tk_full applies when >= 200 CUs are busy (chip-level
+// ceiling: the same block runs about 10 - 20 % slower), tk_part when <= 160.
+struct BigTile { int bm, bn; bool geglu_ok; double tk_part, tk_full, fixed; };
+constexpr int NUM_BIG_TILES = 4;
+constexpr BigTile BIG_TILES[NUM_BIG_TILES] = {
+    {256, 256, true, 1.00, 1.08, 9.5},
+    {256, 320, false, 1.07, 1.30, 15.3},
+    {192, 256, true, 0.70, 0.76, 9.6},
+    {128, 320, false, 0.72, 0.80, 7.2},
+};
+int launch_big(const GemmK& k, int cfg, hipStream_t st);     // cfg = index into BIG_TILES
 
 }  // namespace icd_gemm_detail

@@ -22,7 +22,6 @@ if kind == "conv":
     x, w, b = rnd(B * H * W, Ci), rnd(Co, 9 * Ci) * (9 * Ci) ** -0.5, torch.zeros(Co, device=dev)
     import ctypes as C
     from invertible_cd_amd import _lib
-    dbg = int(os.environ.get("DBGFLAGS", "0"), 0)
     def fn():
         out = torch.empty((B * H * W, Co), device=dev, dtype=torch.float16)
         d = _lib.GemmDesc()
@@ -39,7 +38,6 @@ elif kind in ("dense", "geglu"):
     res = None if kind == "geglu" else rnd(M, N)
     import ctypes as C
     from invertible_cd_amd import _lib
-    dbg = int(os.environ.get("DBGFLAGS", "0"), 0)
     def fn():
         out = torch.empty((M, N // 2 if kind == "geglu" else N), device=dev, dtype=torch.float16)
         d = _lib.GemmDesc()
@@ -56,14 +54,17 @@ else:
     vt = v.reshape(B, Nk, H * d).transpose(1, 2).contiguous()
     fn = lambda: ops.attention_fused(q, k, vt, B, H, Nq, Nk, d, d ** -0.5)
     flops = 4.0 * B * H * Nq * Nk * d
-for _ in range(3):
-    fn()
-torch.cuda.synchronize()
-e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-e0.record()
-for _ in range(iters):
-    fn()
-e1.record()
-torch.cuda.synchronize()
-ms = e0.elapsed_time(e1) / iters
-print(f"{kind} {a}: {ms * 1e3:.1f} us/call  {flops / ms / 1e9:.1f} TFLOP/s")
+# DBGFLAGS may be a comma-separated list: every entry is timed in this process (same box, same clocks)
+for dbg_s in os.environ.get("DBGFLAGS", "0").split(","):
+    dbg = int(dbg_s, 0)
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    print(f"{kind} {a} flags={dbg_s}: {ms * 1e3:.1f} us/call  {flops / ms / 1e9:.1f} TFLOP/s")

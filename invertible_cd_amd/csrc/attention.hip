@@ -14,9 +14,9 @@
 //     owns ONE query column and 32 of the tile's 64 keys, so the online-softmax row reductions are in-lane plus one
 //     cross-half shuffle.  The softmax scale is folded into the exp2 argument (one FMA + one v_exp_f32 per score);
 //     key masking exists only in a peeled instantiation for a ragged last tile.
-//   * O^T += V^T.P^T reuses the S^T accumulator registers directly as the B operand: the k-index <-> key permutation is
-//     chosen to match the 32x32 accumulator layout (keys 16s+4h+{0..3,8..11}), V^T fragments are fetched with two
-//     ds_read_b64 in the same permutation.  P never leaves registers.
+//   * O^T += V^T.P^T reuses the S^T accumulator registers directly as the B operand: K rows enter the S^T MFMA in a
+//     bit-swapped order so the k-slots of a lane are 8 consecutive keys and a V^T fragment is one ds_read_b128.
+//     P never leaves registers.
 //   * when the padded head dim leaves a free V^T row (d = 40, 80, ...) that row is loaded with ones and the MFMA itself
 //     accumulates the softmax denominator (with exactly the fp16-rounded P the numerator uses): no VALU row sums.
 //   * XCD-aware block order: the q-tiles of one (b, h) run on one XCD so its K/V stay in that XCD's L2.
@@ -46,6 +46,18 @@ struct AttnK {
 };
 
 // KS = 16-wide k-steps over the head dim (dpad16 = 16*KS); DT = 32-row tiles of the head dim; QT = query tiles per wave
+//
+// The loop is VALU-issue bound (PMC: VALU pipe 70 % busy with two waves per SIMD, MFMA pipe 25 %), so everything that is
+// not exp / scale / convert / max is kept out of the steady state:
+//   * K rows are fed to the S^T MFMA in a bit-swapped order (row r <- key r with bits 2 and 3 exchanged), so that the 8
+//     accumulator values a lane contributes to one P^T k-slot are 8 CONSECUTIVE keys: every V^T fragment is one
+//     ds_read_b128 and P goes from the accumulators to the B operand with no register shuffles;
+//   * the global -> LDS source pointers are computed once and bumped per tile; the ragged last tile (key masking,
+//     guarded loads) is peeled out of the loop, and the loop is unrolled by two so LDS offsets are immediates;
+//   * row sums come from the MFMA pipe (a ones-row of V^T when the padded head dim leaves one, otherwise one extra MFMA
+//     per 16 keys with an all-ones A operand);
+//   * lazy rescaling: O / l are rescaled only when a row maximum grows by more than 2^8 since the last rescale (P then
+//     stays <= 256, exact in fp16's relative precision); the check is one wave-uniform branch.
 template <int KS, int DT, int QT>
 __global__ __launch_bounds__(256, 2) void attn_fused_kernel(AttnK p) {
     constexpr int NCH = 2 * KS;                       // 16-B chunks per K row
@@ -53,8 +65,10 @@ __global__ __launch_bounds__(256, 2) void attn_fused_kernel(AttnK p) {
     constexpr int KT_BYTES = 64 * NCH * 16;           // K tile
     constexpr int VT_BYTES = DT * 32 * 128;           // V^T tile, 64 keys = 128 B per row
     constexpr int STAGE = KT_BYTES + VT_BYTES;
+    constexpr int NKG = (2 * KS + 3) / 4;             // K-tile load groups per wave (64 chunks each)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, wv = tid >> 6, l = tid & 63, lr = l & 31, lh = l >> 5;
+    const int tid = threadIdx.x, l = tid & 63, lr = l & 31, lh = l >> 5;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
 
     int bid = blockIdx.x;
     {
@@ -86,30 +100,81 @@ __global__ __launch_bounds__(256, 2) void attn_fused_kernel(AttnK p) {
         }
     }
 
-    auto issue = [&](int t, int buf) {
-        unsigned char* sk = smem + buf * STAGE;
+    // ---- global -> LDS: per-lane source pointers for full tiles (bumped by one tile per use) -----------------------
+    const half_t* kp[NKG]; int kinc[NKG];
+    const half_t* vp[DT]; int vinc[DT];
+#pragma unroll
+    for (int j = 0; j < NKG; ++j) {
+        const int g = wv + 4 * j;
+        const int cid = g * 64 + l;
+        const int row = cid / NCH, pc = cid - row * NCH;
+        const int dd = k_swz<NCH>(row, pc) * 8;
+        const bool ok = dd < p.d;
+        kp[j] = ok ? Kb + (long long)row * p.ldk + dd : zero;
+        kinc[j] = ok ? 64 * p.ldk : 0;
+    }
+#pragma unroll
+    for (int j = 0; j < DT; ++j) {
+        const int g = wv + 4 * j;
+        const int cid = g * 64 + l;
+        const int row = cid >> 3, pc = cid & 7;
+        const int lc = pc ^ ((row >> 1) & 7);
+        const bool ok = row < p.d;
+        vp[j] = ok ? Vb + (long long)row * p.ldvt + lc * 8 : zero;
+        vinc[j] = ok ? 64 : 0;
+        if (ONES && row == DT * 32 - 1) { vp[j] = icd_ones_page; vinc[j] = 0; }
+    }
+    auto issue_fast = [&](int buf_off) {                  // tile is full: no key guards
+        unsigned char* sk = smem + buf_off;
+        unsigned char* sv = sk + KT_BYTES;
+#pragma unroll
+        for (int j = 0; j < NKG; ++j) {
+            const int g = wv + 4 * j;
+            if (g < 2 * KS) { glds16(kp[j], sk + g * 1024); kp[j] += kinc[j]; }
+        }
+#pragma unroll
+        for (int j = 0; j < DT; ++j) {
+            glds16(vp[j], sv + (wv + 4 * j) * 1024);
+            vp[j] += vinc[j];
+        }
+    };
+    auto issue_slow = [&](int t, int buf_off) {           // ragged last tile: rows / chunks past Nk park on the zero page
+        unsigned char* sk = smem + buf_off;
         unsigned char* sv = sk + KT_BYTES;
         const int kv0 = t * 64;
 #pragma unroll
-        for (int g = wv; g < 2 * KS; g += 4) {          // K tile: 64 rows x NCH chunks = 2*KS groups of 64 chunks
-            const int cid = g * 64 + l;
-            const int row = cid / NCH, pc = cid - row * NCH;
-            const int lc = k_swz<NCH>(row, pc);
-            const int key = kv0 + row, dd = lc * 8;
-            const half_t* src = (key < p.Nk && dd < p.d) ? Kb + (long long)key * p.ldk + dd : zero;
-            glds16(src, sk + g * 1024);
+        for (int j = 0; j < NKG; ++j) {
+            const int g = wv + 4 * j;
+            if (g < 2 * KS) {
+                const int cid = g * 64 + l;
+                const int row = cid / NCH, pc = cid - row * NCH;
+                const int key = kv0 + row, dd = k_swz<NCH>(row, pc) * 8;
+                const half_t* src = (key < p.Nk && dd < p.d) ? Kb + (long long)key * p.ldk + dd : zero;
+                glds16(src, sk + g * 1024);
+            }
         }
 #pragma unroll
-        for (int g = wv; g < 4 * DT; g += 4) {          // V^T tile: DT*32 rows x 8 chunks = 4*DT groups
+        for (int j = 0; j < DT; ++j) {
+            const int g = wv + 4 * j;
             const int cid = g * 64 + l;
             const int row = cid >> 3, pc = cid & 7;
-            const int lc = pc ^ ((row >> 1) & 7);
-            const int key = kv0 + lc * 8;
+            const int key = kv0 + (pc ^ ((row >> 1) & 7)) * 8;
             const half_t* src = (row < p.d && key < p.ldvt) ? Vb + (long long)row * p.ldvt + key : zero;
             if (ONES && row == DT * 32 - 1) src = icd_ones_page;
             glds16(src, sv + g * 1024);
         }
     };
+
+    // ---- LDS read offsets (bytes, buffer 0; buffer / sub-tile offsets are immediates) ------------------------------
+    int kbase[KS], vbase[4];
+    {
+        const int prow = (lr & 0x13) | ((lr & 4) << 1) | ((lr & 8) >> 1);      // bits 2 and 3 exchanged
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) kbase[ks] = (prow * NCH + k_swz<NCH>(prow, ks * 2 + lh)) * 16;
+        const int x = (lr >> 1) & 7;
+#pragma unroll
+        for (int st = 0; st < 4; ++st) vbase[st] = KT_BYTES + lr * 128 + (((2 * st + lh) ^ x) << 4);
+    }
 
     f32x16 o[QT][DT];
 #pragma unroll
@@ -118,8 +183,7 @@ __global__ __launch_bounds__(256, 2) void attn_fused_kernel(AttnK p) {
         for (int i = 0; i < DT; ++i)
 #pragma unroll
             for (int e = 0; e < 16; ++e) o[u][i][e] = 0.f;
-    // running max in RAW score units (the softmax scale is folded into the exp2 argument); running sum only when the
-    // MFMA cannot produce it (see ONES)
+    // m_run: the row offset (raw score units) currently folded into O and l; l_run only when no ones-row exists
     float m_run[QT], l_run[QT];
 #pragma unroll
     for (int u = 0; u < QT; ++u) { m_run[u] = -INFINITY; l_run[u] = 0.f; }
@@ -128,26 +192,27 @@ __global__ __launch_bounds__(256, 2) void attn_fused_kernel(AttnK p) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) zero16[e] = 0.f;
     asm volatile("" : "+v"(zero16));          // keep it in registers: do not re-materialise 16 zeros per tile
+    f16x8 ones8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones8[e] = (half_t)1.f;
+    asm volatile("" : "+v"(ones8));
 
-    auto tile = [&](auto ragged_tag, int t) {
+    auto tile = [&](auto ragged_tag, auto buf_tag, int t) {
         constexpr bool RAGGED = decltype(ragged_tag)::value;
-        const unsigned char* sk = smem + (t & 1) * STAGE;
-        const unsigned char* sv = sk + KT_BYTES;
+        constexpr int BO = decltype(buf_tag)::value * STAGE;
         // ---- S^T[key][q] for two 32-key tiles (x QT query tiles: each K fragment is read once) ----
         f32x16 s[QT][2];
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
-            const int row = kt * 32 + lr;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                const int cc = ks * 2 + lh;
-                f16x8 kf = *reinterpret_cast<const f16x8*>(sk + (row * NCH + k_swz<NCH>(row, cc)) * 16);
+                f16x8 kf = *reinterpret_cast<const f16x8*>(smem + kbase[ks] + (BO + kt * 32 * NCH * 16));
 #pragma unroll
                 for (int u = 0; u < QT; ++u)
                     s[u][kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[u][ks], ks == 0 ? zero16 : s[u][kt], 0, 0, 0);
             }
         }
-        // ---- online softmax (lane owns query column lr; keys 32kt + 8g + 4lh + i) ----
+        // ---- softmax numerators (lane owns query column lr; element e of s[kt] is key 32kt + 16(e>>3) + 8lh + (e&7)) ----
         f16x8 pf[QT][4];
 #pragma unroll
         for (int u = 0; u < QT; ++u) {
@@ -156,67 +221,94 @@ __global__ __launch_bounds__(256, 2) void attn_fused_kernel(AttnK p) {
                 for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
-                        const int key = t * 64 + kt * 32 + 8 * (e >> 2) + 4 * lh + (e & 3);
+                        const int key = t * 64 + kt * 32 + 16 * (e >> 3) + 8 * lh + (e & 7);
                         if (key >= p.Nk) s[u][kt][e] = -INFINITY;
                     }
             }
-            float mx = fmaxf(s[u][0][0], s[u][1][0]);
+            float mx0 = fmaxf(s[u][0][0], s[u][1][0]), mx1 = fmaxf(s[u][0][1], s[u][1][1]);
 #pragma unroll
-            for (int e = 1; e < 16; ++e) mx = fmaxf(mx, fmaxf(s[u][0][e], s[u][1][e]));
+            for (int e = 2; e < 16; e += 2) {
+                mx0 = fmaxf(fmaxf(mx0, s[u][0][e]), s[u][1][e]);
+                mx1 = fmaxf(fmaxf(mx1, s[u][0][e + 1]), s[u][1][e + 1]);
+            }
+            float mx = fmaxf(mx0, mx1);
             mx = fmaxf(mx, __shfl_xor(mx, 32));
-            const float m_new = fmaxf(m_run[u], mx);
-            const float alpha = __builtin_amdgcn_exp2f((m_run[u] - m_new) * c);
-            const float nmc = -m_new * c;
-            m_run[u] = m_new;
-            float rs = 0.f;
+            if (__builtin_amdgcn_ballot_w64((mx - m_run[u]) * c > 8.0f)) {       // rare after the first tiles
+                const float m_new = fmaxf(m_run[u], mx);
+                const float alpha = __builtin_amdgcn_exp2f((m_run[u] - m_new) * c);
+                m_run[u] = m_new;
+                if (!ONES) l_run[u] *= alpha;
+#pragma unroll
+                for (int i = 0; i < DT; ++i)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) o[u][i][e] *= alpha;
+            }
+            const float nmc = -m_run[u] * c;
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const float pv = __builtin_amdgcn_exp2f(fmaf(s[u][kt][e], c, nmc));
-                    if (!ONES) rs += pv;
-                    pf[u][kt * 2 + (e >> 3)][e & 7] = (half_t)pv;
-                }
-            if (!ONES) l_run[u] = l_run[u] * alpha + rs;
-#pragma unroll
-            for (int i = 0; i < DT; ++i)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) o[u][i][e] *= alpha;
+                for (int e = 0; e < 16; ++e)
+                    pf[u][kt * 2 + (e >> 3)][e & 7] = (half_t)__builtin_amdgcn_exp2f(fmaf(s[u][kt][e], c, nmc));
         }
         // ---- O^T[dcol][q] += V^T[dcol][keys] . P^T[keys][q]  (each V^T fragment read once for the QT query tiles) ----
+        f32x16 ls[QT];
 #pragma unroll
         for (int st = 0; st < 4; ++st) {
-            const int c0 = st * 2;                      // keys 16st + 4lh + {0..3} and +8
 #pragma unroll
             for (int i = 0; i < DT; ++i) {
-                const int row = i * 32 + lr;
-                const unsigned char* rp = sv + row * 128 + lh * 8;
-                const int x = (row >> 1) & 7;
-                f16x4 v0 = *reinterpret_cast<const f16x4*>(rp + ((c0 ^ x) << 4));
-                f16x4 v1 = *reinterpret_cast<const f16x4*>(rp + (((c0 + 1) ^ x) << 4));
-                f16x8 vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                f16x8 vf = *reinterpret_cast<const f16x8*>(smem + vbase[st] + (BO + i * 4096));
 #pragma unroll
                 for (int u = 0; u < QT; ++u) o[u][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[u][st], o[u][i], 0, 0, 0);
             }
+            if (!ONES) {
+#pragma unroll
+                for (int u = 0; u < QT; ++u)
+                    ls[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones8, pf[u][st], st == 0 ? zero16 : ls[u], 0, 0, 0);
+            }
+        }
+        if (!ONES) {
+#pragma unroll
+            for (int u = 0; u < QT; ++u) l_run[u] += ls[u][0];          // every row of ones . P^T is the full 64-key sum
         }
     };
+    using F = std::false_type;
+    using T = std::true_type;
+    using B0 = std::integral_constant<int, 0>;
+    using B1 = std::integral_constant<int, 1>;
 
-    const int nt = (p.Nk + 63) >> 6;
-    const bool last_ragged = (p.Nk & 63) != 0;
-    issue(0, 0);
-    for (int t = 0; t < nt; ++t) {
-        __builtin_amdgcn_s_waitcnt(0x0f70);
+    const int nfull = p.Nk >> 6;
+    const bool ragged = (p.Nk & 63) != 0;
+    auto handover = [&]() {
+        __builtin_amdgcn_s_waitcnt(0x0f70);              // vmcnt(0): this wave's part of the next tile has landed
         __syncthreads();
-        if (t + 1 < nt) issue(t + 1, (t + 1) & 1);
-        if (last_ragged && t == nt - 1) tile(std::true_type{}, t);
-        else tile(std::false_type{}, t);
+    };
+    auto step = [&](auto buf_tag, int t) {               // full tile t sits in buffer BUF
+        constexpr int BUF = decltype(buf_tag)::value;
+        handover();
+        if (t + 1 < nfull) issue_fast((BUF ^ 1) * STAGE);
+        else if (ragged) issue_slow(t + 1, (BUF ^ 1) * STAGE);
+        tile(F{}, buf_tag, t);
+    };
+    if (nfull > 0) issue_fast(0);
+    else issue_slow(0, 0);
+    int t = 0;
+    for (; t + 1 < nfull; t += 2) {
+        step(B0{}, t);
+        step(B1{}, t + 1);
+    }
+    if (t < nfull) {
+        step(B0{}, t);
+        if (ragged) { handover(); tile(T{}, B1{}, t + 1); }
+    } else if (ragged) {
+        handover();
+        tile(T{}, B0{}, t);
     }
     // ---- normalise and store: lane holds 4 consecutive head-dim columns of query row q0 + 32u + lr ----
 #pragma unroll
     for (int u = 0; u < QT; ++u) {
         float l_tot;
         if (ONES) l_tot = __shfl(o[u][DT - 1][15], lr + 32);   // row DT*32-1 of O^T = sum_k P (the V^T ones-row), upper half-wave
-        else l_tot = l_run[u] + __shfl_xor(l_run[u], 32);
+        else l_tot = l_run[u];
         const float inv = 1.0f / l_tot;
         const int qrow = q0 + u * 32 + lr;
         if (qrow < p.Nq) {

@@ -58,8 +58,11 @@ struct AttnK {
 //     per 16 keys with an all-ones A operand);
 //   * lazy rescaling: O / l are rescaled only when a row maximum grows by more than 2^8 since the last rescale (P then
 //     stays <= 256, exact in fp16's relative precision); the check is one wave-uniform branch.
-template <int KS, int DT, int QT>
-__global__ __launch_bounds__(256, 2) void attn_fused_kernel(AttnK p) {
+//   * NST-stage LDS ring (NST = 3 where it fits): tiles are requested two ahead and handed over with a counted vmcnt -
+//     one tile of compute (~0.6 us) does not cover the global -> LDS latency (PMC: 35 % of wave cycles in s_waitcnt
+//     with a 2-stage ring).
+template <int KS, int DT, int QT, int OCC, int NST>
+__global__ __launch_bounds__(256, OCC) void attn_fused_kernel(AttnK p) {
     constexpr int NCH = 2 * KS;                       // 16-B chunks per K row
     constexpr bool ONES = KS * 16 < DT * 32;          // a free padded V^T row exists: MFMA computes the denominator
     constexpr int KT_BYTES = 64 * NCH * 16;           // K tile
@@ -197,21 +200,45 @@ __global__ __launch_bounds__(256, 2) void attn_fused_kernel(AttnK p) {
     for (int e = 0; e < 8; ++e) ones8[e] = (half_t)1.f;
     asm volatile("" : "+v"(ones8));
 
-    auto tile = [&](auto ragged_tag, auto buf_tag, int t) {
+    // BO = byte offset of the tile's LDS stage: a literal in the unrolled loop (folds into the ds_read immediates).
+    // Fragment reads are issued in batches and fenced (sched_barrier): left alone, the register allocator reuses one
+    // quad for every fragment and serialises ds_read -> s_waitcnt lgkmcnt(0) -> v_mfma, i.e. 16 exposed LDS latencies
+    // per tile (measured: removing the LDS reads made the old loop 28 % faster, removing the exps did nothing).
+    auto tile = [&](auto ragged_tag, const int BO, int t) {
         constexpr bool RAGGED = decltype(ragged_tag)::value;
-        constexpr int BO = decltype(buf_tag)::value * STAGE;
-        // ---- S^T[key][q] for two 32-key tiles (x QT query tiles: each K fragment is read once) ----
+        // ---- K fragments in batches of 2 x KC, then S^T[key][q] for two 32-key tiles ----
+        constexpr int KC = KS <= 6 ? KS : (KS + 1) / 2;
         f32x16 s[QT][2];
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt) {
+        for (int k0 = 0; k0 < KS; k0 += KC) {
+            f16x8 kf[2][KC];
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                f16x8 kf = *reinterpret_cast<const f16x8*>(smem + kbase[ks] + (BO + kt * 32 * NCH * 16));
+            for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                for (int u = 0; u < QT; ++u)
-                    s[u][kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[u][ks], ks == 0 ? zero16 : s[u][kt], 0, 0, 0);
-            }
+                for (int kk = 0; kk < KC; ++kk)
+                    if (k0 + kk < KS)
+                        kf[kt][kk] = *reinterpret_cast<const f16x8*>(smem + kbase[k0 + kk] + (BO + kt * 32 * NCH * 16));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kk = 0; kk < KC; ++kk)
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int u = 0; u < QT; ++u)
+                        if (k0 + kk < KS)
+                            s[u][kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kt][kk], qf[u][k0 + kk],
+                                                                              k0 + kk == 0 ? zero16 : s[u][kt], 0, 0, 0);
+            if (k0 + KC < KS) __builtin_amdgcn_sched_barrier(0);
         }
+        // ---- V^T fragments of the first VPRE key steps: in flight while the softmax runs ----
+        constexpr int VPRE = QT * DT <= 2 ? 4 : QT * DT <= 4 ? 2 : 1;      // at most 8 fragments (32 VGPRs) ahead
+        f16x8 vf[4][DT];
+#pragma unroll
+        for (int st = 0; st < VPRE; ++st)
+#pragma unroll
+            for (int i = 0; i < DT; ++i)
+                vf[st][i] = *reinterpret_cast<const f16x8*>(smem + vbase[st] + (BO + i * 4096));
+        __builtin_amdgcn_sched_barrier(0);
         // ---- softmax numerators (lane owns query column lr; element e of s[kt] is key 32kt + 16(e>>3) + 8lh + (e&7)) ----
         f16x8 pf[QT][4];
 #pragma unroll
@@ -232,7 +259,10 @@ __global__ __launch_bounds__(256, 2) void attn_fused_kernel(AttnK p) {
                 mx1 = fmaxf(fmaxf(mx1, s[u][0][e + 1]), s[u][1][e + 1]);
             }
             float mx = fmaxf(mx0, mx1);
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            {   // other half-wave's maximum with v_permlane32_swap (VALU; a ds_bpermute would drain the LDS queue)
+                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+                mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+            }
             if (__builtin_amdgcn_ballot_w64((mx - m_run[u]) * c > 8.0f)) {       // rare after the first tiles
                 const float m_new = fmaxf(m_run[u], mx);
                 const float alpha = __builtin_amdgcn_exp2f((m_run[u] - m_new) * c);
@@ -250,16 +280,22 @@ __global__ __launch_bounds__(256, 2) void attn_fused_kernel(AttnK p) {
                 for (int e = 0; e < 16; ++e)
                     pf[u][kt * 2 + (e >> 3)][e & 7] = (half_t)__builtin_amdgcn_exp2f(fmaf(s[u][kt][e], c, nmc));
         }
-        // ---- O^T[dcol][q] += V^T[dcol][keys] . P^T[keys][q]  (each V^T fragment read once for the QT query tiles) ----
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- O^T[dcol][q] += V^T[dcol][keys] . P^T[keys][q]  (each V^T fragment feeds the QT query tiles; the
+        //      fragments of key step st+1 are requested before the MFMAs of step st) ----
         f32x16 ls[QT];
 #pragma unroll
         for (int st = 0; st < 4; ++st) {
+            if (st + 1 >= VPRE && st + 1 < 4) {
 #pragma unroll
-            for (int i = 0; i < DT; ++i) {
-                f16x8 vf = *reinterpret_cast<const f16x8*>(smem + vbase[st] + (BO + i * 4096));
-#pragma unroll
-                for (int u = 0; u < QT; ++u) o[u][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[u][st], o[u][i], 0, 0, 0);
+                for (int i = 0; i < DT; ++i)
+                    vf[st + 1][i] = *reinterpret_cast<const f16x8*>(smem + vbase[st + 1] + (BO + i * 4096));
+                __builtin_amdgcn_sched_barrier(0);
             }
+#pragma unroll
+            for (int i = 0; i < DT; ++i)
+#pragma unroll
+                for (int u = 0; u < QT; ++u) o[u][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[st][i], pf[u][st], o[u][i], 0, 0, 0);
             if (!ONES) {
 #pragma unroll
                 for (int u = 0; u < QT; ++u)
@@ -273,36 +309,39 @@ __global__ __launch_bounds__(256, 2) void attn_fused_kernel(AttnK p) {
     };
     using F = std::false_type;
     using T = std::true_type;
-    using B0 = std::integral_constant<int, 0>;
-    using B1 = std::integral_constant<int, 1>;
 
     const int nfull = p.Nk >> 6;
     const bool ragged = (p.Nk & 63) != 0;
-    auto handover = [&]() {
-        __builtin_amdgcn_s_waitcnt(0x0f70);              // vmcnt(0): this wave's part of the next tile has landed
-        __syncthreads();
+    const int nt = nfull + (ragged ? 1 : 0);
+    constexpr int PD = NST - 1;                          // prefetch distance in tiles
+    constexpr int KREM = (2 * KS) % 4;                   // waves >= KREM issue one K group less per tile
+    auto issue = [&](int tt, int buf_off) {
+        if (tt < nfull) issue_fast(buf_off);
+        else issue_slow(tt, buf_off);
     };
-    auto step = [&](auto buf_tag, int t) {               // full tile t sits in buffer BUF
-        constexpr int BUF = decltype(buf_tag)::value;
-        handover();
-        if (t + 1 < nfull) issue_fast((BUF ^ 1) * STAGE);
-        else if (ragged) issue_slow(t + 1, (BUF ^ 1) * STAGE);
-        tile(F{}, buf_tag, t);
+    // tile t has landed (this wave's part) when at most the loads of the `keep` later tiles are outstanding
+    auto wait_landed = [&](int keep) {
+        if (keep <= 0) __builtin_amdgcn_s_waitcnt(0x0f70);
+        else if (KREM != 0 && wv >= KREM) __builtin_amdgcn_s_waitcnt(0x0f70 | (NKG - 1 + DT));
+        else __builtin_amdgcn_s_waitcnt(0x0f70 | (NKG + DT));
     };
-    if (nfull > 0) issue_fast(0);
-    else issue_slow(0, 0);
+    static_assert(NKG + DT < 16 && NST <= 3, "vmcnt immediate / keep count");
+    auto step = [&](auto ragged_tag, const int buf, int t) {      // tile t sits in stage `buf`
+        wait_landed(nt - 1 - t < PD - 1 ? nt - 1 - t : PD - 1);
+        __syncthreads();                                  // tile t visible to all; everybody is done with tile t-1
+        if (t + PD < nt) issue(t + PD, ((buf + PD) % NST) * STAGE);
+        tile(ragged_tag, buf * STAGE, t);
+    };
+#pragma unroll
+    for (int i = 0; i < PD; ++i)
+        if (i < nt) issue(i, i * STAGE);
     int t = 0;
-    for (; t + 1 < nfull; t += 2) {
-        step(B0{}, t);
-        step(B1{}, t + 1);
+    for (; t + NST <= nfull; t += NST) {
+#pragma unroll
+        for (int i = 0; i < NST; ++i) step(F{}, i, t + i);
     }
-    if (t < nfull) {
-        step(B0{}, t);
-        if (ragged) { handover(); tile(T{}, B1{}, t + 1); }
-    } else if (ragged) {
-        handover();
-        tile(T{}, B0{}, t);
-    }
+    for (int i = 0; t < nfull; ++t, ++i) step(F{}, i, t);      // < NST leftover full tiles, stages 0, 1, ..
+    if (ragged) step(T{}, nfull % NST, nfull);
     // ---- normalise and store: lane holds 4 consecutive head-dim columns of query row q0 + 32u + lr ----
 #pragma unroll
     for (int u = 0; u < QT; ++u) {
@@ -328,17 +367,18 @@ __global__ __launch_bounds__(256, 2) void attn_fused_kernel(AttnK p) {
     }
 }
 
-template <int KS, int DT, int QT>
+template <int KS, int DT, int QT, int OCC = 2, int NST = 3>
 int launch_attn(AttnK k, hipStream_t st) {
-    constexpr int smem = 2 * (64 * 2 * KS * 16 + DT * 32 * 128);
+    constexpr int smem = NST * (64 * 2 * KS * 16 + DT * 32 * 128);
+    static_assert(smem * OCC <= 160 * 1024, "LDS ring x occupancy exceeds the CU's 160 KiB");
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fused_kernel<KS, DT, QT>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fused_kernel<KS, DT, QT, OCC, NST>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         attr_set = true;
     }
     k.nqt = (k.Nq + 128 * QT - 1) / (128 * QT);
-    hipLaunchKernelGGL((attn_fused_kernel<KS, DT, QT>), dim3(k.nqt * k.B * k.H), dim3(256), smem, st, k);
+    hipLaunchKernelGGL((attn_fused_kernel<KS, DT, QT, OCC, NST>), dim3(k.nqt * k.B * k.H), dim3(256), smem, st, k);
     ICD_CHECK_LAUNCH("icd_attention_fused");
     return ICD_OK;
 }
@@ -362,12 +402,12 @@ extern "C" int icd_attention_fused(const void* q, const void* k, const void* vt,
     hipStream_t st = (hipStream_t)stream;
     // two query tiles per wave when the sequence is long enough to still fill the chip with 256-row workgroups
     const bool wide = (long long)((Nq + 255) / 256) * B * H >= 512 && Nk >= 256;
-    if (d <= 16) return launch_attn<1, 1, 1>(a, st);
-    if (d <= 32) return launch_attn<2, 1, 1>(a, st);
-    if (d <= 48) return wide ? launch_attn<3, 2, 2>(a, st) : launch_attn<3, 2, 1>(a, st);
-    if (d <= 64) return launch_attn<4, 2, 1>(a, st);      // QT = 2 measured slower at d = 64 (256 VGPRs, spills)
-    if (d <= 80) return launch_attn<5, 3, 1>(a, st);
-    if (d <= 96) return launch_attn<6, 3, 1>(a, st);
-    if (d <= 128) return launch_attn<8, 4, 1>(a, st);
-    return launch_attn<10, 5, 1>(a, st);
+    if (d <= 16) return launch_attn<1, 1, 1, 2, 2>(a, st);
+    if (d <= 32) return launch_attn<2, 1, 1, 2, 2>(a, st);
+    if (d <= 48) return wide ? launch_attn<3, 2, 2, 2, 2>(a, st) : launch_attn<3, 2, 1, 2, 2>(a, st);
+    if (d <= 64) return launch_attn<4, 2, 1, 2, 2>(a, st);      // QT = 2 needs > 256 VGPRs at d = 64
+    if (d <= 80) return launch_attn<5, 3, 1, 2, 2>(a, st);
+    if (d <= 96) return launch_attn<6, 3, 1, 2, 2>(a, st);
+    if (d <= 128) return launch_attn<8, 4, 1, 2, 2>(a, st);
+    return launch_attn<10, 5, 1, 2, 2>(a, st);
 }

@@ -51,7 +51,9 @@ elif kind in ("dense", "geglu"):
 else:
     B, H, Nq, Nk, d = a
     q, k, v = rnd(B * Nq, H * d), rnd(B * Nk, H * d), rnd(B * Nk, H * d)
-    vt = v.reshape(B, Nk, H * d).transpose(1, 2).contiguous()
+    ldv = (Nk + 7) // 8 * 8
+    vt = torch.zeros(B, H * d, ldv, device=dev, dtype=torch.float16)
+    vt[:, :, :Nk] = v.reshape(B, Nk, H * d).transpose(1, 2)
     fn = lambda: ops.attention_fused(q, k, vt, B, H, Nq, Nk, d, d ** -0.5)
     flops = 4.0 * B * H * Nq * Nk * d
 # DBGFLAGS may be a comma-separated list: every entry is timed in this process (same box, same clocks)

@@ -27,12 +27,12 @@ __device__ __forceinline__ int swz_off(int row, int chunk) {        // byte offs
 // erf with |error| < 1.5e-7 (Abramowitz & Stegun 7.1.26): plenty for an fp16 result, ~4x cheaper than erff
 __device__ __forceinline__ float erf_fast(float x) {
     const float ax = fabsf(x);
-    const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));     // v_rcp_f32 (1 ulp); an IEEE divide is 10 instructions
     float p = fmaf(1.061405429f, t, -1.453152027f);
     p = fmaf(p, t, 1.421413741f);
     p = fmaf(p, t, -0.284496736f);
     p = fmaf(p, t, 0.254829592f);
-    const float y = 1.0f - p * t * __expf(-ax * ax);
+    const float y = 1.0f - p * t * __builtin_amdgcn_exp2f(-1.4426950408889634f * ax * ax);
     return copysignf(y, x);
 }
 __device__ __forceinline__ float gelu_fast(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752f)); }

@@ -44,14 +44,34 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+// Cross-lane reductions on the VALU (DPP within a row of 16 lanes, v_permlane{16,32}_swap across rows): no LDS round
+// trips.  group_* reduce aligned groups of W lanes (W = 4 .. 64); every lane of the group receives the result.
+__device__ __forceinline__ float dpp_mov(float v, int ctrl_quad_xor1_xor2_hmirror_mirror) {
+    switch (ctrl_quad_xor1_xor2_hmirror_mirror) {
+    case 0: return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
+    case 1: return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]
+    case 2: return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, false));  // row_half_mirror
+    default: return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, false)); // row_mirror
+    }
+}
+template <int W, typename Op>
+__device__ __forceinline__ float group_reduce(float v, Op op) {
+    v = op(v, dpp_mov(v, 0));
+    v = op(v, dpp_mov(v, 1));
+    if (W >= 8) v = op(v, dpp_mov(v, 2));
+    if (W >= 16) v = op(v, dpp_mov(v, 3));
+    if (W >= 32) {
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        v = op(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    }
+    if (W >= 64) {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        v = op(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    }
     return v;
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    return v;
-}
+template <int W> __device__ __forceinline__ float group_sum(float v) { return group_reduce<W>(v, [](float a, float b) { return a + b; }); }
+template <int W> __device__ __forceinline__ float group_max(float v) { return group_reduce<W>(v, [](float a, float b) { return fmaxf(a, b); }); }
+__device__ __forceinline__ float wave_sum(float v) { return group_sum<64>(v); }
+__device__ __forceinline__ float wave_max(float v) { return group_max<64>(v); }
 #endif

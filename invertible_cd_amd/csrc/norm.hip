@@ -8,9 +8,13 @@ namespace {
 
 constexpr int GN_THREADS = 512;
 
-__host__ __device__ inline int gn_pix_per_split(int HW) {
-    int p = (HW + 63) / 64;
-    return p < 64 ? 64 : p;
+// pixels per statistics block: about 1536 blocks per launch (6 per CU) but never fewer than 64 pixels per block
+__host__ __device__ inline int gn_pix_per_split(int B, int HW) {
+    int target = 1536 / (B > 0 ? B : 1);
+    if (target < 1) target = 1;
+    const int most = HW / 64 > 0 ? HW / 64 : 1;
+    const int nsplit = target < most ? target : most;
+    return (HW + nsplit - 1) / nsplit;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -89,17 +93,22 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const half_t* __re
     const int C = C0 + C1, nchunk = C >> 3;
     const int rpi = GN_THREADS / nchunk;
     const int tid = threadIdx.x, b = blockIdx.y;
-    if (tid < groups) {
+    {   // finish the statistics: 16 lanes per group walk the partials (fixed order -> reproducible), DPP tree on top
+        const int g = tid >> 4, j = tid & 15;
         float ss = 0.f, qq = 0.f;
-        for (int sp = 0; sp < nsplit; ++sp) {
-            const float* o = ws + (((long long)b * nsplit + sp) * groups + tid) * 2;
-            ss += o[0]; qq += o[1];
+        if (g < groups)
+            for (int sp = j; sp < nsplit; sp += 16) {
+                const float* o = ws + (((long long)b * nsplit + sp) * groups + g) * 2;
+                ss += o[0]; qq += o[1];
+            }
+        ss = group_sum<16>(ss); qq = group_sum<16>(qq);
+        if (g < groups && j == 0) {
+            const float n = (float)HW * (float)(C / groups);
+            const float mean = ss / n;
+            const float var = fmaxf(qq / n - mean * mean, 0.f);
+            s_mean[g] = mean;
+            s_rstd[g] = rsqrtf(var + eps);
         }
-        const float n = (float)HW * (float)(C / groups);
-        const float mean = ss / n;
-        const float var = fmaxf(qq / n - mean * mean, 0.f);
-        s_mean[tid] = mean;
-        s_rstd[tid] = rsqrtf(var + eps);
     }
     __syncthreads();
     const int chunk = tid % nchunk, rsub = tid / nchunk;
@@ -130,10 +139,10 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const half_t* __re
     };
     int p = p_begin + rsub;
     for (; p + 3 * rpi < p_end; p += 4 * rpi) {          // 4 loads in flight per thread
-        f16x8 v0 = *reinterpret_cast<const f16x8*>(base + (long long)p * cs);
-        f16x8 v1 = *reinterpret_cast<const f16x8*>(base + (long long)(p + rpi) * cs);
-        f16x8 v2 = *reinterpret_cast<const f16x8*>(base + (long long)(p + 2 * rpi) * cs);
-        f16x8 v3 = *reinterpret_cast<const f16x8*>(base + (long long)(p + 3 * rpi) * cs);
+        f16x8 v0 = __builtin_nontemporal_load(reinterpret_cast<const f16x8*>(base + (long long)p * cs));
+        f16x8 v1 = __builtin_nontemporal_load(reinterpret_cast<const f16x8*>(base + (long long)(p + rpi) * cs));
+        f16x8 v2 = __builtin_nontemporal_load(reinterpret_cast<const f16x8*>(base + (long long)(p + 2 * rpi) * cs));
+        f16x8 v3 = __builtin_nontemporal_load(reinterpret_cast<const f16x8*>(base + (long long)(p + 3 * rpi) * cs));
         *reinterpret_cast<f16x8*>(ob + (long long)p * C) = norm8(v0);
         *reinterpret_cast<f16x8*>(ob + (long long)(p + rpi) * C) = norm8(v1);
         *reinterpret_cast<f16x8*>(ob + (long long)(p + 2 * rpi) * C) = norm8(v2);
@@ -196,6 +205,83 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const half_t* __restrict
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// LayerNorm, several rows per wave: LPR lanes own one row (CPL 16-B chunks each), so all 64 lanes carry data at
+// C = 320 / 640 / 1280 (LPR = 8 / 16 / 32, CPL = 5); gamma / beta stay in registers for the LN_ITERS row groups a wave
+// walks through (re-reading them per row costs 4x the row's own bytes through L1), and the next group's loads are in
+// flight while the current one is reduced (DPP / permlane, no LDS).  Same exact two-pass arithmetic as above.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int LN_ITERS = 4;
+
+template <int LPR, int CPL>
+__global__ __launch_bounds__(256) void layernorm_multi_kernel(const half_t* __restrict__ x, long long rows, int C,
+                                                               const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, float eps,
+                                                               half_t* __restrict__ out) {
+    constexpr int RPW = 64 / LPR;
+    const int l = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int sub = l % LPR, rw = l / LPR;
+    const long long row0 = ((long long)blockIdx.x * 4 + wv) * (RPW * LN_ITERS) + rw;
+    f32x4 g[CPL][2], bt[CPL][2];
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) {
+        const int c = (sub + i * LPR) * 8;
+        g[i][0] = *reinterpret_cast<const f32x4*>(gamma + c); g[i][1] = *reinterpret_cast<const f32x4*>(gamma + c + 4);
+        bt[i][0] = *reinterpret_cast<const f32x4*>(beta + c); bt[i][1] = *reinterpret_cast<const f32x4*>(beta + c + 4);
+    }
+    const float invC = 1.0f / (float)C;
+    f16x8 v[2][CPL];
+    auto load = [&](int buf, long long row) {
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) {
+            if (row < rows) v[buf][i] = __builtin_nontemporal_load(reinterpret_cast<const f16x8*>(x + row * C + (sub + i * LPR) * 8));
+            else
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[buf][i][e] = (half_t)0.f;
+        }
+    };
+    load(0, row0);
+#pragma unroll
+    for (int it = 0; it < LN_ITERS; ++it) {
+        const long long row = row0 + (long long)it * RPW;
+        const int cur = it & 1;
+        if (it + 1 < LN_ITERS) load(cur ^ 1, row + RPW);
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < CPL; ++i)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sum += (float)v[cur][i][e];
+        const float mean = group_sum<LPR>(sum) * invC;
+        float sq = 0.f;
+#pragma unroll
+        for (int i = 0; i < CPL; ++i)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = (float)v[cur][i][e] - mean; sq += d * d; }
+        const float rstd = rsqrtf(group_sum<LPR>(sq) * invC + eps);
+        if (row < rows) {
+            half_t* orow = out + row * C;
+#pragma unroll
+            for (int i = 0; i < CPL; ++i) {
+                f16x8 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    o[e] = (half_t)(((float)v[cur][i][e] - mean) * rstd * g[i][0][e] + bt[i][0][e]);
+                    o[4 + e] = (half_t)(((float)v[cur][i][4 + e] - mean) * rstd * g[i][1][e] + bt[i][1][e]);
+                }
+                *reinterpret_cast<f16x8*>(orow + (sub + i * LPR) * 8) = o;
+            }
+        }
+    }
+}
+
+template <int LPR, int CPL>
+void launch_ln_multi(const half_t* x, long long rows, int C, const float* gamma, const float* beta, float eps, half_t* out,
+                     hipStream_t st) {
+    const long long rows_per_block = 4LL * (64 / LPR) * LN_ITERS;
+    hipLaunchKernelGGL((layernorm_multi_kernel<LPR, CPL>), dim3((unsigned)((rows + rows_per_block - 1) / rows_per_block)), dim3(256),
+                       0, st, x, rows, C, gamma, beta, eps, out);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Row softmax for the materialised-P path: fp32 scores -> fp16 probabilities, pad columns zeroed. One wave / row.
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ s, long long rows, int cols,
@@ -217,7 +303,7 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
 }  // namespace
 
 extern "C" int64_t icd_groupnorm_ws_floats(int32_t B, int32_t HW, int32_t groups) {
-    const int pps = gn_pix_per_split(HW);
+    const int pps = gn_pix_per_split(B, HW);
     const int nsplit = (HW + pps - 1) / pps;
     return (int64_t)B * nsplit * groups * 2;
 }
@@ -229,10 +315,10 @@ extern "C" int icd_groupnorm(const void* x0, int32_t C0, const void* x1, int32_t
     const int C = C0 + C1;
     ICD_CHECK_ARG(C0 > 0 && C0 % 8 == 0 && C1 >= 0 && C1 % 8 == 0, "icd_groupnorm: channels must be multiples of 8");
     ICD_CHECK_ARG((C1 == 0) == (x1 == nullptr), "icd_groupnorm: x1/C1 mismatch");
-    ICD_CHECK_ARG(groups > 0 && groups <= 64 && C % groups == 0, "icd_groupnorm: bad group count %d for C=%d", groups, C);
+    ICD_CHECK_ARG(groups > 0 && groups <= 32 && C % groups == 0, "icd_groupnorm: bad group count %d for C=%d", groups, C);
     ICD_CHECK_ARG(C / 8 <= GN_THREADS, "icd_groupnorm: C=%d too large", C);
     ICD_CHECK_ARG(B > 0 && HW > 0, "icd_groupnorm: empty input");
-    const int pps = gn_pix_per_split(HW);
+    const int pps = gn_pix_per_split(B, HW);
     const int nsplit = (HW + pps - 1) / pps;
     const int rpi = GN_THREADS / (C / 8);
     const size_t smem = (size_t)rpi * C * 2 * sizeof(float);
@@ -253,8 +339,17 @@ extern "C" int icd_layernorm(const void* x, int64_t rows, int32_t C, const float
     ICD_CHECK_ARG(x && out && gamma && beta, "icd_layernorm: null pointer");
     ICD_CHECK_ARG(C > 0 && C % 8 == 0 && C <= 2048, "icd_layernorm: C must be a multiple of 8 and <= 2048 (got %d)", C);
     ICD_CHECK_ARG(rows > 0, "icd_layernorm: empty input");
-    hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
-                       (const half_t*)x, (long long)rows, C, gamma, beta, eps, (half_t*)out);
+    hipStream_t st = (hipStream_t)stream;
+    const half_t* xh = (const half_t*)x;
+    half_t* oh = (half_t*)out;
+    const int nchunk = C / 8;
+    // widths with 5 chunks per lane group (C = 320 * 2^k) take the multi-row kernel; anything else the generic one
+    if (nchunk == 40) launch_ln_multi<8, 5>(xh, rows, C, gamma, beta, eps, oh, st);
+    else if (nchunk == 80) launch_ln_multi<16, 5>(xh, rows, C, gamma, beta, eps, oh, st);
+    else if (nchunk == 160) launch_ln_multi<32, 5>(xh, rows, C, gamma, beta, eps, oh, st);
+    else
+        hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, xh, (long long)rows, C, gamma,
+                           beta, eps, oh);
     ICD_CHECK_LAUNCH("icd_layernorm");
     return ICD_OK;
 }

@@ -48,6 +48,16 @@ elif kind in ("dense", "geglu"):
         _lib.check(_lib.load().icd_gemm(C.byref(d), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
         return out
     flops = 2.0 * M * N * K
+elif kind == "ln":
+    rows, Cc = a
+    x, gam, bet = rnd(rows, Cc), torch.ones(Cc, device=dev), torch.zeros(Cc, device=dev)
+    fn = lambda: ops.layernorm(x, gam, bet)
+    flops = 4.0 * rows * Cc * 1e3          # reported "TFLOP/s" column = GB/s (4 B per element)
+elif kind == "gn":
+    B, HW, Cc = a
+    x, gam, bet = rnd(B * HW, Cc), torch.ones(Cc, device=dev), torch.zeros(Cc, device=dev)
+    fn = lambda: ops.groupnorm(x, B, HW, gam, bet, 1e-5, True)
+    flops = 6.0 * B * HW * Cc * 1e3        # GB/s at 6 B per element
 else:
     B, H, Nq, Nk, d = a
     q, k, v = rnd(B * Nq, H * d), rnd(B * Nk, H * d), rnd(B * Nk, H * d)

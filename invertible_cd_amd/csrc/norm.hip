@@ -300,6 +300,46 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
     for (int c = l; c < ld_p; c += 64) pr[c] = c < cols ? (half_t)(__expf((sr[c] - mx) * scale) * inv) : (half_t)0.f;
 }
 
+// Row in registers: one global read of the fp32 scores, one exp per element, 16-B loads / 8-B stores.  NV = float4
+// vectors per lane (cols <= 256 * NV, ld_s % 4 == 0, ld_p % 4 == 0).
+template <int NV>
+__global__ __launch_bounds__(256) void softmax_rows_reg_kernel(const float* __restrict__ s, long long rows, int cols,
+                                                                int ld_s, float scale, half_t* __restrict__ p, int ld_p) {
+    const int l = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* sr = s + row * ld_s;
+    f32x4 v[NV];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (l + i * 64) * 4;
+        if (c < cols) v[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(sr + c));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (c + e >= cols) v[i][e] = -INFINITY;          // ragged tail / lanes past the row
+            mx = fmaxf(mx, v[i][e]);
+        }
+    }
+    mx = wave_max(mx);
+    const float k = scale * 1.4426950408889634f, nm = -mx * k;
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[i][e] = __builtin_amdgcn_exp2f(fmaf(v[i][e], k, nm)); sum += v[i][e]; }
+    const float inv = 1.0f / wave_sum(sum);
+    half_t* pr = p + row * ld_p;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (l + i * 64) * 4;
+        if (c < ld_p) {
+            f16x4 o = {(half_t)(v[i][0] * inv), (half_t)(v[i][1] * inv), (half_t)(v[i][2] * inv), (half_t)(v[i][3] * inv)};
+            *reinterpret_cast<f16x4*>(pr + c) = o;            // exp2(-inf) = 0 -> pad columns are written as zeros
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int64_t icd_groupnorm_ws_floats(int32_t B, int32_t HW, int32_t groups) {
@@ -358,8 +398,17 @@ extern "C" int icd_softmax_rows(const float* s, int64_t rows, int32_t cols, int3
                                 int32_t ld_p, void* stream) {
     ICD_CHECK_ARG(s && p, "icd_softmax_rows: null pointer");
     ICD_CHECK_ARG(rows > 0 && cols > 0 && ld_s >= cols && ld_p >= cols, "icd_softmax_rows: bad shape");
-    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, s,
-                       (long long)rows, cols, ld_s, scale, (half_t*)p, ld_p);
+    const dim3 grid((unsigned)((rows + 3) / 4));
+    hipStream_t st = (hipStream_t)stream;
+    const bool vec = ld_s % 4 == 0 && ld_p % 4 == 0 && ld_p <= ld_s + 3 && scale > 0.f;
+    if (vec && ld_p <= 256)
+        hipLaunchKernelGGL(softmax_rows_reg_kernel<1>, grid, dim3(256), 0, st, s, (long long)rows, cols, ld_s, scale, (half_t*)p, ld_p);
+    else if (vec && ld_p <= 1024)
+        hipLaunchKernelGGL(softmax_rows_reg_kernel<4>, grid, dim3(256), 0, st, s, (long long)rows, cols, ld_s, scale, (half_t*)p, ld_p);
+    else if (vec && ld_p <= 4096)
+        hipLaunchKernelGGL(softmax_rows_reg_kernel<16>, grid, dim3(256), 0, st, s, (long long)rows, cols, ld_s, scale, (half_t*)p, ld_p);
+    else
+        hipLaunchKernelGGL(softmax_rows_kernel, grid, dim3(256), 0, st, s, (long long)rows, cols, ld_s, scale, (half_t*)p, ld_p);
     ICD_CHECK_LAUNCH("icd_softmax_rows");
     return ICD_OK;
 }

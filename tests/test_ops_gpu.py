@@ -218,13 +218,17 @@ def test_layernorm(rows, C):
     assert rel_l2(out, F.layer_norm(x.float(), (C,), g, b, 1e-5)) < TOL
 
 
-def test_softmax_rows():
+@pytest.mark.parametrize("rows,cols,ld,scale", [(37, 77, 80, 1.0), (130, 256, 256, 0.158), (65, 1024, 1024, 0.158),
+                                                 (19, 1000, 1024, 0.5), (9, 4096, 4096, 0.158), (5, 77, 78, 1.0)])
+def test_softmax_rows(rows, cols, ld, scale):
+    """fp32 scores -> fp16 probabilities; every register-resident width, the ragged tail and the generic fallback (ld % 4)."""
     ops = _ops()
-    s = torch.randn(37, 80, generator=torch.Generator().manual_seed(27)) * 3
-    p = ops.softmax_rows(s.cuda(), 77, 80, scale=1.0)
-    ref = torch.softmax(s[:, :77], -1)
-    assert rel_l2(p[:, :77], ref) < TOL
-    assert float(p[:, 77:].abs().max()) == 0.0
+    s = torch.randn(rows, ld, generator=torch.Generator().manual_seed(27)) * 3
+    p = ops.softmax_rows(s.cuda(), cols, ld, scale=scale)
+    ref = torch.softmax(s[:, :cols] * scale, -1)
+    assert rel_l2(p[:, :cols], ref) < TOL
+    if ld > cols:
+        assert float(p[:, cols:].abs().max()) == 0.0
 
 
 def _attn_ref(q, k, v, B, H, Nq, Nk, d):

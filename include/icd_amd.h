@@ -50,6 +50,8 @@ int icd_version(void);
 #define ICD_GEMM_GEGLU      1   /* out[m, j] = h * gelu_erf(g); weights/bias pre-interleaved in 32-column groups  */
 #define ICD_GEMM_OUT_F32    2   /* out is float (attention scores before softmax)                                   */
 #define ICD_GEMM_OUT_TRANS  4   /* out[(b*N + n)*ldo + (m % rows_per_sample)], b = m / rows_per_sample  (V^T)      */
+#define ICD_GEMM_PAD_HI     8   /* conv: zero padding on the bottom / right edge only (AutoencoderKL Downsample2D:  */
+                                /* F.pad(x, (0,1,0,1)) + conv3x3 stride 2 pad 0), instead of ksize/2 on every side   */
 
 /* out = alpha * (A (*) W^T) + bias[n] + rowbias[m / rows_per_sample][n] + resid[m][n]
  * A is either a dense row-major [M, K] matrix (mode 0; Linear, 1x1 conv, attention bmm) or the implicit im2col
@@ -128,9 +130,20 @@ int icd_conv_in(const void* x_nchw, int32_t x_is_f32, int32_t B, int32_t H, int3
  * implicit GEMM (icd_gemm mode 1, C0 = 8, K = 72, weights [Cout, 3,3,8]) on the matrix cores - what the executor does. */
 int icd_pack_latent(const void* x_nchw, int32_t x_is_f32, int32_t B, int32_t HW, void* out, void* stream);
 
+/* General form of icd_pack_latent: NCHW [B,C,HW], C <= 8 -> [B*HW, 8] fp16; padding channels are zero except
+ * `ones_channel` (>= C, or -1 for none), which is 1.0 inside the image.  The VAE decoder uses it to fold
+ * post_quant_conv (1x1, with bias) into conv_in exactly: the bias rides on the ones channel, so the zero padding of
+ * the 3x3 conv still sees zeros outside the image (utils/generation.py:258 vae.decode). */
+int icd_pack_nchw(const void* x_nchw, int32_t x_is_f32, int32_t B, int32_t C, int32_t HW, int32_t ones_channel, void* out,
+                  void* stream);
+
 /* conv_out: 3x3 pad 1 over NHWC fp16 [B,H*W,Cin] -> NCHW eps [B,4,H,W] (fp16 or fp32).  w: fp16 [4, 3,3,Cin]. */
 int icd_conv_out(const void* x, int32_t B, int32_t H, int32_t W, int32_t Cin, const void* w, const float* bias,
                  void* eps_nchw, int32_t out_is_f32, void* stream);
+/* Same with Cout = 1..4 output channels, result NCHW [B,Cout,H,W]; w stays [4, 3,3,Cin] (rows >= Cout ignored).
+ * AutoencoderKL decoder.conv_out (128 -> 3) and encoder.conv_out + quant_conv folded to the 4 mean channels. */
+int icd_conv_out_n(const void* x, int32_t B, int32_t H, int32_t W, int32_t Cin, const void* w, const float* bias,
+                   int32_t Cout, void* out_nchw, int32_t out_is_f32, void* stream);
 
 /* Consistency boundary step, eps-prediction (utils/generation.py:136-155 == utils/generation_sdxl.py:112-132):
  *   x0 = (x - sigma_t*eps)/alpha_t ; out = alpha_s*x0 + sigma_s*eps, (alpha_s, sigma_s) := (1, 0) where s == 0.

@@ -12,6 +12,7 @@ LIB_PATH = os.environ.get("ICD_AMD_LIB") or os.path.join(_HERE, "lib", "libicd_a
 ICD_GEMM_GEGLU = 1
 ICD_GEMM_OUT_F32 = 2
 ICD_GEMM_OUT_TRANS = 4
+ICD_GEMM_PAD_HI = 8
 ICD_HOOK_QUERY = 0
 ICD_HOOK_PROBS = 1
 
@@ -98,6 +99,9 @@ SIGNATURES = {
     "icd_unet_num_attention_layers": (C.c_int32, [C.c_void_p]),
     "icd_unet_workspace_bytes": (C.c_int64, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "icd_unet_forward": (C.c_int, [C.c_void_p, C.POINTER(UNetIO), C.c_void_p]),
+    "icd_pack_nchw": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "icd_conv_out_n": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
+                                 C.c_void_p, C.c_int32, C.c_void_p]),
     "icd_profile_enable": (C.c_int, [C.c_int32]),
     "icd_profile_read": (C.c_int, [C.POINTER(ProfileRow), C.c_int32]),
     "icd_profile_dump": (C.c_int, [C.POINTER(ProfileRecord), C.c_int32]),

@@ -79,36 +79,39 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const TIn* __restrict__ x,
 // NCHW [B,4,H,W] latents -> token-major [B*H*W, 8] fp16 (channels 4..7 zero) so that conv_in can run on the MFMA
 // implicit-GEMM path (K = 9 * 8 = 72).
 template <typename TIn>
-__global__ void pack_latent_kernel(const TIn* __restrict__ x, int B, int HW, half_t* __restrict__ out) {
+__global__ void pack_latent_kernel(const TIn* __restrict__ x, int B, int C, int HW, int ones_ch, half_t* __restrict__ out) {
     const long long pix = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (pix >= (long long)B * HW) return;
     const int b = (int)(pix / HW), r = (int)(pix - (long long)b * HW);
     f16x8 o;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) o[c] = (half_t)(float)x[((long long)b * 4 + c) * HW + r];
-#pragma unroll
-    for (int c = 4; c < 8; ++c) o[c] = (half_t)0.f;
+    for (int c = 0; c < 8; ++c)
+        o[c] = c < C ? (half_t)(float)x[((long long)b * C + c) * HW + r] : (half_t)(c == ones_ch ? 1.f : 0.f);
     *reinterpret_cast<f16x8*>(out + pix * 8) = o;
 }
 
-// conv_out: one wave per output pixel; lanes stride over 8-channel chunks; 4 output channels.  w: [4][3][3][Cin].
-template <typename TOut>
+// conv_out: LPP lanes per output pixel (64 / LPP pixels per wave) stride over 8-channel chunks; up to 4 output
+// channels, NCHW result.  w: [4][3][3][Cin] (rows >= Cout are ignored).  LPP = 64 for the UNet's 320 input channels,
+// 16 for the VAE decoder's 128 (a full wave per pixel would leave 48 lanes idle on 512 x 512 images).
+template <typename TOut, int LPP>
 __global__ __launch_bounds__(256) void conv_out_kernel(const half_t* __restrict__ x, int B, int H, int W, int Cin,
                                                         const half_t* __restrict__ w, const float* __restrict__ bias,
-                                                        TOut* __restrict__ eps) {
-    const int l = threadIdx.x & 63;
-    const long long pix = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+                                                        int Cout, TOut* __restrict__ eps) {
+    constexpr int PPW = 64 / LPP;
+    const int l = threadIdx.x & 63, sub = l % LPP;
+    const long long pix = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * PPW + l / LPP;
     const int HW = H * W;
-    if (pix >= (long long)B * HW) return;
-    const int b = (int)(pix / HW), rem = (int)(pix - (long long)b * HW);
+    const bool live = pix < (long long)B * HW;
+    const long long pc = live ? pix : 0;
+    const int b = (int)(pc / HW), rem = (int)(pc - (long long)b * HW);
     const int y = rem / W, xx = rem - y * W;
     const int nch = Cin >> 3;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     for (int t = 0; t < 9; ++t) {
         const int yy = y + t / 3 - 1, xc = xx + t % 3 - 1;
-        if ((unsigned)yy >= (unsigned)H || (unsigned)xc >= (unsigned)W) continue;   // wave-uniform
+        if (!live || (unsigned)yy >= (unsigned)H || (unsigned)xc >= (unsigned)W) continue;
         const half_t* xp = x + ((long long)b * HW + yy * W + xc) * Cin;
-        for (int c = l; c < nch; c += 64) {
+        for (int c = sub; c < nch; c += LPP) {
             f16x8 v = *reinterpret_cast<const f16x8*>(xp + c * 8);
 #pragma unroll
             for (int o = 0; o < 4; ++o) {
@@ -119,10 +122,10 @@ __global__ __launch_bounds__(256) void conv_out_kernel(const half_t* __restrict_
         }
     }
 #pragma unroll
-    for (int o = 0; o < 4; ++o) acc[o] = wave_sum(acc[o]);
-    if (l < 4) {
-        const float v = (l == 0 ? acc[0] : l == 1 ? acc[1] : l == 2 ? acc[2] : acc[3]) + (bias ? bias[l] : 0.f);
-        eps[((long long)(b * 4 + l) * H + y) * W + xx] = (TOut)v;
+    for (int o = 0; o < 4; ++o) acc[o] = group_sum<LPP>(acc[o]);
+    if (live && sub < Cout) {
+        const float v = (sub == 0 ? acc[0] : sub == 1 ? acc[1] : sub == 2 ? acc[2] : acc[3]) + (bias ? bias[sub] : 0.f);
+        eps[((long long)(b * Cout + sub) * H + y) * W + xx] = (TOut)v;
     }
 }
 
@@ -183,32 +186,50 @@ extern "C" int icd_conv_in(const void* x_nchw, int32_t x_is_f32, int32_t B, int3
     return ICD_OK;
 }
 
-extern "C" int icd_pack_latent(const void* x_nchw, int32_t x_is_f32, int32_t B, int32_t HW, void* out, void* stream) {
-    ICD_CHECK_ARG(x_nchw && out && B > 0 && HW > 0, "icd_pack_latent: bad arguments");
+extern "C" int icd_pack_nchw(const void* x_nchw, int32_t x_is_f32, int32_t B, int32_t C, int32_t HW, int32_t ones_channel,
+                             void* out, void* stream) {
+    ICD_CHECK_ARG(x_nchw && out && B > 0 && HW > 0, "icd_pack_nchw: bad arguments");
+    ICD_CHECK_ARG(C > 0 && C <= 8 && ones_channel < 8 && (ones_channel < 0 || ones_channel >= C),
+                  "icd_pack_nchw: C must be 1..8 and the ones channel one of the padding channels (C=%d, ones=%d)", C, ones_channel);
     const long long pixels = (long long)B * HW;
     dim3 grid((unsigned)((pixels + 255) / 256));
     if (x_is_f32)
-        hipLaunchKernelGGL(pack_latent_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x_nchw, B, HW, (half_t*)out);
+        hipLaunchKernelGGL(pack_latent_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x_nchw, B, C, HW,
+                           ones_channel, (half_t*)out);
     else
-        hipLaunchKernelGGL(pack_latent_kernel<half_t>, grid, dim3(256), 0, (hipStream_t)stream, (const half_t*)x_nchw, B, HW, (half_t*)out);
-    ICD_CHECK_LAUNCH("icd_pack_latent");
+        hipLaunchKernelGGL(pack_latent_kernel<half_t>, grid, dim3(256), 0, (hipStream_t)stream, (const half_t*)x_nchw, B, C, HW,
+                           ones_channel, (half_t*)out);
+    ICD_CHECK_LAUNCH("icd_pack_nchw");
+    return ICD_OK;
+}
+
+extern "C" int icd_pack_latent(const void* x_nchw, int32_t x_is_f32, int32_t B, int32_t HW, void* out, void* stream) {
+    return icd_pack_nchw(x_nchw, x_is_f32, B, 4, HW, -1, out, stream);
+}
+
+extern "C" int icd_conv_out_n(const void* x, int32_t B, int32_t H, int32_t W, int32_t Cin, const void* w, const float* bias,
+                              int32_t Cout, void* out_nchw, int32_t out_is_f32, void* stream) {
+    ICD_CHECK_ARG(x && w && out_nchw, "icd_conv_out: null pointer");
+    ICD_CHECK_ARG(B > 0 && H > 0 && W > 0 && Cin > 0 && Cin % 8 == 0, "icd_conv_out: bad shape");
+    ICD_CHECK_ARG(Cout >= 1 && Cout <= 4, "icd_conv_out: Cout must be 1..4 (got %d)", Cout);
+    const long long pixels = (long long)B * H * W;
+    hipStream_t st = (hipStream_t)stream;
+    const int nch = Cin / 8;
+#define CO_LAUNCH(T, LPP)                                                                                              \
+    hipLaunchKernelGGL((conv_out_kernel<T, LPP>), dim3((unsigned)((pixels + 4 * (64 / LPP) - 1) / (4 * (64 / LPP)))),  \
+                       dim3(256), 0, st, (const half_t*)x, B, H, W, Cin, (const half_t*)w, bias, Cout, (T*)out_nchw)
+    if (nch <= 8) { if (out_is_f32) CO_LAUNCH(float, 8); else CO_LAUNCH(half_t, 8); }
+    else if (nch <= 16) { if (out_is_f32) CO_LAUNCH(float, 16); else CO_LAUNCH(half_t, 16); }
+    else if (nch <= 32) { if (out_is_f32) CO_LAUNCH(float, 32); else CO_LAUNCH(half_t, 32); }
+    else { if (out_is_f32) CO_LAUNCH(float, 64); else CO_LAUNCH(half_t, 64); }
+#undef CO_LAUNCH
+    ICD_CHECK_LAUNCH("icd_conv_out");
     return ICD_OK;
 }
 
 extern "C" int icd_conv_out(const void* x, int32_t B, int32_t H, int32_t W, int32_t Cin, const void* w,
                             const float* bias, void* eps_nchw, int32_t out_is_f32, void* stream) {
-    ICD_CHECK_ARG(x && w && eps_nchw, "icd_conv_out: null pointer");
-    ICD_CHECK_ARG(B > 0 && H > 0 && W > 0 && Cin > 0 && Cin % 8 == 0, "icd_conv_out: bad shape");
-    const long long pixels = (long long)B * H * W;
-    dim3 grid((unsigned)((pixels + 3) / 4));
-    if (out_is_f32)
-        hipLaunchKernelGGL(conv_out_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const half_t*)x, B, H, W, Cin,
-                           (const half_t*)w, bias, (float*)eps_nchw);
-    else
-        hipLaunchKernelGGL(conv_out_kernel<half_t>, grid, dim3(256), 0, (hipStream_t)stream, (const half_t*)x, B, H, W, Cin,
-                           (const half_t*)w, bias, (half_t*)eps_nchw);
-    ICD_CHECK_LAUNCH("icd_conv_out");
-    return ICD_OK;
+    return icd_conv_out_n(x, B, H, W, Cin, w, bias, 4, eps_nchw, out_is_f32, stream);
 }
 
 extern "C" int icd_x0_step(const void* x, const void* eps, const float* coef, int32_t B, int64_t per_sample,

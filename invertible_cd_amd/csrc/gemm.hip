@@ -74,7 +74,7 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_kernel(GemmK p) {
     // the steady-state loader is one 64-bit add per chunk, no selects.
     const int lrow = l >> 3, pchunk = l & 7;
     const int Cin = p.C0 + p.C1;
-    const int ntaps = p.ksize * p.ksize, pad = p.ksize >> 1;
+    const int ntaps = p.ksize * p.ksize, pad = (p.flags & ICD_GEMM_PAD_HI) ? 0 : p.ksize >> 1;
     const int Hu = p.Hin << p.upsample, Wu = p.Win << p.upsample;
     const bool ktail = (p.K & 63) != 0;
 

@@ -47,7 +47,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_big_kernel(GemmK p) {
     // ---- loader state (see gemm.hip: biased pointers, zero-page parking, one M0 per group of 4 chunks) ----------
     const int lrow = l >> 3, pchunk = l & 7;
     const int Cin = p.C0 + p.C1;
-    const int ntaps = p.ksize * p.ksize, pad = p.ksize >> 1;
+    const int ntaps = p.ksize * p.ksize, pad = (p.flags & ICD_GEMM_PAD_HI) ? 0 : p.ksize >> 1;
     const int Hu = p.Hin << p.upsample, Wu = p.Win << p.upsample;
     const int k_begin = kt_begin * BK;
 

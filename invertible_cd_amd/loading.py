@@ -96,10 +96,18 @@ def _load_unet_state(model_id, cfg, teacher_checkpoint):
     return sd
 
 
+def _build_vae(comp, cfg, device, dtype):
+    """components['vae_state_dict'] (diffusers AutoencoderKL layout) -> the HIP AutoencoderKL of this package."""
+    if "vae" not in comp and comp.get("vae_state_dict") is not None:
+        from .vae import AutoencoderKL
+        comp["vae"] = AutoencoderKL(cfg, comp["vae_state_dict"], device=device, dtype=dtype)
+
+
 def load_models(model_id, device, reverse_checkpoint, forward_checkpoint, r=64, w_embed_dim=0, teacher_checkpoint=None,
                 dtype='fp32', components=None):
     """SD1.5: (ldm_stable, reverse_cons_model, forward_cons_model).  `components` may supply real
-    {'vae','tokenizer','text_encoder'} objects; otherwise labelled synthetic stand-ins are attached."""
+    {'vae','tokenizer','text_encoder'} objects or 'vae_state_dict' (AutoencoderKL weights, run on the HIP kernels);
+    otherwise labelled synthetic stand-ins are attached."""
     tdtype = torch.float32 if dtype == 'fp32' else torch.float16
     cfg = dataclasses.replace(SD15, time_cond_proj_dim=int(w_embed_dim))
     if w_embed_dim > 0:
@@ -107,6 +115,8 @@ def load_models(model_id, device, reverse_checkpoint, forward_checkpoint, r=64, 
     comp = dict(components or {})
     comp.setdefault("tokenizer", SyntheticTokenizer())
     comp.setdefault("text_encoder", SyntheticTextEncoder(cfg.cross_dim, device))
+    from .vae import SD_VAE
+    _build_vae(comp, SD_VAE, device, tdtype)
     comp.setdefault("vae", SyntheticVAE(device))
     base_sd = _load_unet_state(model_id, cfg, teacher_checkpoint)
 
@@ -130,6 +140,8 @@ def load_models_xl(model_id, reverse_checkpoint, forward_checkpoint, teacher_che
     """SDXL: (stable_pipe, pipe, forw_pipe); fp16 UNets, LoRA fused in fp32 (utils/loading.py:122,141)."""
     cfg = SDXL
     comp = dict(components or {})
+    from .vae import SDXL_VAE
+    _build_vae(comp, SDXL_VAE, device, torch.float16)
     base_sd = _load_unet_state(model_id, cfg, teacher_checkpoint)
 
     def pipeline(sd, cls):

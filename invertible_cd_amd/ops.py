@@ -8,7 +8,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import GemmDesc, ICD_GEMM_GEGLU, ICD_GEMM_OUT_F32, ICD_GEMM_OUT_TRANS
+from ._lib import GemmDesc, ICD_GEMM_GEGLU, ICD_GEMM_OUT_F32, ICD_GEMM_OUT_TRANS, ICD_GEMM_PAD_HI
 
 
 def _stream():
@@ -24,6 +24,12 @@ def _chk16(t, name):
 
 
 # ------------------------------------------------------------------------------------------------ packing helpers
+def _chk_rows(t, name):
+    """2-D fp16 operand that may be a column slice of a wider matrix (q / k halves of a fused projection)."""
+    assert t.is_cuda and t.dtype == torch.float16 and t.dim() == 2 and t.stride(1) == 1 and t.stride(0) % 8 == 0 \
+        and t.data_ptr() % 16 == 0, f"{name}: need a row-major cuda fp16 matrix with 16-byte aligned rows"
+
+
 def pack_conv_weight(w_oihw):
     """[O, I, kh, kw] -> [O, kh*kw*I] fp16 (tap-major, channel-minor: the K order of the implicit GEMM)."""
     o = w_oihw.shape[0]
@@ -80,8 +86,9 @@ def gemm(a, w, bias=None, resid=None, rowbias=None, rows_per_sample=0, geglu=Fal
 
 
 def conv3x3(x, B, H, W, w_packed, bias=None, x2=None, stride=1, upsample=False, resid=None, rowbias=None, ksize=3,
-            debug_flags=0):
-    """Implicit-GEMM conv over NHWC x [B*H*W, C0] (optionally cat with x2 [.., C1]); returns [B*Ho*Wo, Cout]."""
+            debug_flags=0, pad_hi=False):
+    """Implicit-GEMM conv over NHWC x [B*H*W, C0] (optionally cat with x2 [.., C1]); returns [B*Ho*Wo, Cout].
+    pad_hi: zero padding on the bottom/right edge only (AutoencoderKL Downsample2D)."""
     _chk16(x, "x"); _chk16(w_packed, "w")
     C0 = x.shape[-1]
     C1 = x2.shape[-1] if x2 is not None else 0
@@ -101,7 +108,7 @@ def conv3x3(x, B, H, W, w_packed, bias=None, x2=None, stride=1, upsample=False, 
     d.rows_per_sample = Ho * Wo
     d.mode, d.C0, d.C1 = 1, C0, C1
     d.Hin, d.Win, d.Hout, d.Wout, d.ksize, d.stride, d.upsample = H, W, Ho, Wo, ksize, stride, int(upsample)
-    d.batch, d.zdiv, d.alpha, d.flags = 1, 1, 1.0, debug_flags
+    d.batch, d.zdiv, d.alpha, d.flags = 1, 1, 1.0, debug_flags | (ICD_GEMM_PAD_HI if pad_hi else 0)
     ws = _splitk_ws(d, x.device)
     _lib.check(_lib.load().icd_gemm(C.byref(d), _stream()), "icd_gemm(conv)")
     return out
@@ -153,8 +160,8 @@ def project_vt(x, w, B, n_tokens, ld_keys):
 
 def attention_fused(q, k, vt, B, H, Nq, Nk, d, scale):
     """q [B*Nq, H*d], k [B*Nk, H*d], vt [B, H*d, ld] -> out [B*Nq, H*d]."""
-    _chk16(q, "q"); _chk16(k, "k"); _chk16(vt, "vt")
-    out = torch.empty_like(q)
+    _chk_rows(q, "q"); _chk_rows(k, "k"); _chk16(vt, "vt")
+    out = torch.empty((q.shape[0], q.shape[1]), device=q.device, dtype=torch.float16)
     _lib.check(_lib.load().icd_attention_fused(_p(q), _p(k), _p(vt), _p(out), B, H, Nq, Nk, d, q.stride(0), k.stride(0),
                                                vt.stride(1), out.stride(0), vt.stride(0), scale, _stream()),
                "icd_attention_fused")
@@ -219,12 +226,23 @@ def conv_in(x_nchw, w_packed, bias):
     return out
 
 
-def conv_out(x, B, H, W, w_packed, bias, out_dtype=torch.float16):
+def conv_out(x, B, H, W, w_packed, bias, out_dtype=torch.float16, cout=4):
+    """3x3 pad-1 conv NHWC [B*H*W, Cin] -> NCHW [B, cout, H, W], cout <= 4; w_packed [4, 9*Cin]."""
     _chk16(x, "x")
-    eps = torch.empty((B, 4, H, W), device=x.device, dtype=out_dtype)
-    _lib.check(_lib.load().icd_conv_out(_p(x), B, H, W, x.shape[-1], _p(w_packed), _p(bias), _p(eps),
-                                        int(out_dtype == torch.float32), _stream()), "icd_conv_out")
+    eps = torch.empty((B, cout, H, W), device=x.device, dtype=out_dtype)
+    _lib.check(_lib.load().icd_conv_out_n(_p(x), B, H, W, x.shape[-1], _p(w_packed), _p(bias), cout, _p(eps),
+                                          int(out_dtype == torch.float32), _stream()), "icd_conv_out")
     return eps
+
+
+def pack_nchw(x_nchw, ones_channel=-1):
+    """NCHW [B, C<=8, H, W] (fp16/fp32) -> token-major [B*H*W, 8] fp16; padding channels zero, `ones_channel` = 1."""
+    B, Cc, H, W = x_nchw.shape
+    assert x_nchw.is_contiguous() and x_nchw.dtype in (torch.float16, torch.float32)
+    out = torch.empty((B * H * W, 8), device=x_nchw.device, dtype=torch.float16)
+    _lib.check(_lib.load().icd_pack_nchw(_p(x_nchw), int(x_nchw.dtype == torch.float32), B, Cc, H * W, ones_channel, _p(out),
+                                         _stream()), "icd_pack_nchw")
+    return out
 
 
 def x0_step(x, eps, coef, out_dtype=None):

@@ -39,6 +39,25 @@ def synthetic_state_dict(cfg: UNetConfig, seed: int = 0, device="cpu", dtype=tor
     return sd
 
 
+def synthetic_vae_state_dict(cfg, seed: int = 0, device="cpu", dtype=torch.float32):
+    """Seeded AutoencoderKL weights (vae.VAEConfig.state_dict_shapes layout), same recipe as the UNet's."""
+    sd = {}
+    for key, shape in cfg.state_dict_shapes().items():
+        g = _gen("vae:" + key, seed, device)
+        if key.endswith(".bias"):
+            t = 0.05 * torch.randn(shape, generator=g, device=device)
+        elif "norm" in key:
+            t = 1.0 + 0.1 * torch.randn(shape, generator=g, device=device)
+        else:
+            fan_in = 1
+            for d in shape[1:]:
+                fan_in *= d
+            gain = 0.5 if key.endswith((".conv2.weight", ".to_out.0.weight")) else 1.0
+            t = torch.randn(shape, generator=g, device=device) * (gain / fan_in ** 0.5)
+        sd[key] = t.to(dtype)
+    return sd
+
+
 def synthetic_lora(cfg: UNetConfig, seed: int = 1, rank: int = 64, device="cpu", scale: float = 0.5):
     """{module path: (down [r, in(,k,k)], up [out, r(,1,1)])} for every LoRA target of the iCD students."""
     lora = {}

@@ -141,3 +141,60 @@ def test_fuse_lora_matches_definition():
     assert torch.allclose(out["l.weight"], ref, atol=1e-6)
     conv_delta = torch.einsum("or,rikl->oikl", lora["m"][1][:, :, 0, 0], lora["m"][0])
     assert torch.allclose(out["m.weight"], W["m.weight"] + 4.0 * conv_delta, atol=1e-5)
+
+
+def test_vae_oracle_architecture_pins():
+    """AutoencoderKL restatement: exact parameter count of the SD VAE, key layout shared with the product module."""
+    import torch
+    from oracle import vae_ref
+    from invertible_cd_amd.vae import SD_VAE, SDXL_VAE
+    assert vae_ref.count_params(vae_ref.SD_VAE) == 83_653_863
+    shapes = vae_ref.param_shapes(vae_ref.SD_VAE)
+    assert len(shapes) == 248
+    assert {k: tuple(v) for k, v in SD_VAE.state_dict_shapes().items()} == {k: tuple(v) for k, v in shapes.items()}
+    assert SDXL_VAE.scaling_factor == vae_ref.SDXL_VAE["scaling_factor"] == 0.13025
+    assert shapes["encoder.down_blocks.1.resnets.0.conv_shortcut.weight"] == (256, 128, 1, 1)
+    assert shapes["decoder.up_blocks.2.resnets.0.conv_shortcut.weight"] == (256, 512, 1, 1)
+    assert "encoder.down_blocks.3.downsamplers.0.conv.weight" not in shapes
+    assert "decoder.up_blocks.3.upsamplers.0.conv.weight" not in shapes
+    # runs end to end at reduced width; encode halves the resolution three times, decode doubles it three times
+    cfg = dict(vae_ref.SD_VAE, block_out_channels=(32, 32, 64, 64))
+    g = torch.Generator().manual_seed(0)
+    w = {k: torch.randn(s, generator=g) * 0.05 for k, s in vae_ref.param_shapes(cfg).items()}
+    img = vae_ref.decode(w, cfg, torch.randn(1, 4, 4, 6, generator=g))
+    assert img.shape == (1, 3, 32, 48)
+    assert vae_ref.encode_mean(w, cfg, img).shape == (1, 4, 4, 6)
+    # the asymmetric Downsample2D padding: bottom/right only
+    x = torch.zeros(1, 32, 4, 4); x[0, 0, 0, 0] = 1.0
+    wd = torch.zeros(32, 32, 3, 3); wd[0, 0, 0, 0] = 1.0
+    y = torch.nn.functional.conv2d(torch.nn.functional.pad(x, (0, 1, 0, 1)), wd, stride=2)
+    assert y[0, 0, 0, 0] == 1.0 and y.shape[-1] == 2
+
+
+def test_vae_host_algebra_folds_are_exact():
+    """pack_vae_state_dict folds post_quant_conv into conv_in (bias on a ones channel), quant_conv into conv_out (mean rows)
+    and the V bias into the output projection - checked against the oracle's unfused arithmetic in fp64 on CPU."""
+    import torch
+    from oracle import vae_ref
+    from invertible_cd_amd import synthetic
+    from invertible_cd_amd.vae import SD_VAE, pack_vae_state_dict
+    F = torch.nn.functional
+    cfg = SD_VAE.scaled((32, 32, 64, 64))
+    sd = synthetic.synthetic_vae_state_dict(cfg, seed=11)
+    P = pack_vae_state_dict(cfg, sd, device="cpu")
+    g = torch.Generator().manual_seed(1)
+    z = torch.randn(2, 4, 5, 7, generator=g, dtype=torch.float64)
+    ref = F.conv2d(F.conv2d(z, sd["post_quant_conv.weight"].double(), sd["post_quant_conv.bias"].double()),
+                   sd["decoder.conv_in.weight"].double(), sd["decoder.conv_in.bias"].double(), padding=1)
+    z8 = torch.zeros(2, 8, 5, 7, dtype=torch.float64); z8[:, :4] = z; z8[:, 4] = 1.0
+    w8 = P["decoder.conv_in.weight"].double().reshape(-1, 3, 3, 8).permute(0, 3, 1, 2)
+    got = F.conv2d(z8, w8, P["decoder.conv_in.bias"].double(), padding=1)
+    assert float((got - ref).abs().max()) < 2e-3                       # only the fp16 rounding of the packed weights
+    h = torch.randn(2, 64, 5, 7, generator=g, dtype=torch.float64)
+    mom = F.conv2d(F.conv2d(h, sd["encoder.conv_out.weight"].double(), sd["encoder.conv_out.bias"].double(), padding=1),
+                   sd["quant_conv.weight"].double(), sd["quant_conv.bias"].double())[:, :4]
+    w4 = P["encoder.conv_out_mean.weight"].double().reshape(4, 3, 3, 64).permute(0, 3, 1, 2)
+    assert float((F.conv2d(h, w4, P["encoder.conv_out_mean.bias"].double(), padding=1) - mom).abs().max()) < 2e-3
+    a = "decoder.mid_block.attentions.0."
+    fused = sd[a + "to_out.0.weight"].double() @ sd[a + "to_v.bias"].double() + sd[a + "to_out.0.bias"].double()
+    assert float((P[a + "to_out.bias"].double() - fused).abs().max()) < 1e-6

@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--arch", default="sd15", choices=["sd15", "sdxl"])
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default 32 for sd15, 8 for sdxl)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-vae", action="store_true", help="skip the separate VAE-decode leg (SURVEY section 8f rank 1)")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
     ap.add_argument("--no-ref-batching", action="store_true",
                     help="skip the extra CFG-doubled measurement (use under rocprofv3 so kernel stats match the timed region)")
@@ -199,6 +200,28 @@ def main():
         ref_batching = batch * 2 / (time.perf_counter() - t1)
         solver.eliminate_dead_uncond = True
 
+    # VAE decode of one step's latents, timed separately ("VAE decode ... reported separately"); it is
+    # NOT part of `value`.  SD VAE width for both architectures; SDXL latents are 128x128 -> 1024x1024 images.
+    vae_leg = None
+    if rank == 0 and not a.no_vae:
+        from invertible_cd_amd import synthetic, vae as vae_mod
+        vcfg = vae_mod.SD_VAE if a.arch == "sd15" else vae_mod.SDXL_VAE
+        vsd = synthetic.synthetic_vae_state_dict(vcfg, seed=0, device=device, dtype=torch.float16)
+        m = vae_mod.AutoencoderKL(vcfg, vsd, device=device, max_chunk=8 if a.arch == "sd15" else 2)
+        del vsd
+        lat = (outs[-1].float() / vcfg.scaling_factor).clamp(-30, 30)
+        m.decode(lat[:2]); torch.cuda.synchronize()
+        tv = time.perf_counter()
+        img = m.decode(lat)["sample"]
+        torch.cuda.synchronize()
+        tv = time.perf_counter() - tv
+        ok = bool(torch.isfinite(img).all())
+        per_img_unet = dt / (batch * a.steps)
+        vae_leg = {"decode_ms_per_image": round(tv / batch * 1e3, 3), "decode_images_per_sec": round(batch / tv, 2),
+                   "finite": ok, "images_per_sec_unet_plus_decode_1gpu": round(1.0 / (per_img_unet + tv / batch), 2),
+                   "note": "AutoencoderKL decode of one step's latents on the same HIP operators, synthetic weights; not in `value`"}
+        del m, img
+
     if rank != 0:
         return
     images = batch * a.steps * world
@@ -241,6 +264,8 @@ def main():
                                       "gbps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["bytes"] else None}
                                   for k, v in fam.items()}
         out["kernel_families_note"] = "per-family table from the last warm-up step; roofline from the timed region"
+    if vae_leg is not None:
+        out["vae_decode"] = vae_leg
     if world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(a.arch, sd, cfg)
     print(json.dumps(out))

@@ -61,10 +61,15 @@ struct AttnK {
 //   * NST-stage LDS ring (NST = 3 where it fits): tiles are requested two ahead and handed over with a counted vmcnt -
 //     one tile of compute (~0.6 us) does not cover the global -> LDS latency (PMC: 35 % of wave cycles in s_waitcnt
 //     with a 2-stage ring).
+// Tried and dropped (same-box A/B): an intra-wave software pipeline (S^T MFMAs of tile t+1 issued before the softmax of
+// tile t, second S accumulator set, 3-stage ring) is not faster, QT = 2 at d = 64 spills - at one query tile per wave
+// every ds_read_b128 feeds exactly one MFMA, which is 125 B/clk of LDS traffic per CU at full MFMA rate: the loop is
+// LDS-bandwidth bound, and only more MFMAs per fragment (QT = 2 where the registers allow it: d <= 48) lift that.
 template <int KS, int DT, int QT, int OCC, int NST>
 __global__ __launch_bounds__(256, OCC) void attn_fused_kernel(AttnK p) {
     constexpr int NCH = 2 * KS;                       // 16-B chunks per K row
     constexpr bool ONES = KS * 16 < DT * 32;          // a free padded V^T row exists: MFMA computes the denominator
+    constexpr bool LS_MFMA = !ONES && QT == 1;        // otherwise: one extra MFMA per key step (QT = 1) or VALU sums
     constexpr int KT_BYTES = 64 * NCH * 16;           // K tile
     constexpr int VT_BYTES = DT * 32 * 128;           // V^T tile, 64 keys = 128 B per row
     constexpr int STAGE = KT_BYTES + VT_BYTES;
@@ -191,10 +196,7 @@ __global__ __launch_bounds__(256, OCC) void attn_fused_kernel(AttnK p) {
 #pragma unroll
     for (int u = 0; u < QT; ++u) { m_run[u] = -INFINITY; l_run[u] = 0.f; }
     const float c = p.scale_log2;
-    f32x16 zero16;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) zero16[e] = 0.f;
-    asm volatile("" : "+v"(zero16));          // keep it in registers: do not re-materialise 16 zeros per tile
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // folds into the MFMA's inline-constant srcC
     f16x8 ones8;
 #pragma unroll
     for (int e = 0; e < 8; ++e) ones8[e] = (half_t)1.f;
@@ -204,11 +206,9 @@ __global__ __launch_bounds__(256, OCC) void attn_fused_kernel(AttnK p) {
     // Fragment reads are issued in batches and fenced (sched_barrier): left alone, the register allocator reuses one
     // quad for every fragment and serialises ds_read -> s_waitcnt lgkmcnt(0) -> v_mfma, i.e. 16 exposed LDS latencies
     // per tile (measured: removing the LDS reads made the old loop 28 % faster, removing the exps did nothing).
-    auto tile = [&](auto ragged_tag, const int BO, int t) {
-        constexpr bool RAGGED = decltype(ragged_tag)::value;
+    auto qk = [&](f32x16 (&s)[QT][2], const int BO, const bool rag, const int t) {
         // ---- K fragments in batches of 2 x KC, then S^T[key][q] for two 32-key tiles ----
-        constexpr int KC = KS <= 6 ? KS : (KS + 1) / 2;
-        f32x16 s[QT][2];
+        constexpr int KC = QT > 1 && KS > 3 ? 2 : KS <= 6 ? KS : (KS + 1) / 2;
 #pragma unroll
         for (int k0 = 0; k0 < KS; k0 += KC) {
             f16x8 kf[2][KC];
@@ -228,8 +228,21 @@ __global__ __launch_bounds__(256, OCC) void attn_fused_kernel(AttnK p) {
                         if (k0 + kk < KS)
                             s[u][kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kt][kk], qf[u][k0 + kk],
                                                                               k0 + kk == 0 ? zero16 : s[u][kt], 0, 0, 0);
-            if (k0 + KC < KS) __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_sched_barrier(0);
         }
+        if (rag) {                                       // ragged last tile only (wave-uniform): keys past Nk -> -inf
+#pragma unroll
+            for (int u = 0; u < QT; ++u)
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int key = t * 64 + kt * 32 + 16 * (e >> 3) + 8 * lh + (e & 7);
+                        if (key >= p.Nk) s[u][kt][e] = -INFINITY;
+                    }
+        }
+    };
+    auto softmax_pv = [&](f32x16 (&s)[QT][2], const int BO) {
         // ---- V^T fragments of the first VPRE key steps: in flight while the softmax runs ----
         constexpr int VPRE = QT * DT <= 2 ? 4 : QT * DT <= 4 ? 2 : 1;      // at most 8 fragments (32 VGPRs) ahead
         f16x8 vf[4][DT];
@@ -243,15 +256,6 @@ __global__ __launch_bounds__(256, OCC) void attn_fused_kernel(AttnK p) {
         f16x8 pf[QT][4];
 #pragma unroll
         for (int u = 0; u < QT; ++u) {
-            if (RAGGED) {
-#pragma unroll
-                for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int key = t * 64 + kt * 32 + 16 * (e >> 3) + 8 * lh + (e & 7);
-                        if (key >= p.Nk) s[u][kt][e] = -INFINITY;
-                    }
-            }
             float mx0 = fmaxf(s[u][0][0], s[u][1][0]), mx1 = fmaxf(s[u][0][1], s[u][1][1]);
 #pragma unroll
             for (int e = 2; e < 16; e += 2) {
@@ -274,11 +278,16 @@ __global__ __launch_bounds__(256, OCC) void attn_fused_kernel(AttnK p) {
                     for (int e = 0; e < 16; ++e) o[u][i][e] *= alpha;
             }
             const float nmc = -m_run[u] * c;
+            float rs = 0.f;
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                for (int e = 0; e < 16; ++e)
-                    pf[u][kt * 2 + (e >> 3)][e & 7] = (half_t)__builtin_amdgcn_exp2f(fmaf(s[u][kt][e], c, nmc));
+                for (int e = 0; e < 16; ++e) {
+                    const float pv = __builtin_amdgcn_exp2f(fmaf(s[u][kt][e], c, nmc));
+                    if (!ONES && !LS_MFMA) rs += pv;
+                    pf[u][kt * 2 + (e >> 3)][e & 7] = (half_t)pv;
+                }
+            if (!ONES && !LS_MFMA) l_run[u] += rs;      // this lane's 32 keys; the other half-wave is added at the end
         }
         __builtin_amdgcn_sched_barrier(0);
         // ---- O^T[dcol][q] += V^T[dcol][keys] . P^T[keys][q]  (each V^T fragment feeds the QT query tiles; the
@@ -296,13 +305,13 @@ __global__ __launch_bounds__(256, OCC) void attn_fused_kernel(AttnK p) {
             for (int i = 0; i < DT; ++i)
 #pragma unroll
                 for (int u = 0; u < QT; ++u) o[u][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[st][i], pf[u][st], o[u][i], 0, 0, 0);
-            if (!ONES) {
+            if (LS_MFMA) {
 #pragma unroll
                 for (int u = 0; u < QT; ++u)
                     ls[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones8, pf[u][st], st == 0 ? zero16 : ls[u], 0, 0, 0);
             }
         }
-        if (!ONES) {
+        if (LS_MFMA) {
 #pragma unroll
             for (int u = 0; u < QT; ++u) l_run[u] += ls[u][0];          // every row of ones . P^T is the full 64-key sum
         }
@@ -326,28 +335,36 @@ __global__ __launch_bounds__(256, OCC) void attn_fused_kernel(AttnK p) {
         else __builtin_amdgcn_s_waitcnt(0x0f70 | (NKG + DT));
     };
     static_assert(NKG + DT < 16 && NST <= 3, "vmcnt immediate / keep count");
-    auto step = [&](auto ragged_tag, const int buf, int t) {      // tile t sits in stage `buf`
-        wait_landed(nt - 1 - t < PD - 1 ? nt - 1 - t : PD - 1);
-        __syncthreads();                                  // tile t visible to all; everybody is done with tile t-1
-        if (t + PD < nt) issue(t + PD, ((buf + PD) % NST) * STAGE);
-        tile(ragged_tag, buf * STAGE, t);
-    };
+    {
+        auto step = [&](const bool rag, const int buf, int t) {      // tile t sits in stage `buf`
+            wait_landed(nt - 1 - t < PD - 1 ? nt - 1 - t : PD - 1);
+            __syncthreads();                              // tile t visible to all; everybody is done with tile t-1
+            if (t + PD < nt) issue(t + PD, ((buf + PD) % NST) * STAGE);
+            f32x16 s[QT][2];
+            qk(s, buf * STAGE, rag, t);
+            softmax_pv(s, buf * STAGE);
+        };
 #pragma unroll
-    for (int i = 0; i < PD; ++i)
-        if (i < nt) issue(i, i * STAGE);
-    int t = 0;
-    for (; t + NST <= nfull; t += NST) {
+        for (int i = 0; i < PD; ++i)
+            if (i < nt) issue(i, i * STAGE);
+        int t = 0;
+        for (; t + NST <= nfull; t += NST) {
 #pragma unroll
-        for (int i = 0; i < NST; ++i) step(F{}, i, t + i);
+            for (int i = 0; i < NST; ++i) step(false, i, t + i);
+        }
+        for (int i = 0; t < nfull; ++t, ++i) step(false, i, t);      // < NST leftover full tiles, stages 0, 1, ..
+        if (ragged) step(true, nfull % NST, nfull);
     }
-    for (int i = 0; t < nfull; ++t, ++i) step(F{}, i, t);      // < NST leftover full tiles, stages 0, 1, ..
-    if (ragged) step(T{}, nfull % NST, nfull);
     // ---- normalise and store: lane holds 4 consecutive head-dim columns of query row q0 + 32u + lr ----
 #pragma unroll
     for (int u = 0; u < QT; ++u) {
         float l_tot;
         if (ONES) l_tot = __shfl(o[u][DT - 1][15], lr + 32);   // row DT*32-1 of O^T = sum_k P (the V^T ones-row), upper half-wave
-        else l_tot = l_run[u];
+        else if (LS_MFMA) l_tot = l_run[u];
+        else {
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run[u]), __float_as_uint(l_run[u]), false, false);
+            l_tot = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+        }
         const float inv = 1.0f / l_tot;
         const int qrow = q0 + u * 32 + lr;
         if (qrow < p.Nq) {
@@ -367,7 +384,7 @@ __global__ __launch_bounds__(256, OCC) void attn_fused_kernel(AttnK p) {
     }
 }
 
-template <int KS, int DT, int QT, int OCC = 2, int NST = 3>
+template <int KS, int DT, int QT, int OCC = 2, int NST = 2>
 int launch_attn(AttnK k, hipStream_t st) {
     constexpr int smem = NST * (64 * 2 * KS * 16 + DT * 32 * 128);
     static_assert(smem * OCC <= 160 * 1024, "LDS ring x occupancy exceeds the CU's 160 KiB");
@@ -405,7 +422,7 @@ extern "C" int icd_attention_fused(const void* q, const void* k, const void* vt,
     if (d <= 16) return launch_attn<1, 1, 1, 2, 2>(a, st);
     if (d <= 32) return launch_attn<2, 1, 1, 2, 2>(a, st);
     if (d <= 48) return wide ? launch_attn<3, 2, 2, 2, 2>(a, st) : launch_attn<3, 2, 1, 2, 2>(a, st);
-    if (d <= 64) return launch_attn<4, 2, 1, 2, 2>(a, st);      // QT = 2 needs > 256 VGPRs at d = 64
+    if (d <= 64) return launch_attn<4, 2, 1, 2, 2>(a, st);      // QT = 2 spills at d = 64 (measured slower)
     if (d <= 80) return launch_attn<5, 3, 1, 2, 2>(a, st);
     if (d <= 96) return launch_attn<6, 3, 1, 2, 2>(a, st);
     if (d <= 128) return launch_attn<8, 4, 1, 2, 2>(a, st);

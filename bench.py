@@ -92,6 +92,21 @@ def build_sdxl(batch, device):
     return step, None, None, SDXL
 
 
+def hbm_traffic(arch, batch, family):
+    """HBM-side bytes per launch of `family` from the committed PMC summary of this workload (rocprofv3 cannot run inside
+    the timed process); None when no summary matches the workload.  See tools/hbm_traffic.py for the corrections."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*hbm_traffic*.json"))):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if d.get("arch") == arch and d.get("per_gpu_batch") == batch and family in d.get("families", {}):
+            best = d["families"][family]["traffic_bytes"]           # latest round wins (sorted by name)
+    return best
+
+
 def cpu_baseline(arch, sd, cfg):
     """The reference's CPU path restated (oracle): config[0] = SD1.5, B=1, 4 steps, CFG-doubled UNet batch of 2, fp32."""
     import numpy as np
@@ -256,7 +271,7 @@ def main():
             ach = d["bytes"] / (d["ms"] * 1e-3)
             roof = {"bound": "hbm", "kernel": dom, "achieved": round(ach / 1e9, 1), "peak": PEAK_HBM / 1e9, "unit": "GB/s",
                     "frac": round(ach / PEAK_HBM, 4)}
-        roof.update({"traffic": None, "launches": d["launches"], "avg_launch_us": round(d["ms"] / d["launches"] * 1e3, 2),
+        roof.update({"traffic": hbm_traffic(a.arch, batch, dom), "launches": d["launches"], "avg_launch_us": round(d["ms"] / d["launches"] * 1e3, 2),
                      "algorithmic_per_launch": (d["flops"] or d["bytes"]) / d["launches"]})
         out["roofline"] = roof
         out["kernel_families"] = {k: {"launches": v["launches"], "ms": round(v["ms"], 3),

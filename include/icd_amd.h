@@ -53,6 +53,15 @@ int icd_version(void);
 #define ICD_GEMM_PAD_HI     8   /* conv: zero padding on the bottom / right edge only (AutoencoderKL Downsample2D:  */
                                 /* F.pad(x, (0,1,0,1)) + conv3x3 stride 2 pad 0), instead of ksize/2 on every side   */
 
+/* Planner overrides for A/B tuning (tools/gemm_bench.py) and for tests that must exercise one tile family; they never
+ * change results beyond fp32 summation order.  Not needed by callers. */
+#define ICD_GEMM_TUNE_WM2        0x00040000   /* 128x128 tile, no split-K                                            */
+#define ICD_GEMM_TUNE_WM4        0x00080000   /* 256x128 tile, no split-K                                            */
+#define ICD_GEMM_TUNE_FORCE_BIG  0x00100000   /* take a 256-wide tile (gemm_big.hip) whatever the chip fill           */
+#define ICD_GEMM_TUNE_NO_BIG     0x00200000   /* never take one                                                      */
+#define ICD_GEMM_TUNE_BN256      0x00400000   /* big tiles: only the BN = 256 shapes                                 */
+#define ICD_GEMM_TUNE_BIG_CFG(i) (((i) + 1) << 24)   /* force big-tile configuration i (0..3, see gemm_common.h)      */
+
 /* out = alpha * (A (*) W^T) + bias[n] + rowbias[m / rows_per_sample][n] + resid[m][n]
  * A is either a dense row-major [M, K] matrix (mode 0; Linear, 1x1 conv, attention bmm) or the implicit im2col
  * view of one/two NHWC tensors (mode 1; conv3x3 pad 1, stride 1|2, optional nearest-2x upsample in the loader,

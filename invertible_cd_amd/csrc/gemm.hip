@@ -232,9 +232,8 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_kernel(GemmK p) {
         if (NSTAGE == 2 || t + (NSTAGE - 2) >= nk) __builtin_amdgcn_s_waitcnt(0x0f70);                   // vmcnt(0)
         else __builtin_amdgcn_s_waitcnt(0x0f70 | (LOADS * (NSTAGE - 2)));                                 // vmcnt(LOADS)
         __builtin_amdgcn_s_barrier();
-        if (t + NSTAGE - 1 < nk && !(p.flags & 0x10000)) issue_stage(kt_begin + t + NSTAGE - 1, SN * STAGE_BYTES);
+        if (t + NSTAGE - 1 < nk) issue_stage(kt_begin + t + NSTAGE - 1, SN * STAGE_BYTES);
         const unsigned char* sb = smem + S * STAGE_BYTES;
-        if (p.flags & 0x20000) return;
         // register double-buffered fragments: the ds_reads of sub-step s+1 are in flight under the MFMAs of sub-step s
         f16x8 af[2][2], wf[2][2];
 #pragma unroll
@@ -549,16 +548,16 @@ extern "C" int icd_gemm(const icd_gemm_desc* d, void* stream) {
     {
         const bool conv_fast = d->mode == 1 && ((d->C0 + d->C1) % 64 == 0) && (d->C0 % 64 == 0);
         const bool base_ok = batch == 1 && !trans && (d->mode == 0 || conv_fast) && d->M >= 256 && (d->Nw <= 0 || d->Nw >= d->N) &&
-                             (d->K % 64 == 0) && !(d->flags & 0x200000);
+                             (d->K % 64 == 0) && !(d->flags & ICD_GEMM_TUNE_NO_BIG);
         // Cost model in units of "one k-tile of a 256x256 block" (calibrated with tools/gemm_bench.py, same-box A/B):
         // a block owns its CU, so a launch costs rounds x (k-tiles x tk + fixed), fixed = prologue + exposed epilogue.
         int cfg = -1, s = 1;
         double best = 1e30, best_fill = 0.0;
-        const int forced = ((d->flags >> 24) & 15) - 1;          // tuning override: flags bits 24..27 = cfg + 1
+        const int forced = ((d->flags >> 24) & 15) - 1;          // ICD_GEMM_TUNE_BIG_CFG(i)
         for (int ci = 0; ci < NUM_BIG_TILES && base_ok; ++ci) {
             const BigTile& c = BIG_TILES[ci];
             if (forced >= 0 && ci != forced) continue;
-            if (d->N % c.bn != 0 || (geglu && !c.geglu_ok) || ((d->flags & 0x400000) && c.bn != 256)) continue;
+            if (d->N % c.bn != 0 || (geglu && !c.geglu_ok) || ((d->flags & ICD_GEMM_TUNE_BN256) && c.bn != 256)) continue;
             const long long b0 = (long long)((d->M + c.bm - 1) / c.bm) * (d->N / c.bn);
             int smax = 1;
             if (allow_split && b0 < 192 && nk_total >= 16) {
@@ -580,7 +579,7 @@ extern "C" int icd_gemm(const icd_gemm_desc* d, void* stream) {
                 if (cost < best) { best = cost; cfg = ci; s = sx; best_fill = (double)bt / (double)(((bt + 255) / 256) * 256); }
             }
         }
-        if (cfg >= 0 && (best_fill >= 0.45 || forced >= 0 || (d->flags & 0x100000))) {
+        if (cfg >= 0 && (best_fill >= 0.45 || forced >= 0 || (d->flags & ICD_GEMM_TUNE_FORCE_BIG))) {
             const BigTile& c = BIG_TILES[cfg];
             k.nbm = (d->M + c.bm - 1) / c.bm; k.nbn = d->N / c.bn;
             k.kt_per_split = (nk_total + s - 1) / s;
@@ -600,8 +599,8 @@ extern "C" int icd_gemm(const icd_gemm_desc* d, void* stream) {
         }
     }
     plan_gemm(d->M, d->N, d->K, batch, allow_split, d->splitk_ws_bytes, &wm, &ks);
-    if (d->flags & 0x40000) { wm = 2; ks = 1; }          // tuning overrides (tools/gemm_bench.py)
-    if (d->flags & 0x80000) { wm = 4; ks = 1; }
+    if (d->flags & ICD_GEMM_TUNE_WM2) { wm = 2; ks = 1; }          // tuning overrides (tools/gemm_bench.py)
+    if (d->flags & ICD_GEMM_TUNE_WM4) { wm = 4; ks = 1; }
     k.ksplit = ks;
     k.kt_per_split = (nk_total + ks - 1) / ks;
     k.ksplit = (nk_total + k.kt_per_split - 1) / k.kt_per_split;      // no empty splits

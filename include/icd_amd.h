@@ -123,6 +123,14 @@ int icd_attention_fused(const void* q, const void* k, const void* vt, void* out,
                         int32_t Nk, int32_t d, int32_t ldq, int32_t ldk, int32_t ldvt, int32_t ldo,
                         int64_t vt_batch_stride, float scale, void* stream);
 
+/* Same with flags: ICD_ATTN_CAUSAL masks keys after the query (needs Nq == Nk) - the causal self-attention of the CLIP
+ * text encoders behind `text_encoder(ids)[0]` (utils/generation.py:293,301) and `encode_prompt`
+ * (utils/generation_sdxl.py:31-44). */
+#define ICD_ATTN_CAUSAL 1
+int icd_attention_fused_ex(const void* q, const void* k, const void* vt, void* out, int32_t B, int32_t H, int32_t Nq,
+                           int32_t Nk, int32_t d, int32_t ldq, int32_t ldk, int32_t ldvt, int32_t ldo,
+                           int64_t vt_batch_stride, float scale, int32_t flags, void* stream);
+
 /* Sinusoidal embeddings.  kind 0: diffusers Timesteps(dim, flip_sin_to_cos=True, shift=0) -> [cos || sin];
  * kind 1: guidance_scale_embedding (utils/generation.py:96-122) -> [sin || cos] of 1000*w, denominator half-1.
  * vals: fp32 [n] on device; out fp16 [n, dim]. */
@@ -130,6 +138,11 @@ int icd_sinusoid(const float* vals, int32_t n, int32_t dim, int32_t kind, void* 
 
 /* y = silu(x) over n fp16 elements (time-embedding activation shared by all ResnetBlock2D.time_emb_proj). */
 int icd_silu(const void* x, int64_t n, void* out, void* stream);
+/* kind 0 silu, 1 quick_gelu x*sigmoid(1.702x) (CLIP ViT-L text MLP), 2 gelu erf form (OpenCLIP bigG text MLP). */
+int icd_activation(const void* x, int64_t n, int32_t kind, void* out, void* stream);
+/* CLIPTextEmbeddings: out[r, :] = tok_emb[ids[r], :] + pos_emb[r % T, :]; ids int64 [rows] on device, tables fp16. */
+int icd_embed_tokens(const int64_t* ids, const void* tok_emb, const void* pos_emb, int64_t rows, int32_t T, int32_t C,
+                     int32_t vocab, void* out, void* stream);
 
 /* conv_in: 3x3 pad 1, Cin=4 NCHW latents (fp16 or fp32) -> NHWC fp16 [B, H*W, Cout].  w: fp16 [Cout, 3,3,4]. */
 int icd_conv_in(const void* x_nchw, int32_t x_is_f32, int32_t B, int32_t H, int32_t W, const void* w,

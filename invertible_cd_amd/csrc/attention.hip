@@ -43,6 +43,7 @@ struct AttnK {
     long long vt_bs;              // elements between the V^T blocks of consecutive samples
     float scale_log2;
     int nqt;
+    int causal;                   // keys after the query are masked (CLIP text encoder); Nq == Nk
 };
 
 // KS = 16-wide k-steps over the head dim (dpad16 = 16*KS); DT = 32-row tiles of the head dim; QT = query tiles per wave
@@ -230,16 +231,18 @@ __global__ __launch_bounds__(256, OCC) void attn_fused_kernel(AttnK p) {
                                                                               k0 + kk == 0 ? zero16 : s[u][kt], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (rag) {                                       // ragged last tile only (wave-uniform): keys past Nk -> -inf
+        if (rag || p.causal) {                           // wave-uniform: ragged last tile (keys past Nk) / causal mask -> -inf
 #pragma unroll
-            for (int u = 0; u < QT; ++u)
+            for (int u = 0; u < QT; ++u) {
+                const int last = p.causal ? min(p.Nk - 1, q0 + u * 32 + lr) : p.Nk - 1;    // last key this query may see
 #pragma unroll
                 for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
                         const int key = t * 64 + kt * 32 + 16 * (e >> 3) + 8 * lh + (e & 7);
-                        if (key >= p.Nk) s[u][kt][e] = -INFINITY;
+                        if (key > last) s[u][kt][e] = -INFINITY;
                     }
+            }
         }
     };
     auto softmax_pv = [&](f32x16 (&s)[QT][2], const int BO) {
@@ -402,9 +405,22 @@ int launch_attn(AttnK k, hipStream_t st) {
 
 }  // namespace
 
+extern "C" int icd_attention_fused_ex(const void* q, const void* k, const void* vt, void* out, int32_t B, int32_t H,
+                                      int32_t Nq, int32_t Nk, int32_t d, int32_t ldq, int32_t ldk, int32_t ldvt, int32_t ldo,
+                                      int64_t vt_batch_stride, float scale, int32_t flags, void* stream);
+
 extern "C" int icd_attention_fused(const void* q, const void* k, const void* vt, void* out, int32_t B, int32_t H,
                                    int32_t Nq, int32_t Nk, int32_t d, int32_t ldq, int32_t ldk, int32_t ldvt,
                                    int32_t ldo, int64_t vt_batch_stride, float scale, void* stream) {
+    return icd_attention_fused_ex(q, k, vt, out, B, H, Nq, Nk, d, ldq, ldk, ldvt, ldo, vt_batch_stride, scale, 0, stream);
+}
+
+extern "C" int icd_attention_fused_ex(const void* q, const void* k, const void* vt, void* out, int32_t B, int32_t H,
+                                      int32_t Nq, int32_t Nk, int32_t d, int32_t ldq, int32_t ldk, int32_t ldvt, int32_t ldo,
+                                      int64_t vt_batch_stride, float scale, int32_t flags, void* stream) {
+    ICD_CHECK_ARG((flags & ~ICD_ATTN_CAUSAL) == 0, "icd_attention_fused: unknown flags 0x%x", flags);
+    ICD_CHECK_ARG(!(flags & ICD_ATTN_CAUSAL) || Nq == Nk, "icd_attention_fused: the causal mask needs Nq == Nk");
+    ICD_CHECK_ARG(scale > 0.f, "icd_attention_fused: scale must be positive");
     ICD_CHECK_ARG(q && k && vt && out, "icd_attention_fused: null pointer");
     ICD_CHECK_ARG(B > 0 && H > 0 && Nq > 0 && Nk > 0, "icd_attention_fused: empty shape");
     ICD_CHECK_ARG(d > 0 && d % 8 == 0 && d <= 160, "icd_attention_fused: head dim must be a multiple of 8, <= 160 (got %d)", d);
@@ -416,6 +432,7 @@ extern "C" int icd_attention_fused(const void* q, const void* k, const void* vt,
     a.vt_bs = vt_batch_stride > 0 ? vt_batch_stride : (long long)H * d * ldvt;
     a.scale_log2 = scale * 1.4426950408889634f;
     a.nqt = 0;
+    a.causal = (flags & ICD_ATTN_CAUSAL) ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
     // two query tiles per wave when the sequence is long enough to still fill the chip with 256-row workgroups
     const bool wide = (long long)((Nq + 255) / 256) * B * H >= 512 && Nk >= 256;

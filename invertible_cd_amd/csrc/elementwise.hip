@@ -29,13 +29,36 @@ __global__ void sinusoid_kernel(const float* __restrict__ vals, int n, int dim, 
     }
 }
 
-__global__ void silu_kernel(const half_t* __restrict__ x, long long n8, half_t* __restrict__ out) {
+// KIND 0: silu   1: quick_gelu x*sigmoid(1.702x) (CLIP ViT-L text MLP)   2: gelu (erf form; OpenCLIP bigG text MLP)
+template <int KIND>
+__global__ void activation_kernel(const half_t* __restrict__ x, long long n8, half_t* __restrict__ out) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n8) return;
     f16x8 v = *reinterpret_cast<const f16x8*>(x + i * 8), o;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = (half_t)silu_f((float)v[e]);
+    for (int e = 0; e < 8; ++e) {
+        const float f = (float)v[e];
+        o[e] = (half_t)(KIND == 0 ? silu_f(f) : KIND == 1 ? f / (1.0f + __expf(-1.702f * f)) : gelu_erf_f(f));
+    }
     *reinterpret_cast<f16x8*>(out + i * 8) = o;
+}
+
+// out[b*T + t, :] = tok[ids[b*T + t], :] + pos[t, :]   (CLIPTextEmbeddings); thread = one 8-channel chunk of one token
+__global__ void embed_tokens_kernel(const long long* __restrict__ ids, const half_t* __restrict__ tok,
+                                    const half_t* __restrict__ pos, long long rows, int T, int C, int vocab,
+                                    half_t* __restrict__ out) {
+    const int nch = C >> 3;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * nch) return;
+    const long long r = i / nch;
+    const int c = (int)(i - r * nch) * 8;
+    long long id = ids[r];
+    id = id < 0 ? 0 : id >= vocab ? vocab - 1 : id;               // the host validates; never read out of bounds
+    f16x8 a = *reinterpret_cast<const f16x8*>(tok + id * C + c);
+    f16x8 b = *reinterpret_cast<const f16x8*>(pos + (r % T) * C + c), o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)a[e] + (float)b[e]);
+    *reinterpret_cast<f16x8*>(out + r * C + c) = o;
 }
 
 // conv_in: thread = (pixel, 8 output channels).  Input NCHW with 4 channels; weights [Cout][3][3][4] fp16.
@@ -164,9 +187,34 @@ extern "C" int icd_sinusoid(const float* vals, int32_t n, int32_t dim, int32_t k
 extern "C" int icd_silu(const void* x, int64_t n, void* out, void* stream) {
     ICD_CHECK_ARG(x && out && n > 0 && n % 8 == 0, "icd_silu: n must be a positive multiple of 8");
     const long long n8 = n / 8;
-    hipLaunchKernelGGL(silu_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(activation_kernel<0>, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        (const half_t*)x, n8, (half_t*)out);
     ICD_CHECK_LAUNCH("icd_silu");
+    return ICD_OK;
+}
+
+extern "C" int icd_activation(const void* x, int64_t n, int32_t kind, void* out, void* stream) {
+    ICD_CHECK_ARG(x && out && n > 0 && n % 8 == 0, "icd_activation: n must be a positive multiple of 8");
+    ICD_CHECK_ARG(kind >= 0 && kind <= 2, "icd_activation: kind must be 0 (silu), 1 (quick_gelu) or 2 (gelu)");
+    const long long n8 = n / 8;
+    const dim3 grid((unsigned)((n8 + 255) / 256));
+    hipStream_t st = (hipStream_t)stream;
+    if (kind == 0) hipLaunchKernelGGL(activation_kernel<0>, grid, dim3(256), 0, st, (const half_t*)x, n8, (half_t*)out);
+    else if (kind == 1) hipLaunchKernelGGL(activation_kernel<1>, grid, dim3(256), 0, st, (const half_t*)x, n8, (half_t*)out);
+    else hipLaunchKernelGGL(activation_kernel<2>, grid, dim3(256), 0, st, (const half_t*)x, n8, (half_t*)out);
+    ICD_CHECK_LAUNCH("icd_activation");
+    return ICD_OK;
+}
+
+extern "C" int icd_embed_tokens(const int64_t* ids, const void* tok_emb, const void* pos_emb, int64_t rows, int32_t T,
+                                int32_t C, int32_t vocab, void* out, void* stream) {
+    ICD_CHECK_ARG(ids && tok_emb && pos_emb && out, "icd_embed_tokens: null pointer");
+    ICD_CHECK_ARG(rows > 0 && T > 0 && rows % T == 0 && C > 0 && C % 8 == 0 && vocab > 0, "icd_embed_tokens: bad shape");
+    const long long total = (long long)rows * (C / 8);
+    hipLaunchKernelGGL(embed_tokens_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const long long*)ids, (const half_t*)tok_emb, (const half_t*)pos_emb, (long long)rows, T, C, vocab,
+                       (half_t*)out);
+    ICD_CHECK_LAUNCH("icd_embed_tokens");
     return ICD_OK;
 }
 

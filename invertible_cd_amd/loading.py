@@ -103,6 +103,15 @@ def _build_vae(comp, cfg, device, dtype):
         comp["vae"] = AutoencoderKL(cfg, comp["vae_state_dict"], device=device, dtype=dtype)
 
 
+def _build_text_encoders(comp, device, dtype, xl):
+    """components['text_encoder_state_dict'] (and '_2' for SDXL) in transformers' CLIP key layout -> HIP CLIPTextModel."""
+    from .clip import CLIPTextModel, CLIP_VIT_L, OPENCLIP_BIGG
+    if "text_encoder" not in comp and comp.get("text_encoder_state_dict") is not None:
+        comp["text_encoder"] = CLIPTextModel(CLIP_VIT_L, comp["text_encoder_state_dict"], False, device, dtype)
+    if xl and "text_encoder_2" not in comp and comp.get("text_encoder_2_state_dict") is not None:
+        comp["text_encoder_2"] = CLIPTextModel(OPENCLIP_BIGG, comp["text_encoder_2_state_dict"], True, device, dtype)
+
+
 def load_models(model_id, device, reverse_checkpoint, forward_checkpoint, r=64, w_embed_dim=0, teacher_checkpoint=None,
                 dtype='fp32', components=None):
     """SD1.5: (ldm_stable, reverse_cons_model, forward_cons_model).  `components` may supply real
@@ -114,6 +123,7 @@ def load_models(model_id, device, reverse_checkpoint, forward_checkpoint, r=64, 
         print(f'Forward CD is initialized with guidance embedding, dim {w_embed_dim}')
     comp = dict(components or {})
     comp.setdefault("tokenizer", SyntheticTokenizer())
+    _build_text_encoders(comp, device, tdtype, xl=False)
     comp.setdefault("text_encoder", SyntheticTextEncoder(cfg.cross_dim, device))
     from .vae import SD_VAE
     _build_vae(comp, SD_VAE, device, tdtype)
@@ -142,6 +152,7 @@ def load_models_xl(model_id, reverse_checkpoint, forward_checkpoint, teacher_che
     comp = dict(components or {})
     from .vae import SDXL_VAE
     _build_vae(comp, SDXL_VAE, device, torch.float16)
+    _build_text_encoders(comp, device, torch.float16, xl=True)
     base_sd = _load_unet_state(model_id, cfg, teacher_checkpoint)
 
     def pipeline(sd, cls):

@@ -158,12 +158,12 @@ def project_vt(x, w, B, n_tokens, ld_keys):
     return out
 
 
-def attention_fused(q, k, vt, B, H, Nq, Nk, d, scale):
-    """q [B*Nq, H*d], k [B*Nk, H*d], vt [B, H*d, ld] -> out [B*Nq, H*d]."""
+def attention_fused(q, k, vt, B, H, Nq, Nk, d, scale, causal=False):
+    """q [B*Nq, H*d], k [B*Nk, H*d], vt [B, H*d, ld] -> out [B*Nq, H*d]; causal: keys after the query are masked."""
     _chk_rows(q, "q"); _chk_rows(k, "k"); _chk16(vt, "vt")
     out = torch.empty((q.shape[0], q.shape[1]), device=q.device, dtype=torch.float16)
-    _lib.check(_lib.load().icd_attention_fused(_p(q), _p(k), _p(vt), _p(out), B, H, Nq, Nk, d, q.stride(0), k.stride(0),
-                                               vt.stride(1), out.stride(0), vt.stride(0), scale, _stream()),
+    _lib.check(_lib.load().icd_attention_fused_ex(_p(q), _p(k), _p(vt), _p(out), B, H, Nq, Nk, d, q.stride(0), k.stride(0),
+                                                  vt.stride(1), out.stride(0), vt.stride(0), scale, 1 if causal else 0, _stream()),
                "icd_attention_fused")
     return out
 
@@ -213,6 +213,27 @@ def silu(x):
     _chk16(x, "x")
     out = torch.empty_like(x)
     _lib.check(_lib.load().icd_silu(_p(x), x.numel(), _p(out), _stream()), "icd_silu")
+    return out
+
+
+ACT_SILU, ACT_QUICK_GELU, ACT_GELU = 0, 1, 2
+
+
+def activation(x, kind):
+    _chk16(x, "x")
+    out = torch.empty_like(x)
+    _lib.check(_lib.load().icd_activation(_p(x), x.numel(), kind, _p(out), _stream()), "icd_activation")
+    return out
+
+
+def embed_tokens(ids, tok_emb, pos_emb):
+    """ids int64 [B, T] -> [B*T, C] fp16 = tok_emb[ids] + pos_emb[t]."""
+    assert ids.is_cuda and ids.dtype == torch.int64 and ids.is_contiguous() and ids.dim() == 2
+    _chk16(tok_emb, "tok_emb"); _chk16(pos_emb, "pos_emb")
+    B, T = ids.shape
+    out = torch.empty((B * T, tok_emb.shape[1]), device=ids.device, dtype=torch.float16)
+    _lib.check(_lib.load().icd_embed_tokens(_p(ids), _p(tok_emb), _p(pos_emb), B * T, T, tok_emb.shape[1], tok_emb.shape[0],
+                                            _p(out), _stream()), "icd_embed_tokens")
     return out
 
 

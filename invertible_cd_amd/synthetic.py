@@ -58,6 +58,24 @@ def synthetic_vae_state_dict(cfg, seed: int = 0, device="cpu", dtype=torch.float
     return sd
 
 
+def synthetic_clip_state_dict(cfg, with_projection=False, seed: int = 0, device="cpu", dtype=torch.float32, prefix="text_model."):
+    """Seeded CLIP text-encoder weights in the checkpoint key layout (clip.CLIPTextConfig.state_dict_shapes)."""
+    sd = {}
+    for key, shape in cfg.state_dict_shapes(with_projection).items():
+        g = _gen("clip:" + key, seed, device)
+        if key.endswith(".bias"):
+            t = 0.05 * torch.randn(shape, generator=g, device=device)
+        elif "layer_norm" in key:
+            t = 1.0 + 0.1 * torch.randn(shape, generator=g, device=device)
+        elif "embedding" in key:
+            t = 0.5 * torch.randn(shape, generator=g, device=device)
+        else:
+            gain = 0.5 if key.endswith(("out_proj.weight", "fc2.weight")) else 1.0
+            t = torch.randn(shape, generator=g, device=device) * (gain / shape[-1] ** 0.5)
+        sd[(prefix if key != "text_projection.weight" else "") + key] = t.to(dtype)
+    return sd
+
+
 def synthetic_lora(cfg: UNetConfig, seed: int = 1, rank: int = 64, device="cpu", scale: float = 0.5):
     """{module path: (down [r, in(,k,k)], up [out, r(,1,1)])} for every LoRA target of the iCD students."""
     lora = {}

@@ -198,3 +198,15 @@ def test_vae_host_algebra_folds_are_exact():
     a = "decoder.mid_block.attentions.0."
     fused = sd[a + "to_out.0.weight"].double() @ sd[a + "to_v.bias"].double() + sd[a + "to_out.0.bias"].double()
     assert float((P[a + "to_out.bias"].double() - fused).abs().max()) < 1e-6
+
+
+def test_clip_layout_matches_transformers_classes():
+    """The text-encoder key layout / parameter counts of the product module equal those of the transformers classes the
+    reference instantiates (utils/loading.py:41,108-112): 123 060 480 (CLIP ViT-L) and 694 659 840 (OpenCLIP bigG + projection)."""
+    import math
+    from oracle import clip_ref
+    from invertible_cd_amd import clip
+    for cfg, proj, n in ((clip.CLIP_VIT_L, False, 123_060_480), (clip.OPENCLIP_BIGG, True, 694_659_840)):
+        shapes = cfg.state_dict_shapes(proj)
+        assert sum(math.prod(s) for s in shapes.values()) == n
+        assert clip_ref.state_dict_keys(cfg.to_dict(), proj) == {k: tuple(v) for k, v in shapes.items()}

@@ -1,0 +1,44 @@
+"""Prompt -> image through the reference-shaped API with every stage on the HIP operators: SyntheticTokenizer ids ->
+CLIPTextModel (clip.py) -> 4-step consistency loop with an AttentionStore controller (unet.py + p2p.py) -> AutoencoderKL
+decode (vae.py).  Full SD1.5 sizes, seeded synthetic weights (no checkpoints offline): checks the plumbing between the
+rows of SURVEY.md section 8 (shapes, dtypes, determinism, controller bookkeeping), not image quality."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_prompt_to_image_end_to_end():
+    from invertible_cd_amd import clip, generation, p2p, synthetic, vae
+    from invertible_cd_amd.loading import load_models
+    from invertible_cd_amd.schedulers import DDIMScheduler
+    comp = {"vae_state_dict": synthetic.synthetic_vae_state_dict(vae.SD_VAE, seed=0, device="cuda", dtype=torch.float16),
+            "text_encoder_state_dict": synthetic.synthetic_clip_state_dict(clip.CLIP_VIT_L, seed=0)}
+    ldm, rev, fwd = load_models("synthetic:sd15", "cuda", reverse_checkpoint="synthetic:1", forward_checkpoint=None,
+                                w_embed_dim=512, dtype="fp16", components=comp)
+    assert isinstance(rev.vae, vae.AutoencoderKL) and isinstance(rev.text_encoder, clip.CLIPTextModel) and fwd is None
+    solver = generation.Generator(ldm, 50, DDIMScheduler.sd15(), forward_cons_model=rev, reverse_cons_model=rev,
+                                  reverse_timesteps=[259, 519, 779, 999], forward_timesteps=[19, 259, 519, 779])
+    prompts = ["a photo of a cat sitting on a bench", "a photo of a dog sitting on a bench", "a red car"]
+
+    def run():
+        store = p2p.AttentionStore()
+        img, lat = generation.runner(model=rev, prompt=prompts, controller=store, solver=solver, is_cons_forward=True,
+                                     generator=torch.Generator().manual_seed(3), guidance_scale=7.0, tau1=1.0, tau2=1.0,
+                                     w_embed_dim=512, return_type="image")
+        return img, lat, store
+
+    img, lat, store = run()
+    assert isinstance(img, np.ndarray) and img.shape == (3, 512, 512, 3) and img.dtype == np.uint8
+    assert lat.shape == (1, 4, 64, 64)                      # the shared initial latent (utils/generation.py:538-542)
+    assert solver.context.shape == (6, 77, 768)             # cat([uncond.expand, cond]) of the CLIP hidden states
+    assert store.cur_step == 4 and len(store.attention_store["down_cross"]) == 4
+    img2, _, _ = run()
+    assert np.array_equal(img, img2)                        # same seed -> bit-identical image
+    assert img.std() > 0                                    # not a constant image
+    # latents instead of images, no controller
+    latents, _ = generation.runner(model=rev, prompt=prompts[:1], controller=None, solver=solver, is_cons_forward=True,
+                                   generator=torch.Generator().manual_seed(3), guidance_scale=7.0, tau1=1.0, tau2=1.0,
+                                   w_embed_dim=512, return_type="latent")
+    assert latents.shape == (1, 4, 64, 64) and torch.isfinite(latents).all()

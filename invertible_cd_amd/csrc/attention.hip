@@ -387,6 +387,149 @@ __global__ __launch_bounds__(256, OCC) void attn_fused_kernel(AttnK p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Cross-attention (context of <= 96 tokens: 77 CLIP tokens everywhere in this path).  K and V^T of one (batch, head) are
+// 2 x 77 x d halves: every wave loads ALL their MFMA fragments into registers once (straight from global memory in
+// fragment layout) and then streams query tiles: Q fragments in, 12 + 12 MFMAs (d = 64), one exact softmax over the 96
+// key slots, O out.  No LDS, no barriers, no online rescaling.  The kernel is HBM-bound by construction (Q in + O out,
+// arithmetic intensity ~ 77 flop/B): what matters is bytes in flight, so each wave prefetches the
+// next tile's Q fragments before it computes the current one.
+// ---------------------------------------------------------------------------------------------------------------
+template <int KS, int DT>
+__global__ __launch_bounds__(256, 2) void attn_cross_kernel(AttnK p, int tiles_per_wave) {
+    constexpr int KT = 3;                             // 32-key tiles (96 key slots)
+    constexpr int ST = 6;                             // 16-key steps of the PV product
+    const int tid = threadIdx.x, l = tid & 63, lr = l & 31, lh = l >> 5;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nchunk = (p.Nq + 32 * tiles_per_wave * 4 - 1) / (32 * tiles_per_wave * 4);      // blocks per (b, h)
+    int bid = blockIdx.x;
+    {
+        const int nblk = gridDim.x;
+        const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
+        bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    }
+    const int qc = bid % nchunk, bh = bid / nchunk;
+    const int b = bh / p.H, h = bh - b * p.H;
+    const half_t* Kb = p.k + (long long)b * p.Nk * p.ldk + h * p.d;
+    const half_t* Vb = p.vt + (long long)b * p.vt_bs + (long long)h * p.d * p.ldvt;
+    f16x8 z8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) z8[e] = (half_t)0.f;
+
+    // K fragments (A operand of S^T = K.Q^T): lane row = key 32kt + perm(lr) (bits 2,3 exchanged, see attn_fused_kernel)
+    const int prow = (lr & 0x13) | ((lr & 4) << 1) | ((lr & 8) >> 1);
+    f16x8 kf[KT][KS];
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int key = kt * 32 + prow, dd = ks * 16 + lh * 8;
+            kf[kt][ks] = (key < p.Nk && dd < p.d) ? *reinterpret_cast<const f16x8*>(Kb + (long long)key * p.ldk + dd) : z8;
+        }
+    // V^T fragments (A operand of O^T = V^T.P^T): lane row = head-dim 32i + lr, keys 16st + 8lh .. +7
+    f16x8 vf[ST][DT];
+#pragma unroll
+    for (int st = 0; st < ST; ++st)
+#pragma unroll
+        for (int i = 0; i < DT; ++i) {
+            const int row = i * 32 + lr, key = st * 16 + lh * 8;
+            vf[st][i] = (row < p.d && key < p.ldvt) ? *reinterpret_cast<const f16x8*>(Vb + (long long)row * p.ldvt + key) : z8;
+        }
+    const float c = p.scale_log2;
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int q_first = (qc * 4 + wv) * tiles_per_wave * 32;
+
+    auto load_q = [&](f16x8 (&qf)[KS], int q0) {
+        const int qrow = q0 + lr;
+        const half_t* qp = p.q + ((long long)b * p.Nq + qrow) * p.ldq + h * p.d;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int dd = ks * 16 + lh * 8;
+            qf[ks] = (qrow < p.Nq && dd < p.d) ? *reinterpret_cast<const f16x8*>(qp + dd) : z8;
+        }
+    };
+    f16x8 qa[KS], qb[KS];
+    load_q(qa, q_first);
+    auto tile = [&](f16x8 (&qf)[KS], f16x8 (&qn)[KS], int q0, bool more) {
+        if (more) load_q(qn, q0 + 32);                    // next tile's Q in flight under this tile's work
+        f32x16 s[KT];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt)
+                s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kt][ks], qf[ks], ks == 0 ? zero16 : s[kt], 0, 0, 0);
+        // element e of s[kt] is key 32kt + 16(e>>3) + 8lh + (e&7); mask the slots past Nk, exact softmax over the rest
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int key = kt * 32 + 16 * (e >> 3) + 8 * lh + (e & 7);
+                if (key >= p.Nk) s[kt][e] = -INFINITY;
+                mx = fmaxf(mx, s[kt][e]);
+            }
+        {
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+            mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+        }
+        const float nmc = -mx * c;
+        float rs = 0.f;
+        f16x8 pf[ST];
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float pv = __builtin_amdgcn_exp2f(fmaf(s[kt][e], c, nmc));
+                rs += pv;
+                pf[kt * 2 + (e >> 3)][e & 7] = (half_t)pv;
+            }
+        f32x16 o[DT];
+#pragma unroll
+        for (int st = 0; st < ST; ++st)
+#pragma unroll
+            for (int i = 0; i < DT; ++i)
+                o[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[st][i], pf[st], st == 0 ? zero16 : o[i], 0, 0, 0);
+        float l_tot;
+        {
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(rs), __float_as_uint(rs), false, false);
+            l_tot = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+        }
+        const float inv = 1.0f / l_tot;
+        const int qrow = q0 + lr;
+        if (qrow < p.Nq) {
+            half_t* op = p.out + ((long long)b * p.Nq + qrow) * p.ldo + h * p.d;
+#pragma unroll
+            for (int i = 0; i < DT; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int dc = i * 32 + 8 * g + 4 * lh;
+                    if (dc < p.d) {
+                        f16x4 v = {(half_t)(o[i][4 * g] * inv), (half_t)(o[i][4 * g + 1] * inv),
+                                   (half_t)(o[i][4 * g + 2] * inv), (half_t)(o[i][4 * g + 3] * inv)};
+                        *reinterpret_cast<f16x4*>(op + dc) = v;
+                    }
+                }
+        }
+    };
+    for (int t = 0; t < tiles_per_wave; t += 2) {         // two named Q fragment sets: no register copies
+        const int q0 = q_first + t * 32;
+        if (q0 >= p.Nq) break;
+        tile(qa, qb, q0, t + 1 < tiles_per_wave && q0 + 32 < p.Nq);
+        if (t + 1 < tiles_per_wave && q0 + 32 < p.Nq) tile(qb, qa, q0 + 32, t + 2 < tiles_per_wave && q0 + 64 < p.Nq);
+    }
+}
+
+template <int KS, int DT>
+int launch_attn_cross(AttnK k, hipStream_t st) {
+    // tiles per wave: amortise the K / V^T fragment loads (24 x 1 KiB per wave from L2) but keep >= ~4 blocks per CU
+    int tpw = 8;
+    while (tpw > 1 && (long long)((k.Nq + 128 * tpw - 1) / (128 * tpw)) * k.B * k.H < 1024) tpw >>= 1;
+    const int nchunk = (k.Nq + 128 * tpw - 1) / (128 * tpw);
+    hipLaunchKernelGGL((attn_cross_kernel<KS, DT>), dim3(nchunk * k.B * k.H), dim3(256), 0, st, k, tpw);
+    ICD_CHECK_LAUNCH("icd_attention_fused(cross)");
+    return ICD_OK;
+}
+
 template <int KS, int DT, int QT, int OCC = 2, int NST = 2>
 int launch_attn(AttnK k, hipStream_t st) {
     constexpr int smem = NST * (64 * 2 * KS * 16 + DT * 32 * 128);
@@ -436,6 +579,14 @@ extern "C" int icd_attention_fused_ex(const void* q, const void* k, const void* 
     hipStream_t st = (hipStream_t)stream;
     // two query tiles per wave when the sequence is long enough to still fill the chip with 256-row workgroups
     const bool wide = (long long)((Nq + 255) / 256) * B * H >= 512 && Nk >= 256;
+    // cross-attention with enough query tiles to give every wave >= 2 of them (so the 24 KiB of K / V^T fragments per
+    // wave amortise and the next Q tile prefetches): K / V^T fragments live in registers.  Shorter problems (SDXL's
+    // 1024-query layers at batch 8) are launch + latency bound either way (~20 us for 42 MB) and stay on the tiled kernel.
+    if (Nk <= 96 && d <= 64 && !a.causal && (long long)((Nq + 127) / 128) * B * H >= 2048) {
+        if (d <= 32) return launch_attn_cross<2, 1>(a, st);
+        if (d <= 48) return launch_attn_cross<3, 2>(a, st);
+        return launch_attn_cross<4, 2>(a, st);
+    }
     if (d <= 16) return launch_attn<1, 1, 1, 2, 2>(a, st);
     if (d <= 32) return launch_attn<2, 1, 1, 2, 2>(a, st);
     if (d <= 48) return wide ? launch_attn<3, 2, 2, 2, 2>(a, st) : launch_attn<3, 2, 1, 2, 2>(a, st);

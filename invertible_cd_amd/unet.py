@@ -178,6 +178,7 @@ class UNet2DConditionModel:
         # p2p plugin state (set by p2p.register_attention_control / Generator.get_noise_pred)
         self.attn_controller = None
         self.attn_cond_only = False
+        self._t_cache = {}
         self._live = []
 
     # ------------------------------------------------------------------ duck-typed nn.Module surface
@@ -248,11 +249,20 @@ class UNet2DConditionModel:
         io_dtype = sample.dtype if sample.dtype in (torch.float16, torch.float32) else torch.float16
         x = sample.to(device=dev, dtype=io_dtype).contiguous()
         B, _, H, W = x.shape
-        if torch.is_tensor(timestep):
+        if torch.is_tensor(timestep) and timestep.is_cuda:
             t = timestep.to(device=dev, dtype=torch.float32).reshape(-1)
+            t = t.expand(B).contiguous() if t.numel() == 1 else t.contiguous()
+        elif torch.is_tensor(timestep) and timestep.numel() > 1:
+            t = timestep.to(device=dev, dtype=torch.float32).reshape(-1).contiguous()
         else:
-            t = torch.tensor([float(timestep)], device=dev, dtype=torch.float32)
-        t = t.expand(B).contiguous() if t.numel() == 1 else t.contiguous()
+            # scalar host timestep (the loops pass CPU ints): one cached device tensor per (value, B) - no host->device
+            # copy per step, and nothing pageable inside a hipGraph capture
+            key = (float(timestep), B)
+            t = self._t_cache.get(key)
+            if t is None:
+                if len(self._t_cache) > 4096:
+                    self._t_cache.clear()
+                t = self._t_cache[key] = torch.full((B,), key[0], device=dev, dtype=torch.float32)
         ctx = encoder_hidden_states.to(device=dev, dtype=torch.float16).contiguous()
         if ctx.shape[0] != B or ctx.shape[2] != self.cfg.cross_dim:
             raise ValueError(f"encoder_hidden_states must be [{B}, n, {self.cfg.cross_dim}], got {tuple(ctx.shape)}")

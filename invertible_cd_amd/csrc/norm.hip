@@ -153,6 +153,109 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const half_t* __re
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// GroupNorm for small feature maps (H*W <= 1024: the 32x32 / 16x16 / 8x8 levels), ONE launch: a block owns one sample's
+// slab of GPB whole groups (CB = GPB * C/groups channels, a multiple of 8), reads it once for the statistics, reduces in
+// LDS in a fixed order, then re-reads it (L2-resident: <= 160 KiB per block) to normalise.  No workspace, no second
+// launch: at small batch the two-kernel form is pure launch latency (61 GroupNorms = 20 % of a B = 1 UNet evaluation).
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(GN_THREADS) void gn_small_kernel(const half_t* __restrict__ x0, int C0,
+                                                               const half_t* __restrict__ x1, int C1, int HW, int groups,
+                                                               int GPB, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, float eps, int silu,
+                                                               half_t* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int C = C0 + C1, cpg = C / groups, CB = GPB * cpg, nch = CB >> 3;
+    const int rpi = GN_THREADS / nch;
+    float* part = reinterpret_cast<float*>(smem_raw);          // [rpi][CB][2]
+    float* chan = part + rpi * CB * 2;                          // [CB][2]  per-channel totals
+    float* stat = chan + CB * 2;                                // [GPB][2] mean, rstd
+    const int tid = threadIdx.x, b = blockIdx.y;
+    const int c_lo = blockIdx.x * CB;
+    const int chunk = tid % nch, rsub = tid / nch;
+    const bool live = rsub < rpi;
+    const int ch = c_lo + chunk * 8;
+    const bool first = ch < C0;
+    const half_t* base = first ? x0 + (long long)b * HW * C0 + ch : x1 + (long long)b * HW * C1 + (ch - C0);
+    const int cs = first ? C0 : C1;
+    float s[8], q[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
+    if (live) {
+        int p = rsub;
+        for (; p + 3 * rpi < HW; p += 4 * rpi) {
+            f16x8 v0 = *reinterpret_cast<const f16x8*>(base + (long long)p * cs);
+            f16x8 v1 = *reinterpret_cast<const f16x8*>(base + (long long)(p + rpi) * cs);
+            f16x8 v2 = *reinterpret_cast<const f16x8*>(base + (long long)(p + 2 * rpi) * cs);
+            f16x8 v3 = *reinterpret_cast<const f16x8*>(base + (long long)(p + 3 * rpi) * cs);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float f0 = (float)v0[e], f1 = (float)v1[e], f2 = (float)v2[e], f3 = (float)v3[e];
+                s[e] += (f0 + f1) + (f2 + f3);
+                q[e] += (f0 * f0 + f1 * f1) + (f2 * f2 + f3 * f3);
+            }
+        }
+        for (; p < HW; p += rpi) {
+            f16x8 v = *reinterpret_cast<const f16x8*>(base + (long long)p * cs);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float f = (float)v[e]; s[e] += f; q[e] += f * f; }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            part[((rsub * CB) + chunk * 8 + e) * 2 + 0] = s[e];
+            part[((rsub * CB) + chunk * 8 + e) * 2 + 1] = q[e];
+        }
+    }
+    __syncthreads();
+    if (tid < CB) {                                             // per-channel totals over the row slots (fixed order)
+        float ss = 0.f, qq = 0.f;
+        for (int r = 0; r < rpi; ++r) { ss += part[(r * CB + tid) * 2]; qq += part[(r * CB + tid) * 2 + 1]; }
+        chan[tid * 2] = ss; chan[tid * 2 + 1] = qq;
+    }
+    __syncthreads();
+    if (tid < GPB) {
+        float ss = 0.f, qq = 0.f;
+        for (int c = 0; c < cpg; ++c) { ss += chan[(tid * cpg + c) * 2]; qq += chan[(tid * cpg + c) * 2 + 1]; }
+        const float n = (float)HW * (float)cpg;
+        const float mean = ss / n;
+        stat[tid * 2] = mean;
+        stat[tid * 2 + 1] = rsqrtf(fmaxf(qq / n - mean * mean, 0.f) + eps);
+    }
+    __syncthreads();
+    if (!live) return;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int g = (chunk * 8 + e) / cpg;
+        sc[e] = stat[g * 2 + 1] * gamma[ch + e];
+        sh[e] = beta[ch + e] - stat[g * 2] * sc[e];
+    }
+    half_t* ob = out + (long long)b * HW * C + ch;
+    auto norm8 = [&](const f16x8& v) {
+        f16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float f = (float)v[e] * sc[e] + sh[e];
+            if (silu) f = silu_f(f);
+            o[e] = (half_t)f;
+        }
+        return o;
+    };
+    int p = rsub;
+    for (; p + 3 * rpi < HW; p += 4 * rpi) {
+        f16x8 v0 = *reinterpret_cast<const f16x8*>(base + (long long)p * cs);
+        f16x8 v1 = *reinterpret_cast<const f16x8*>(base + (long long)(p + rpi) * cs);
+        f16x8 v2 = *reinterpret_cast<const f16x8*>(base + (long long)(p + 2 * rpi) * cs);
+        f16x8 v3 = *reinterpret_cast<const f16x8*>(base + (long long)(p + 3 * rpi) * cs);
+        *reinterpret_cast<f16x8*>(ob + (long long)p * C) = norm8(v0);
+        *reinterpret_cast<f16x8*>(ob + (long long)(p + rpi) * C) = norm8(v1);
+        *reinterpret_cast<f16x8*>(ob + (long long)(p + 2 * rpi) * C) = norm8(v2);
+        *reinterpret_cast<f16x8*>(ob + (long long)(p + 3 * rpi) * C) = norm8(v3);
+    }
+    for (; p < HW; p += rpi)
+        *reinterpret_cast<f16x8*>(ob + (long long)p * C) = norm8(*reinterpret_cast<const f16x8*>(base + (long long)p * cs));
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // LayerNorm: one wave per token row, row kept in registers (C <= 2048), exact two-pass mean / variance.
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void layernorm_kernel(const half_t* __restrict__ x, long long rows, int C,
@@ -358,12 +461,31 @@ extern "C" int icd_groupnorm(const void* x0, int32_t C0, const void* x1, int32_t
     ICD_CHECK_ARG(groups > 0 && groups <= 32 && C % groups == 0, "icd_groupnorm: bad group count %d for C=%d", groups, C);
     ICD_CHECK_ARG(C / 8 <= GN_THREADS, "icd_groupnorm: C=%d too large", C);
     ICD_CHECK_ARG(B > 0 && HW > 0, "icd_groupnorm: empty input");
+    hipStream_t st = (hipStream_t)stream;
+    {   // small maps: one launch, a block per (sample, slab of whole groups whose channel count is a multiple of 8)
+        const int cpg = C / groups;
+        int gpb = 1;
+        while ((gpb * cpg) % 8 != 0) gpb *= 2;                  // 8 / gcd(cpg, 8): 1, 2, 4 or 8
+        const int cb = gpb * cpg;
+        // the slab must not straddle the two concat sources mid-chunk (C0 % 8 == 0 holds) and must tile the groups
+        // measured: wins up to ~12 M elements (every level at small batch, the 16x16 / 8x8 levels at B = 32); above that the
+        // two streaming kernels with their wider rows are faster
+        if (HW <= 1024 && (long long)B * HW * C <= 12LL * 1024 * 1024 && groups % gpb == 0 && cb <= GN_THREADS) {
+            const int rpi_s = GN_THREADS / (cb / 8);
+            const size_t smem_s = ((size_t)rpi_s * cb * 2 + (size_t)cb * 2 + (size_t)gpb * 2) * sizeof(float);
+            if (smem_s <= 64 * 1024) {
+                hipLaunchKernelGGL(gn_small_kernel, dim3(groups / gpb, B), dim3(GN_THREADS), smem_s, st, (const half_t*)x0, C0,
+                                   (const half_t*)x1, C1, HW, groups, gpb, gamma, beta, eps, silu, (half_t*)out);
+                ICD_CHECK_LAUNCH("icd_groupnorm(small)");
+                return ICD_OK;
+            }
+        }
+    }
     const int pps = gn_pix_per_split(B, HW);
     const int nsplit = (HW + pps - 1) / pps;
     const int rpi = GN_THREADS / (C / 8);
     const size_t smem = (size_t)rpi * C * 2 * sizeof(float);
     ICD_CHECK_ARG(smem <= 64 * 1024, "icd_groupnorm: LDS budget exceeded");
-    hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(gn_stats_kernel, dim3(nsplit, B), dim3(GN_THREADS), smem, st, (const half_t*)x0, C0,
                        (const half_t*)x1, C1, HW, groups, pps, stats_ws);
     ICD_CHECK_LAUNCH("icd_groupnorm(stats)");

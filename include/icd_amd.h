@@ -167,6 +167,17 @@ int icd_conv_out(const void* x, int32_t B, int32_t H, int32_t W, int32_t Cin, co
 int icd_conv_out_n(const void* x, int32_t B, int32_t H, int32_t W, int32_t Cin, const void* w, const float* bias,
                    int32_t Cout, void* out_nchw, int32_t out_is_f32, void* stream);
 
+/* Prompt-to-prompt cross-attention edit, fused and in place (utils/p2p.py:190-207 with the replace_cross_attention of
+ * AttentionReplace :227, AttentionRefine :238-241, AttentionReweight :254-258 and the cross_replace_alpha blend):
+ *   probs[(g*heads + h), p, :] for g = 1 .. n_prompts-1  <-  probs[(0*heads + h), p, :] . A[g-1] + D[g-1] (*) itself
+ * probs: fp16 [n_prompts*heads, nq, ld] (the conditional rows of one Attention module), tokens nk <= 80 <= ld, ld % 8 == 0,
+ * pad columns zero (the executor's 80-column buffers for the 77 CLIP tokens);
+ * At: fp16 [n_prompts-1, 96, 80] = A transposed and zero padded (At[e][n][w] = A[e][w][n]), D: fp32 [n_prompts-1, 96] zero
+ * padded - built per step on the device from the controller's mapper / alphas / equalizer / cross_replace_alpha tensors
+ * (invertible_cd_amd/p2p.py).  The product runs on the matrix cores with fp32 accumulation. */
+int icd_p2p_cross_edit(void* probs, int32_t n_prompts, int32_t heads, int64_t nq, int32_t nk, int32_t ld, const void* At,
+                       const float* D, void* stream);
+
 /* Consistency boundary step, eps-prediction (utils/generation.py:136-155 == utils/generation_sdxl.py:112-132):
  *   x0 = (x - sigma_t*eps)/alpha_t ; out = alpha_s*x0 + sigma_s*eps, (alpha_s, sigma_s) := (1, 0) where s == 0.
  * coef: fp32 [B,4] = (alpha_t, sigma_t, alpha_s, sigma_s) per sample (host gathers them from the 1000-entry

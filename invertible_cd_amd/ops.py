@@ -216,6 +216,34 @@ def silu(x):
     return out
 
 
+def p2p_cross_edit_supported(probs):
+    return (probs.is_cuda and probs.dtype == torch.float16 and probs.dim() == 3 and probs.stride(2) == 1 and probs.shape[2] <= 80
+            and probs.stride(1) >= 80 and probs.stride(1) % 8 == 0 and probs.stride(0) == probs.shape[1] * probs.stride(1)
+            and probs.data_ptr() % 16 == 0)
+
+
+def p2p_pack_operator(A, D):
+    """A fp32 [E, T, T] (row w, column n), D fp32 [E, T]  ->  (At fp16 [E, 96, 80], Dp fp32 [E, 96]) for icd_p2p_cross_edit."""
+    E, T, _ = A.shape
+    At = torch.zeros((E, 96, 80), device=A.device, dtype=torch.float16)
+    At[:, :T, :T] = A.transpose(1, 2)
+    Dp = torch.zeros((E, 96), device=A.device, dtype=torch.float32)
+    Dp[:, :T] = D
+    return At, Dp
+
+
+def p2p_cross_edit(probs, n_prompts, At, Dp):
+    """In place on the conditional rows of one cross-attention module: probs fp16 [n_prompts*heads, nq, nk <= 80], a view
+    with row stride ld >= 80 (pad columns zero) of a contiguous buffer; (At, Dp) from p2p_pack_operator."""
+    assert p2p_cross_edit_supported(probs)
+    bh, nq, nk = probs.shape
+    assert bh % n_prompts == 0 and tuple(At.shape) == (n_prompts - 1, 96, 80) and tuple(Dp.shape) == (n_prompts - 1, 96)
+    assert At.dtype == torch.float16 and At.is_contiguous() and Dp.dtype == torch.float32 and Dp.is_contiguous()
+    _lib.check(_lib.load().icd_p2p_cross_edit(_p(probs), n_prompts, bh // n_prompts, nq, nk, probs.stride(1), _p(At), _p(Dp),
+                                              _stream()), "icd_p2p_cross_edit")
+    return probs
+
+
 ACT_SILU, ACT_QUICK_GELU, ACT_GELU = 0, 1, 2
 
 

@@ -230,11 +230,33 @@ class AttentionControlEdit(AttentionStore, abc.ABC):
     def replace_cross_attention(self, attn_base, att_replace):
         raise NotImplementedError
 
+    # ---- the same edit as one linear operator per step (device path: ops.p2p_cross_edit, csrc/p2p.hip) -------------
+    def cross_edit_terms(self, dev):
+        """(A0 [P-1, T, T], D0 [P-1, T]) fp32 on `dev` with  replace_cross_attention(base, cur)[b] == base . A0[b] + D0[b] * cur[b]."""
+        raise NotImplementedError
+
+    def cross_edit_operator(self, step, dev):
+        """The packed operator (ops.p2p_pack_operator) of  a_t * replace_cross_attention(base, cur) + (1 - a_t) * cur  for
+        this step, cached on `dev`."""
+        key = (int(step), str(dev))
+        cache = self.__dict__.setdefault("_edit_ops", {})
+        if key not in cache:                 # built on `dev` with torch ops: no host round trip (a sync inside the UNet's
+            A0, D0 = self.cross_edit_terms(dev)                           # hook callbacks would serialise CPU and GPU)
+            a = self.cross_replace_alpha[step].reshape(self.batch_size - 1, -1).to(dev, torch.float32)       # [P-1, T]
+            from . import ops
+            cache[key] = ops.p2p_pack_operator(A0 * a[:, None, :], D0 * a + (1.0 - a))
+        return cache[key]
+
     def forward(self, attn, is_cross: bool, place_in_unet: str):
         super().forward(attn, is_cross, place_in_unet)          # stores a VIEW: the stored tensor sees the edit below
         in_self_window = self.num_self_replace[0] <= self.cur_step < self.num_self_replace[1]
         if not (is_cross or in_self_window):
             return attn
+        if is_cross and attn.is_cuda:
+            from . import ops                                    # fused in-place HIP kernel (matrix cores, fp32 accumulate)
+            if ops.p2p_cross_edit_supported(attn):               # the executor's 80-column rows; else the torch path below
+                At, Dp = self.cross_edit_operator(self.cur_step, attn.device)
+                return ops.p2p_cross_edit(attn, self.batch_size, At, Dp)
         heads = attn.shape[0] // self.batch_size
         grouped = attn.reshape(self.batch_size, heads, *attn.shape[1:])
         base, edits = grouped[0], grouped[1:]
@@ -254,6 +276,10 @@ class AttentionReplace(AttentionControlEdit):
     def replace_cross_attention(self, attn_base, att_replace):
         return torch.einsum("hpw,bwn->bhpn", attn_base, self.mapper.to(attn_base.dtype))
 
+    def cross_edit_terms(self, dev):
+        m = self.mapper.to(dev, torch.float32)
+        return m, torch.zeros(m.shape[0], m.shape[2], device=dev)
+
 
 class AttentionRefine(AttentionControlEdit):
     def __init__(self, prompts, num_steps: int, cross_replace_steps, self_replace_steps, local_blend: Optional[LocalBlend] = None):
@@ -265,6 +291,14 @@ class AttentionRefine(AttentionControlEdit):
     def replace_cross_attention(self, attn_base, att_replace):
         gathered = attn_base[:, :, self.mapper].permute(2, 0, 1, 3)
         return gathered * self.alphas + att_replace * (1 - self.alphas)
+
+    def cross_edit_terms(self, dev):
+        idx = self.mapper.to(dev, torch.int64)                                 # [P-1, T]; -1 indexes the last token
+        al = self.alphas.reshape(idx.shape[0], -1).to(dev, torch.float32)     # [P-1, T]
+        T = idx.shape[1]
+        A0 = torch.zeros(idx.shape[0], T, T, device=dev)
+        A0.scatter_(1, (idx % T)[:, None, :], al[:, None, :])                 # A0[b, idx[b, n], n] = alphas[b, n]
+        return A0, 1.0 - al
 
 
 class AttentionReweight(AttentionControlEdit):
@@ -279,6 +313,15 @@ class AttentionReweight(AttentionControlEdit):
         if self.prev_controller is not None:
             attn_base = self.prev_controller.replace_cross_attention(attn_base, att_replace)
         return attn_base[None, :, :, :] * self.equalizer[:, None, None, :]
+
+    def cross_edit_terms(self, dev):
+        eq = self.equalizer.to(dev, torch.float32)                            # [P-1, T]
+        if self.prev_controller is not None:
+            A0, D0 = self.prev_controller.cross_edit_terms(dev)
+        else:
+            T = eq.shape[1]
+            A0, D0 = torch.eye(T, device=dev).expand(eq.shape[0], T, T), torch.zeros(eq.shape[0], T, device=dev)
+        return A0 * eq[:, None, :], D0 * eq
 
 
 def make_controller(prompts: List[str], is_replace_controller: bool, cross_replace_steps, self_replace_steps,

@@ -1,0 +1,100 @@
+"""p2p edit controllers on the GPU (fused in-place HIP kernel csrc/p2p.hip for the cross-attention edit, torch for the
+self-attention broadcast / LocalBlend) against the vectors captured from the reference's utils/p2p.py - the same goldens the
+CPU tests match bit for bit.  Probabilities are fp16 on the device, so comparisons use atol 3e-3 on values in [0, 1]."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from invertible_cd_amd import p2p
+from stubs import StubTokenizer
+
+pytestmark = pytest.mark.gpu
+HEADS = 2
+
+
+@pytest.fixture(scope="module")
+def g(golden_dir):
+    return np.load(os.path.join(golden_dir, "p2p.npz"))
+
+
+@pytest.fixture(autouse=True)
+def _globals():
+    p2p.tokenizer = StubTokenizer()
+    p2p.device = "cuda"
+    p2p.NUM_DDIM_STEPS = 4
+    p2p.LOW_RESOURCE = False
+    yield
+    p2p.device = "cpu"
+
+
+def _check(g, name, t):
+    t = t.float().cpu()
+    stats = g[name + "__stats"]
+    assert float(t.double().sum()) == pytest.approx(stats[0], rel=2e-3), name
+    assert float((t.double() ** 2).sum()) == pytest.approx(stats[1], rel=4e-3), name
+    sr, sc = g[name + "__stride"]
+    np.testing.assert_allclose(t[:, ::sr, ::sc].numpy(), g[name], rtol=0, atol=3e-3, err_msg=name)
+
+
+def _run(g, prefix, controller, n_prompts, seed, steps=4, cond_only=False, padded=False):
+    walk = list(zip(g["walk_place"].tolist(), [bool(x) for x in g["walk_cross"]], g["walk_n"].tolist()))
+    controller.num_att_layers = len(walk)
+    gen = torch.Generator().manual_seed(seed)
+    changed, i = [], 0
+    for step in range(steps):
+        for place, is_cross, n in walk:
+            m = 77 if is_cross else n
+            P32 = torch.softmax(torch.randn(2 * n_prompts * HEADS, n, m, generator=gen) * 2.0, dim=-1)
+            if padded and is_cross:                              # the executor's layout: row stride 80, 77 live columns
+                buf = torch.zeros(P32.shape[0], n, 80, dtype=torch.float16, device="cuda")
+                buf[:, :, :77] = P32.half()
+                P = buf[:, :, :77]
+            else:
+                P = P32.half().cuda()
+            before = P.clone()
+            half = P.shape[0] // 2
+            if cond_only:
+                R = controller.call_cond_only(P[half:], is_cross, place)
+                assert R.data_ptr() == P[half:].data_ptr()
+            else:
+                R = controller(P, is_cross, place)
+                assert R is P
+            assert torch.equal(P[:half], before[:half])
+            ch = not torch.equal(P, before)
+            changed.append(int(ch))
+            if ch:
+                _check(g, f"{prefix}_out{i}", P)
+            i += 1
+    assert changed == g[f"{prefix}_changed"].tolist()
+    assert controller.cur_step == int(g[f"{prefix}_cur_step"])
+    for key, lst in controller.attention_store.items():
+        assert len(lst) == int(g[f"{prefix}_storelen_{key}"])
+        for j, t in enumerate(lst):
+            _check(g, f"{prefix}_store_{key}_{j}", t)
+
+
+PROMPTS = ["a cat sitting on a bench", "a dog sitting on a bench"]
+
+
+@pytest.mark.parametrize("cond_only,padded", [(False, False), (True, True)])
+def test_replace_on_device(g, cond_only, padded):
+    c = p2p.make_controller(PROMPTS, True, 0.5, 0.5)
+    _run(g, "replace", c, 2, 101, cond_only=cond_only, padded=padded)
+
+
+def test_refine_on_device(g):
+    c = p2p.make_controller(["a cat sitting on a bench", "a fluffy cat sitting on a red bench"], False,
+                            {"default_": 0.8, "fluffy": (0.0, 0.4)}, 0.4)
+    _run(g, "refine", c, 2, 102)
+
+
+def test_reweight_chained_on_device(g):
+    c = p2p.make_controller(PROMPTS, True, 0.6, 0.2, equilizer_params={"words": ("dog",), "values": (3.0,)})
+    _run(g, "reweight", c, 2, 103)
+
+
+def test_three_prompt_group_on_device(g):
+    c = p2p.make_controller(["a cat sitting on a bench", "a dog sitting on a bench", "a cat sitting on a sofa"], True, 0.5, 0.25)
+    _run(g, "replace3", c, 3, 104, steps=2)

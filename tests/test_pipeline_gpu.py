@@ -42,3 +42,42 @@ def test_prompt_to_image_end_to_end():
                                    generator=torch.Generator().manual_seed(3), guidance_scale=7.0, tau1=1.0, tau2=1.0,
                                    w_embed_dim=512, return_type="latent")
     assert latents.shape == (1, 4, 64, 64) and torch.isfinite(latents).all()
+
+
+def test_image_file_inversion_then_edit(tmp_path):
+    """The reference's editing flow (running/sd1.5/edit.py:353-455): image file -> inversion.invert (VAE encode + 4-step
+    forward consistency inversion) -> make_controller (Replace + Reweight + LocalBlend) -> runner (4-step reverse with
+    dynamic guidance) -> decoded images.  Full SD1.5 sizes, synthetic weights; checks plumbing and invariants."""
+    from PIL import Image
+    from invertible_cd_amd import clip, generation, inversion, p2p, synthetic, vae
+    from invertible_cd_amd.loading import load_models
+    from invertible_cd_amd.schedulers import DDIMScheduler
+    rng = np.random.default_rng(0)
+    path = str(tmp_path / "img.png")
+    Image.fromarray(rng.integers(0, 255, (300, 400, 3), dtype=np.uint8)).save(path)          # load_512 resizes to 512x512
+    comp = {"vae_state_dict": synthetic.synthetic_vae_state_dict(vae.SD_VAE, seed=0, device="cuda", dtype=torch.float16),
+            "text_encoder_state_dict": synthetic.synthetic_clip_state_dict(clip.CLIP_VIT_L, seed=0)}
+    ldm, rev, fwd = load_models("synthetic:sd15", "cuda", reverse_checkpoint="synthetic:1", forward_checkpoint="synthetic:2",
+                                w_embed_dim=512, dtype="fp16", components=comp)
+    solver = generation.Generator(ldm, 50, DDIMScheduler.sd15(), forward_cons_model=fwd, reverse_cons_model=rev,
+                                  reverse_timesteps=[259, 519, 779, 999], forward_timesteps=[19, 259, 519, 779])
+    src, dst = "a photo of a cat sitting on a bench", "a photo of a dog sitting on a bench"
+    (image_gt, image_rec), latent, uncond = inversion.invert(solver, stop_step=50, is_cons_inversion=True, inv_guidance_scale=0.0,
+                                                             w_embed_dim=512, image_path=path, prompt=src, seed=1)
+    assert image_gt.shape == (512, 512, 3) and image_rec.shape == (512, 512, 3) and uncond is None
+    assert latent.shape == (1, 4, 64, 64) and torch.isfinite(latent).all()
+    p2p.tokenizer, p2p.device, p2p.NUM_DDIM_STEPS = rev.tokenizer, "cuda", 4
+    ctrl = p2p.make_controller([src, dst], True, 0.5, 0.5, blend_words=(("cat",), ("dog",)),
+                               equilizer_params={"words": ("dog",), "values": (2.0,)})
+    images, _ = generation.runner(model=rev, prompt=[src, dst], controller=ctrl, solver=solver, is_cons_forward=True,
+                                  latent=latent, guidance_scale=19.0, tau1=0.8, tau2=0.8, w_embed_dim=512)
+    p2p.device = "cpu"
+    assert images.shape == (2, 512, 512, 3) and images.dtype == np.uint8
+    assert ctrl.cur_step == 4 and isinstance(ctrl, p2p.AttentionReweight)
+    assert not np.array_equal(images[0], images[1])          # the edit prompt changed the second image
+    # NPI branch of invert: the conditional embedding repeated n_steps times (utils/inversion.py:101-102)
+    _, _, npi = inversion.invert(solver, stop_step=50, is_cons_inversion=True, inv_guidance_scale=0.0, w_embed_dim=512,
+                                 image_path=path, prompt=src, do_npi=True, seed=1)
+    assert len(npi) == solver.n_steps and npi[0].shape == (1, 77, 768)
+    with pytest.raises(NotImplementedError):
+        inversion.invert(solver, stop_step=50, is_cons_inversion=True, w_embed_dim=512, image_path=path, prompt=src, do_nti=True)

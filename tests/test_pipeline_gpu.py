@@ -81,3 +81,37 @@ def test_image_file_inversion_then_edit(tmp_path):
     assert len(npi) == solver.n_steps and npi[0].shape == (1, 77, 768)
     with pytest.raises(NotImplementedError):
         inversion.invert(solver, stop_step=50, is_cons_inversion=True, w_embed_dim=512, image_path=path, prompt=src, do_nti=True)
+
+
+def test_sdxl_prompts_to_pil_images():
+    """SDXL flow of running/sdxl/generate.py at reduced width: two CLIP encoders (clip.py, the second with projection) ->
+    compute_embeddings (penultimate hidden states concatenated, pooled text_embeds, time_ids) -> sample_deterministic
+    (4 steps) -> AutoencoderKL decode (the reference upcasts the VAE: `.to(float32)`) -> PIL images."""
+    from invertible_cd_amd import clip, generation_sdxl, synthetic, unet, vae
+    from invertible_cd_amd.pipelines import StableDiffusionXLPipeline
+    from invertible_cd_amd.schedulers import DDIMScheduler
+    from invertible_cd_amd.unet_config import SDXL
+    cfg = SDXL.scaled((64, 128, 256), cross_dim=128, heads=(2, 4, 8))
+    pooled_dim = cfg.add_in_dim - 6 * cfg.addition_time_embed_dim
+    c1 = clip.CLIPTextConfig(hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=1)
+    c2 = clip.CLIPTextConfig(hidden_size=64, intermediate_size=128, num_hidden_layers=3, num_attention_heads=1,
+                             hidden_act="gelu", projection_dim=pooled_dim)
+    enc1 = clip.CLIPTextModel(c1, synthetic.synthetic_clip_state_dict(c1, seed=1))
+    enc2 = clip.CLIPTextModel(c2, synthetic.synthetic_clip_state_dict(c2, True, seed=2), with_projection=True)
+    tok = synthetic.SyntheticTokenizer()
+    vcfg = vae.SDXL_VAE.scaled((32, 64, 64, 64))
+    v = vae.AutoencoderKL(vcfg, synthetic.synthetic_vae_state_dict(vcfg, seed=3))
+    u = unet.UNet2DConditionModel(cfg, synthetic.synthetic_state_dict(cfg, seed=4), dtype=torch.float16)
+    pipe = StableDiffusionXLPipeline(u, DDIMScheduler.sdxl(), vae=v, tokenizer=tok, tokenizer_2=tok, text_encoder=enc1,
+                                     text_encoder_2=enc2)
+    prompts = ["a photo of a cat", "a dog on a bench"]
+    emb_fn = lambda p, o, c: generation_sdxl.compute_embeddings(p, o, c, 0, [enc1, enc2], [tok, tok], is_train=False)
+    e = emb_fn(prompts, [(1024, 1024)] * 2, [(0, 0)] * 2)
+    assert e["prompt_embeds"].shape == (2, 77, 128) and e["text_embeds"].shape == (2, pooled_dim) and e["time_ids"].shape == (2, 6)
+    lat = torch.randn(2, 4, 16, 16, generator=torch.Generator().manual_seed(0)).cuda().half()
+    images, latents = generation_sdxl.sample_deterministic(pipe, prompts, latents=lat, num_inference_steps=4, guidance_scale=7.0,
+                                                           is_sdxl=True, timesteps=[249, 499, 699, 999],
+                                                           compute_embeddings_fn=emb_fn, return_latent=True)
+    assert len(images) == 2 and images[0].size == (128, 128) and latents.shape == (2, 4, 16, 16)
+    assert v.dtype == torch.float32                          # the reference's upcast request reached the VAE object
+    assert np.asarray(images[0]).std() > 0 and not np.array_equal(np.asarray(images[0]), np.asarray(images[1]))

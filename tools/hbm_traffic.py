@@ -17,7 +17,7 @@ def family(k):
     m = re.search(r"gemm(?:_big)?_kernel<(\d)", k)
     if m:
         return "gemm_dense" if m.group(1) == "0" else "gemm_conv"
-    for pat, f in (("splitk_reduce", "splitk_reduce"), ("attn_fused", "attn_fused"), ("gn_", "groupnorm"), ("layernorm", "layernorm"),
+    for pat, f in (("splitk_reduce", "splitk_reduce"), ("attn_fused", "attn_fused"), ("attn_cross", "attn_fused"), ("gn_", "groupnorm"), ("layernorm", "layernorm"),
                    ("softmax", "softmax")):
         if pat in k:
             return f

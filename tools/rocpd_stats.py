@@ -39,7 +39,7 @@ def main(path):
             f = "gemm_dense" if m.group(1) == "0" else "gemm_conv"
         elif "splitk_reduce" in n:
             f = "splitk_reduce (bench.py counts it inside the GEMM family that launched it)"
-        elif "attn_fused" in n:
+        elif "attn_fused" in n or "attn_cross" in n:
             f = "attn_fused"
         elif "gn_" in n:
             f = "groupnorm"

@@ -547,7 +547,10 @@ extern "C" int icd_gemm(const icd_gemm_desc* d, void* stream) {
     // ---- high-intensity tiles (gemm_big.hip), chosen from BIG_TILES by the cost model below ------------------------
     {
         const bool conv_fast = d->mode == 1 && ((d->C0 + d->C1) % 64 == 0) && (d->C0 % 64 == 0);
-        const bool base_ok = batch == 1 && !trans && (d->mode == 0 || conv_fast) && d->M >= 256 && (d->Nw <= 0 || d->Nw >= d->N) &&
+        // transposed (V^T) outputs take the big tiles when a 32-row tile never straddles two samples and no pad columns
+        // have to be zeroed (ldo == rows_per_sample); otherwise the 128-wide kernel's general epilogue handles them
+        const bool trans_ok = !trans || (d->rows_per_sample % 32 == 0 && d->M % 32 == 0 && d->ldo == d->rows_per_sample);
+        const bool base_ok = batch == 1 && trans_ok && (d->mode == 0 || conv_fast) && d->M >= 256 && (d->Nw <= 0 || d->Nw >= d->N) &&
                              (d->K % 64 == 0) && !(d->flags & ICD_GEMM_TUNE_NO_BIG);
         // Cost model in units of "one k-tile of a 256x256 block" (calibrated with tools/gemm_bench.py, same-box A/B):
         // a block owns its CU, so a launch costs rounds x (k-tiles x tk + fixed), fixed = prologue + exposed epilogue.

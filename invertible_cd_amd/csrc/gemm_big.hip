@@ -238,8 +238,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_big_kernel(GemmK p) {
     const bool geglu = p.flags & ICD_GEMM_GEGLU;
     const bool out_f32 = p.flags & ICD_GEMM_OUT_F32;
     constexpr int LDW = 68;                                      // floats per staged row (64 + 4: conflict-free b128 writes)
+    constexpr int LDT = 36;                                      // transposed patch: [64 n][32 m + 4]
+    const bool trans = p.flags & ICD_GEMM_OUT_TRANS;
     __syncthreads();
-    float* wst = reinterpret_cast<float*>(smem) + wv * (32 * LDW);
+    float* wst = reinterpret_cast<float*>(smem) + wv * (trans ? 64 * LDT : 32 * LDW);
     float* part = p.ksplit > 1 ? p.partial + (long long)split * p.M * p.N : nullptr;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -247,6 +249,32 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_big_kernel(GemmK p) {
 #pragma unroll
         for (int j0 = 0; j0 < TN; j0 += 2) {
             const int jn = (TN - j0) >= 2 ? 2 : 1;               // j-tiles in this group (compile-time after unrolling)
+            if (trans) {
+                // V^T epilogue: out[(b*N + n)*ldo + key], (b, key) = divmod(m, rows_per_sample).  The patch is staged
+                // transposed ([n][m]); lane l then owns column n = l with the 32 consecutive keys of this i-tile
+                // (the planner guarantees rows_per_sample % 32 == 0 and M % 32 == 0: a tile never straddles samples).
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    if (jj >= jn) break;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        wst[(jj * 32 + 8 * (e >> 2) + 4 * lh + (e & 3)) * LDT + lr] = acc[i][j0 + jj][e];
+                }
+                const int n = (wn * TN + j0) * 32 + l;               // column inside the block tile
+                if (l < jn * 32 && n0 + n < p.N && mrow0 < p.M) {
+                    const int b = mrow0 / p.rps, key0 = mrow0 - b * p.rps;
+                    half_t* dst = reinterpret_cast<half_t*>(p.out) + ((long long)b * p.N + n0 + n) * p.ldo + key0;
+                    const float* sp = wst + l * LDT;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        f32x4 v0 = *reinterpret_cast<const f32x4*>(sp + 8 * c), v1 = *reinterpret_cast<const f32x4*>(sp + 8 * c + 4);
+                        f16x8 o = {(half_t)(v0[0] * p.alpha), (half_t)(v0[1] * p.alpha), (half_t)(v0[2] * p.alpha), (half_t)(v0[3] * p.alpha),
+                                   (half_t)(v1[0] * p.alpha), (half_t)(v1[1] * p.alpha), (half_t)(v1[2] * p.alpha), (half_t)(v1[3] * p.alpha)};
+                        *reinterpret_cast<f16x8*>(dst + 8 * c) = o;
+                    }
+                }
+                continue;
+            }
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj) {
                 if (jj >= jn) break;

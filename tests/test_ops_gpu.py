@@ -121,6 +121,39 @@ def test_conv_big_tile(cfg):
     assert rel_l2(out, to_nhwc(ref + rb.float()[:, :, None, None]) + res.float()) < TOL
 
 
+@pytest.mark.parametrize("cfg", [
+    dict(B=2, H=15, W=9, C0=64, C1=0, Co=128, stride=1, up=False, pad_hi=False, big=False),     # odd, non-square
+    dict(B=1, H=13, W=21, C0=128, C1=64, Co=256, stride=1, up=False, pad_hi=False, big=True),   # concat, ragged M in big tiles
+    dict(B=2, H=14, W=10, C0=64, C1=0, Co=64, stride=2, up=False, pad_hi=False, big=False),     # stride 2, even sizes
+    dict(B=2, H=15, W=11, C0=64, C1=0, Co=64, stride=2, up=False, pad_hi=False, big=False),     # stride 2, odd sizes
+    dict(B=1, H=7, W=5, C0=64, C1=0, Co=256, stride=1, up=True, pad_hi=False, big=True),        # upsample of an odd map
+    dict(B=2, H=12, W=20, C0=64, C1=0, Co=64, stride=2, up=False, pad_hi=True, big=False),      # VAE Downsample2D padding
+    dict(B=1, H=16, W=24, C0=128, C1=0, Co=256, stride=2, up=False, pad_hi=True, big=True),
+    dict(B=2, H=9, W=9, C0=24, C1=8, Co=40, stride=1, up=False, pad_hi=False, big=False),       # ragged channels (general loader)
+])
+def test_conv_odd_and_non_square_maps(cfg):
+    """Spatial sizes the UNets never use (they are powers of two) but the VAE accepts (any multiple of 8 in pixels)."""
+    ops = _ops()
+    B, H, W, C0, C1, Co = cfg["B"], cfg["H"], cfg["W"], cfg["C0"], cfg["C1"], cfg["Co"]
+    x = r16(B, C0, H, W, seed=165)
+    x2 = r16(B, C1, H, W, seed=166) if C1 else None
+    Cin = C0 + C1
+    w = r16(Co, Cin, 3, 3, seed=167, scale=(9 * Cin) ** -0.5)
+    bias = torch.randn(Co, generator=torch.Generator().manual_seed(168)) * 0.1
+    xin = x.float() if x2 is None else torch.cat([x.float(), x2.float()], 1)
+    if cfg["up"]:
+        xin = F.interpolate(xin, scale_factor=2.0, mode="nearest")
+    if cfg["pad_hi"]:
+        ref = F.conv2d(F.pad(xin, (0, 1, 0, 1)), w.float(), bias, stride=2)
+    else:
+        ref = F.conv2d(xin, w.float(), bias, stride=cfg["stride"], padding=1)
+    out = ops.conv3x3(to_nhwc(x).cuda(), B, H, W, ops.pack_conv_weight(w).cuda(), bias.cuda(),
+                      x2=None if x2 is None else to_nhwc(x2).cuda(), stride=cfg["stride"], upsample=cfg["up"],
+                      pad_hi=cfg["pad_hi"], debug_flags=ops.FORCE_BIG_TILE if cfg["big"] else 0)
+    assert out.shape[0] == B * ref.shape[2] * ref.shape[3]
+    assert rel_l2(out, to_nhwc(ref)) < TOL
+
+
 def test_gemm_rowbias_alpha_f32():
     ops = _ops()
     B, HW, K, N = 3, 64, 128, 192

@@ -54,6 +54,19 @@ def test_encode_mean_matches_oracle(widths, fused):
     assert e < 3e-3
 
 
+def test_odd_latent_sizes_round_trip_shapes_and_parity():
+    """Latents with odd height / width (72 x 104 pixel images): every level of the decoder and encoder sees odd maps."""
+    cfg, sd, ocfg, vae, vae_ref = _setup((32, 64, 64, 64), seed=9)
+    m = vae.AutoencoderKL(cfg, sd)
+    z = (torch.randn(2, 4, 9, 13, generator=torch.Generator().manual_seed(10)) * 1.5).half().float()
+    got = m.decode(z.cuda())["sample"].float().cpu()
+    ref = vae_ref.decode(sd, ocfg, z)
+    assert got.shape == ref.shape == (2, 3, 72, 104) and rel_l2(got, ref) < 3e-3
+    x = ref.clamp(-1, 1).half().float()
+    e = rel_l2(m.encode(x.cuda())["latent_dist"].mean.float().cpu(), vae_ref.encode_mean(sd, ocfg, x))
+    assert e < 3e-3
+
+
 def test_chunking_and_interface():
     """max_chunk splits the batch without changing results; return_dict=False / fp32 output / error behaviour."""
     cfg, sd, ocfg, vae, vae_ref = _setup((32, 64, 64, 64), seed=7)

@@ -560,6 +560,7 @@ extern "C" int icd_gemm(const icd_gemm_desc* d, void* stream) {
         for (int ci = 0; ci < NUM_BIG_TILES && base_ok; ++ci) {
             const BigTile& c = BIG_TILES[ci];
             if (forced >= 0 && ci != forced) continue;
+            if (ci == 4 && (d->mode != 0 || (nk_total & 1) || nk_total < 2)) continue;     // asm tile: dense, even k-tile count
             if (d->N % c.bn != 0 || (geglu && !c.geglu_ok) || ((d->flags & ICD_GEMM_TUNE_BN256) && c.bn != 256)) continue;
             const long long b0 = (long long)((d->M + c.bm - 1) / c.bm) * (d->N / c.bn);
             int smax = 1;
@@ -568,6 +569,7 @@ extern "C" int icd_gemm(const icd_gemm_desc* d, void* stream) {
                 while (smax > 1 && nk_total / smax < 8) --smax;
                 while (smax > 1 && (long long)smax * d->M * d->N * 4 > d->splitk_ws_bytes) --smax;
             }
+            if (ci == 4) smax = 1;
             for (int sx = 1; sx <= smax; ++sx) {
                 const long long bt = b0 * sx;
                 const long long full = bt / 256, rem = bt % 256;

@@ -44,12 +44,14 @@ __device__ __forceinline__ float gelu_fast(float x) { return 0.5f * x * (1.0f + 
 // chip (about 1.3 - 1.7 us depending on the box's clocks).  tk_full applies when >= 200 CUs are busy (chip-level
 // ceiling: the same block runs about 10 - 20 % slower), tk_part when <= 160.
 struct BigTile { int bm, bn; bool geglu_ok; double tk_part, tk_full, fixed; };
-constexpr int NUM_BIG_TILES = 4;
+constexpr int NUM_BIG_TILES = 5;
 constexpr BigTile BIG_TILES[NUM_BIG_TILES] = {
     {256, 256, true, 1.00, 1.08, 9.5},
     {256, 320, false, 1.07, 1.30, 15.3},
     {192, 256, true, 0.70, 0.76, 9.6},
     {128, 320, false, 0.72, 0.80, 7.2},
+    {256, 256, true, 99.0, 99.0, 9.5},      // [4] generated asm main loop, 4 waves of 128 x 128 (dense, even k-tile count, no split-K):
+                                            //     forced only - measured equal per k-tile, slower per launch
 };
 int launch_big(const GemmK& k, int cfg, hipStream_t st);     // cfg = index into BIG_TILES
 

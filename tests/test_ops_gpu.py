@@ -154,6 +154,28 @@ def test_conv_odd_and_non_square_maps(cfg):
     assert rel_l2(out, to_nhwc(ref)) < TOL
 
 
+@pytest.mark.parametrize("M,N,K,geglu", [(256, 256, 128, False), (300, 512, 384, False), (1024, 1280, 1280, False), (700, 512, 256, True)])
+def test_gemm_hand_scheduled_tile_matches_compiler_tiles(M, N, K, geglu):
+    """Configuration 4 of the big-tile family (256x256, four waves of 128x128, main loop generated by csrc/gen_gemm_asm.py) is
+    never picked by the planner's cost model (it is not faster) but must stay correct: same tile, same
+    fp32 accumulation order as the 8-wave 256x256 tile (bit-identical unless that one is split along K), incl. ragged M,
+    bias / residual and GEGLU."""
+    ops = _ops()
+    a, w = r16(M, K, seed=81).cuda(), r16(N, K, seed=82, scale=K ** -0.5).cuda()
+    bias = (torch.randn(N, generator=torch.Generator().manual_seed(83)) * 0.1).cuda()
+    res = None if geglu else r16(M, N, seed=84).cuda()
+    ref = ops.gemm(a, w, bias=bias, resid=res, geglu=geglu, debug_flags=0x1000000)       # ICD_GEMM_TUNE_BIG_CFG(0)
+    out = ops.gemm(a, w, bias=bias, resid=res, geglu=geglu, debug_flags=0x5000000)       # ICD_GEMM_TUNE_BIG_CFG(4)
+    assert rel_l2(out, ref) < 1e-4
+    want = a.float() @ w.float().t() + bias.float()
+    if geglu:
+        want = want.reshape(M, N // 64, 2, 32)
+        want = (want[:, :, 0] * F.gelu(want[:, :, 1])).reshape(M, N // 2)
+    else:
+        want = want + res.float()
+    assert rel_l2(out, want) < TOL
+
+
 def test_gemm_rowbias_alpha_f32():
     ops = _ops()
     B, HW, K, N = 3, 64, 128, 192

@@ -8,7 +8,10 @@ A "step" = one pass of the hot path over one batch of synthetic latents: the Gen
 on for one GPU: configs[1] "iCD-SD1.5 4-step reverse, batch=32, fp16, 1xMI355X".  Inputs (latents, context, weights) are
 resident in HBM before the timed region.  N > 1: one process per GPU (torchrun), the batch is sharded data-parallel
 (B per GPU, weak scaling), no collective inside the loop, ONE all-gather (RCCL) of the produced latents at the end of
-the timed region.  VAE decode / text encoding are outside this path and not timed.
+the timed region (`--gather images`: per-rank VAE decode + uint8 images instead).  VAE decode / text encoding are
+outside this path and not part of `value` by default.  `python bench.py --gpus N` without a
+launcher re-executes itself under torch.distributed.run with N ranks.  The default run (no --arch/--batch) also times
+SDXL at 8 images/GPU (BASELINE configs[3] per-GPU share) and reports it as the "sdxl" object of the same JSON line.
 
 Extra objects on the JSON line: "roofline" for the dominant kernel family (HIP-event durations recorded by the executor
 on the launch stream during the timed region, algorithmic FLOPs) and "cpu_baseline" (the CPU oracle restating the
@@ -42,7 +45,26 @@ def parse():
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
     ap.add_argument("--no-ref-batching", action="store_true",
                     help="skip the extra CFG-doubled measurement (use under rocprofv3 so kernel stats match the timed region)")
+    ap.add_argument("--gather", default="latents", choices=["latents", "images"],
+                    help="payload of the ONE end-of-run all-gather: fp16 latents (default; VAE decode is outside the timed "
+                         "path, SURVEY 8d) or uint8 images [N,512,512,3] after a per-rank VAE decode inside the timed region "
+                         "(running/sd1.5/generate.py:372-383)")
+    ap.add_argument("--no-sdxl", action="store_true", help="skip the additional SDXL B=8 measurement of the default run")
     return ap.parse_args()
+
+
+def spawn_ranks(a, argv):
+    """`python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run, one process per GPU (RCCL)."""
+    import subprocess
+    n_dev = torch.cuda.device_count()
+    if n_dev < a.gpus:
+        raise SystemExit(f"bench.py --gpus {a.gpus}: only {n_dev} GPU(s) visible on this node")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    port = env.get("MASTER_PORT", "29533")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def build_sd15(batch, device):
@@ -103,8 +125,9 @@ def hbm_traffic(arch, batch, family):
         except Exception:
             continue
         if d.get("arch") == arch and d.get("per_gpu_batch") == batch and family in d.get("families", {}):
-            best = d["families"][family]["traffic_bytes"]           # latest round wins (sorted by name)
-    return best
+            # latest round wins (sorted by name); the file records the sha of the kernel sources it was measured on
+            best = (d["families"][family]["traffic_bytes"], os.path.join("profiles", os.path.basename(f)), d.get("kernels_sha"))
+    return best or (None, None, None)
 
 
 def cpu_baseline(arch, sd, cfg):
@@ -144,21 +167,26 @@ def cpu_baseline(arch, sd, cfg):
             "per_unet_ms": dt * 1e3}
 
 
-def main():
-    a = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = f"cuda:{local_rank}"
+def csrc_sha():
+    """sha1 over the kernel sources: lets a reader see whether a committed PMC summary was taken on these kernels."""
+    import glob, hashlib
+    h = hashlib.sha1()
+    for f in sorted(glob.glob(os.path.join(ROOT, "invertible_cd_amd", "csrc", "*"))):
+        if f.endswith((".hip", ".h", ".inc", ".cpp")):
+            h.update(open(f, "rb").read())
+    return h.hexdigest()[:12]
+
+
+def to_uint8_images(img):
+    """[-1,1] NCHW -> uint8 NHWC, the payload running/sd1.5/generate.py:372-378 gathers."""
+    return ((img.float() / 2 + 0.5).clamp(0, 1) * 255).round().to(torch.uint8).permute(0, 2, 3, 1).contiguous()
+
+
+def run_arch(a, arch, batch, steps, warmup, device, world, rank, primary):
+    """Warm up, time `steps` passes of the hot path + the ONE end-of-run all-gather, return the JSON fields."""
     import torch.distributed as dist
     from invertible_cd_amd import _lib, dist_utils
-    if world > 1:
-        dist_utils.init()
-    batch = a.batch or (32 if a.arch == "sd15" else 8)
-    step, solver, sd, cfg = (build_sd15 if a.arch == "sd15" else build_sdxl)(batch, device)
+    step, solver, sd, cfg = (build_sd15 if arch == "sd15" else build_sdxl)(batch, device)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -166,9 +194,20 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    vae_m = None
+    if (rank == 0 and not a.no_vae and primary) or a.gather == "images" or (world > 1 and primary):
+        from invertible_cd_amd import synthetic, vae as vae_mod
+        vcfg = vae_mod.SD_VAE if arch == "sd15" else vae_mod.SDXL_VAE
+        vsd = synthetic.synthetic_vae_state_dict(vcfg, seed=0, device=device, dtype=torch.float16)
+        vae_m = vae_mod.AutoencoderKL(vcfg, vsd, device=device, max_chunk=8 if arch == "sd15" else 2)
+        del vsd
+
+    def decode_u8(lat):
+        return to_uint8_images(vae_m.decode((lat.float() / vae_m.config.scaling_factor).clamp(-30, 30))["sample"])
+
     fam_table = None
-    for i in range(a.warmup):
-        if i == a.warmup - 1 and not a.no_profile:      # last warm-up pass: per-family table (every launch recorded)
+    for i in range(warmup):
+        if i == warmup - 1 and not a.no_profile:      # last warm-up pass: per-family table (every launch recorded)
             torch.cuda.synchronize()
             _lib.profile_enable(True)
             step()
@@ -177,6 +216,8 @@ def main():
             _lib.profile_enable(False)
         else:
             step()
+    if a.gather == "images":
+        decode_u8(step()[:2])
     sync_all()
     # dominant family = the one carrying the most algorithmic work (stable from run to run, unlike a max over times
     # when two families are within a few per cent of each other)
@@ -186,9 +227,11 @@ def main():
         _lib.profile_enable(True, only=[dominant] if dominant else None)
     outs = []
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    for _ in range(steps):
         outs.append(step())
     local = torch.stack(outs).reshape(-1, *outs[0].shape[1:]).to(torch.float16)
+    if a.gather == "images":
+        local = torch.cat([decode_u8(local[i:i + batch]) for i in range(0, local.shape[0], batch)])
     ids = torch.arange(local.shape[0], device=device, dtype=torch.int64) * world + rank
     gathered, gids = dist_utils.gather_samples(local, ids)                # ONE all-gather at the end (RCCL over xGMI)
     sync_all()
@@ -201,11 +244,27 @@ def main():
         tt = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    assert gathered.shape[0] == batch * a.steps * world and bool(torch.isfinite(gathered).all())
+    assert gathered.shape[0] == batch * steps * world and bool(torch.equal(gids, torch.arange(batch * steps * world, device=device)))
+    assert gathered.dtype == torch.uint8 or bool(torch.isfinite(gathered).all())
+
+    # N > 1: the reference's payload - uint8 images + int64 ids in ONE all-gather (running/sd1.5/generate.py:372-383) -
+    # timed on its own after the timed region (the per-rank VAE decode before it is the separate vae_decode leg)
+    image_gather = None
+    if world > 1 and primary and vae_m is not None and a.gather != "images":
+        u8 = decode_u8(outs[-1])
+        ids1 = torch.arange(batch, device=device, dtype=torch.int64) * world + rank
+        dist_utils.gather_samples(u8, ids1)
+        sync_all()
+        tg = time.perf_counter()
+        g8, _ = dist_utils.gather_samples(u8, ids1)
+        sync_all()
+        tg = time.perf_counter() - tg
+        image_gather = {"payload": f"uint8 [{batch},{u8.shape[1]},{u8.shape[2]},3] per rank + int64 ids", "ms": round(tg * 1e3, 3),
+                        "bytes_per_rank": int(u8.numel()), "gathered_images": int(g8.shape[0])}
 
     # the same loop with the reference's CFG-doubled batching (uncond rows computed and discarded), for the record
     ref_batching = None
-    if solver is not None and rank == 0 and not a.no_ref_batching:
+    if solver is not None and rank == 0 and primary and not a.no_ref_batching:
         solver.eliminate_dead_uncond = False
         step(); torch.cuda.synchronize()
         t1 = time.perf_counter()
@@ -216,49 +275,47 @@ def main():
         solver.eliminate_dead_uncond = True
 
     # VAE decode of one step's latents, timed separately ("VAE decode ... reported separately"); it is
-    # NOT part of `value`.  SD VAE width for both architectures; SDXL latents are 128x128 -> 1024x1024 images.
+    # NOT part of `value` unless --gather images.  SDXL latents are 128x128 -> 1024x1024 images.
     vae_leg = None
-    if rank == 0 and not a.no_vae:
-        from invertible_cd_amd import synthetic, vae as vae_mod
-        vcfg = vae_mod.SD_VAE if a.arch == "sd15" else vae_mod.SDXL_VAE
-        vsd = synthetic.synthetic_vae_state_dict(vcfg, seed=0, device=device, dtype=torch.float16)
-        m = vae_mod.AutoencoderKL(vcfg, vsd, device=device, max_chunk=8 if a.arch == "sd15" else 2)
-        del vsd
-        lat = (outs[-1].float() / vcfg.scaling_factor).clamp(-30, 30)
-        m.decode(lat[:2]); torch.cuda.synchronize()
+    if rank == 0 and not a.no_vae and primary and vae_m is not None:
+        lat = (outs[-1].float() / vae_m.config.scaling_factor).clamp(-30, 30)
+        vae_m.decode(lat[:2]); torch.cuda.synchronize()
         tv = time.perf_counter()
-        img = m.decode(lat)["sample"]
+        img = vae_m.decode(lat)["sample"]
         torch.cuda.synchronize()
         tv = time.perf_counter() - tv
         ok = bool(torch.isfinite(img).all())
-        per_img_unet = dt / (batch * a.steps)
+        per_img_unet = dt / (batch * steps)
         vae_leg = {"decode_ms_per_image": round(tv / batch * 1e3, 3), "decode_images_per_sec": round(batch / tv, 2),
                    "finite": ok, "images_per_sec_unet_plus_decode_1gpu": round(1.0 / (per_img_unet + tv / batch), 2),
                    "note": "AutoencoderKL decode of one step's latents on the same HIP operators, synthetic weights; not in `value`"}
-        del m, img
-
+        del img
+    del vae_m, gathered, local, outs
     if rank != 0:
-        return
-    images = batch * a.steps * world
+        return None, sd, cfg
+    images = batch * steps * world
     value = images / dt
-    algo = ALGO_TFLOP_PER_SAMPLE_FWD[a.arch] * 4e12                       # algorithmic FLOP per image (cond rows only)
+    algo = ALGO_TFLOP_PER_SAMPLE_FWD[arch] * 4e12                       # algorithmic FLOP per image (cond rows only)
+    payload = "uint8 images after a per-rank VAE decode" if a.gather == "images" else "fp16 latents"
     out = {
-        "metric": "4-step iCD images/sec (SD1.5 512^2)" if a.arch == "sd15" else "4-step iCD images/sec (SDXL 1024^2)",
-        "value": round(value, 3), "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "metric": "4-step iCD images/sec (SD1.5 512^2)" if arch == "sd15" else "4-step iCD images/sec (SDXL 1024^2)",
+        "value": round(value, 3), "unit": "images/sec", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": round(dt / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f16", "data": "synthetic",
         "config": {"workload": ("iCD-SD1.5 4-step reverse, batch=32/GPU, fp16, 64x64 latents (512x512), w-embedding gs=7, "
-                                "timesteps [999,779,519,259]" if a.arch == "sd15" else
+                                "timesteps [999,779,519,259]" if arch == "sd15" else
                                 "iCD-SDXL 4-step reverse, batch=8/GPU, fp16, 128x128 latents (1024x1024), gs=7, timesteps [999,699,499,249]"),
                    "per_gpu_batch": batch, "global_batch": batch * world, "unet_evals_per_step": 4,
-                   "dead_uncond_rows_eliminated": a.arch == "sd15", "lora_fused": a.arch == "sd15",
-                   "parallelism": f"dp{world}", "collective": "one all-gather of the fp16 latents at the end of the timed region"},
-        "per_unet_ms": round(dt / a.steps / 4 * 1e3, 3),
+                   "dead_uncond_rows_eliminated": arch == "sd15", "lora_fused": arch == "sd15",
+                   "parallelism": f"dp{world}", "collective": f"one all-gather (RCCL) of the {payload} + int64 ids at the end of the timed region"},
+        "per_unet_ms": round(dt / steps / 4 * 1e3, 3),
         "end_to_end_algorithmic_tflops_per_gpu": round(value / world * algo / 1e12, 1),
         "end_to_end_frac_of_mfma_peak": round(value / world * algo / PEAK_MFMA_F16, 4),
     }
     if ref_batching is not None:
         out["value_reference_cfg_doubled_batching"] = round(ref_batching, 3)
+    if image_gather is not None:
+        out["image_gather"] = image_gather
     if prof is not None:
         fam = fam_table or {k: v for k, v in prof.items() if v["launches"]}
         dom = dominant or max(fam, key=lambda k: fam[k]["ms"])
@@ -271,7 +328,9 @@ def main():
             ach = d["bytes"] / (d["ms"] * 1e-3)
             roof = {"bound": "hbm", "kernel": dom, "achieved": round(ach / 1e9, 1), "peak": PEAK_HBM / 1e9, "unit": "GB/s",
                     "frac": round(ach / PEAK_HBM, 4)}
-        roof.update({"traffic": hbm_traffic(a.arch, batch, dom), "launches": d["launches"], "avg_launch_us": round(d["ms"] / d["launches"] * 1e3, 2),
+        traffic, tsrc, tsha = hbm_traffic(arch, batch, dom)
+        roof.update({"traffic": traffic, "traffic_source": tsrc, "traffic_kernels_sha": tsha, "kernels_sha": csrc_sha(),
+                     "launches": d["launches"], "avg_launch_us": round(d["ms"] / d["launches"] * 1e3, 2),
                      "algorithmic_per_launch": (d["flops"] or d["bytes"]) / d["launches"]})
         out["roofline"] = roof
         out["kernel_families"] = {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
@@ -281,6 +340,47 @@ def main():
         out["kernel_families_note"] = "per-family table from the last warm-up step; roofline from the timed region"
     if vae_leg is not None:
         out["vae_decode"] = vae_leg
+    return out, sd, cfg
+
+
+def main():
+    a = parse()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(a, sys.argv[1:])                # does not return
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    torch.cuda.set_device(local_rank)
+    device = f"cuda:{local_rank}"
+    import torch.distributed as dist
+    from invertible_cd_amd import dist_utils
+    if world > 1:
+        dist_utils.init("nccl")                     # RCCL
+        assert dist.get_world_size() == a.gpus and dist.get_backend() == "nccl"
+    batch = a.batch or (32 if a.arch == "sd15" else 8)
+    out, sd, cfg = run_arch(a, a.arch, batch, a.steps, a.warmup, device, world, rank, primary=True)
+    # The default run also times BASELINE config 4's per-GPU half (SDXL, 8 images per GPU) and carries it as a sub-object of
+    # the same JSON line, so the driver's clock covers it too; `value` stays config 2 (the single-GPU metric configuration).
+    sdxl = None
+    if a.arch == "sd15" and not a.no_sdxl and not a.batch:
+        del sd
+        sd = None
+        torch.cuda.empty_cache()
+        saved = (a.no_vae, a.no_ref_batching)
+        a.no_vae = True
+        sdxl, _, _ = run_arch(a, "sdxl", 8, max(1, min(a.steps, 8)), max(1, min(a.warmup, 2)), device, world, rank, primary=False)
+        a.no_vae, a.no_ref_batching = saved
+        torch.cuda.empty_cache()
+    if rank != 0:
+        return
+    if sdxl is not None:
+        keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "per_unet_ms", "config",
+                "end_to_end_algorithmic_tflops_per_gpu", "end_to_end_frac_of_mfma_peak", "roofline", "kernel_families")
+        out["sdxl"] = {k: sdxl[k] for k in keep if k in sdxl}
     if world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(a.arch, sd, cfg)
     print(json.dumps(out))

@@ -229,6 +229,12 @@ int icd_unet_set_tensor(icd_unet* u, const char* name, const void* ptr, int32_t 
 int icd_unet_finalize(icd_unet* u);
 int32_t icd_unet_num_attention_layers(const icd_unet* u);
 int64_t icd_unet_workspace_bytes(const icd_unet* u, int32_t batch, int32_t H, int32_t W, int32_t n_ctx);
+/* Same, sized for a known materialisation rule of the attention hook: probs_mode 0 = no layer is ever materialised (no
+ * hook), 1 = the rule of the reference's shipped controllers (every cross-attention layer and every layer with <= 32^2
+ * queries, utils/p2p.py:147,184-188), 2 = any layer (what icd_unet_workspace_bytes assumes).  A forward whose hook asks
+ * for more than the arena was sized for fails with ICD_ERR_WORKSPACE. */
+int64_t icd_unet_workspace_bytes_ex(const icd_unet* u, int32_t batch, int32_t H, int32_t W, int32_t n_ctx,
+                                    int32_t probs_mode);
 
 typedef struct {
     const void* sample;        /* NCHW [B, in_ch, H, W], fp16 or fp32 (sample_is_f32) */
@@ -282,6 +288,10 @@ typedef struct {
     double flops;
 } icd_profile_record;
 int icd_profile_dump(icd_profile_record* recs, int32_t max_recs);
+/* Diagnostics for kernel tuning (tools/gemm_timeline.py): while `buf` (device, 4 x uint64 per block of the next launches)
+ * is registered, every block of the 256-wide GEMM tiles stamps s_memrealtime (100 MHz) at: start, first k-tile landed,
+ * main loop done, epilogue done.  NULL switches it off.  No reference counterpart. */
+int icd_debug_gemm_timeline(void* buf);
 
 #ifdef __cplusplus
 }

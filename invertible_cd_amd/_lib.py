@@ -98,6 +98,7 @@ SIGNATURES = {
     "icd_unet_finalize": (C.c_int, [C.c_void_p]),
     "icd_unet_num_attention_layers": (C.c_int32, [C.c_void_p]),
     "icd_unet_workspace_bytes": (C.c_int64, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "icd_unet_workspace_bytes_ex": (C.c_int64, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "icd_unet_forward": (C.c_int, [C.c_void_p, C.POINTER(UNetIO), C.c_void_p]),
     "icd_attention_fused_ex": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int32] * 9
                                + [C.c_int64, C.c_float, C.c_int32, C.c_void_p]),
@@ -109,6 +110,7 @@ SIGNATURES = {
     "icd_pack_nchw": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "icd_conv_out_n": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
                                  C.c_void_p, C.c_int32, C.c_void_p]),
+    "icd_debug_gemm_timeline": (C.c_int, [C.c_void_p]),
     "icd_profile_enable": (C.c_int, [C.c_int32]),
     "icd_profile_read": (C.c_int, [C.POINTER(ProfileRow), C.c_int32]),
     "icd_profile_dump": (C.c_int, [C.POINTER(ProfileRecord), C.c_int32]),

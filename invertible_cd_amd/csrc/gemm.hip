@@ -513,6 +513,11 @@ extern "C" int64_t icd_gemm_workspace_bytes(int32_t M, int32_t N, int32_t K) {
     return need;
 }
 
+static unsigned long long* g_timeline = nullptr;
+// Diagnostics: while a buffer is registered, every big-tile GEMM block writes four s_memrealtime stamps (100 MHz:
+// block start, first k-tile landed, main loop done, epilogue done) to buf[4 * linear block id].  buf == NULL: off.
+extern "C" int icd_debug_gemm_timeline(void* buf) { g_timeline = (unsigned long long*)buf; return ICD_OK; }
+
 extern "C" int icd_gemm(const icd_gemm_desc* d, void* stream) {
     ICD_CHECK_ARG(d != nullptr, "icd_gemm: null descriptor");
     ICD_CHECK_ARG(d->a0 && d->w && d->out, "icd_gemm: a0/w/out must be non-null");
@@ -539,6 +544,7 @@ extern "C" int icd_gemm(const icd_gemm_desc* d, void* stream) {
     k.zdiv = d->zdiv > 0 ? d->zdiv : 1;
     k.a_bs0 = d->a_bs0; k.a_bs1 = d->a_bs1; k.w_bs0 = d->w_bs0; k.w_bs1 = d->w_bs1; k.o_bs0 = d->o_bs0; k.o_bs1 = d->o_bs1;
     k.alpha = d->alpha; k.flags = d->flags;
+    k.timeline = g_timeline;
     const int batch = d->batch > 0 ? d->batch : 1;
     int wm = 2, ks = 1;
     const bool allow_split = !trans && !geglu && batch == 1 && d->splitk_ws != nullptr && d->splitk_ws_bytes > 0;

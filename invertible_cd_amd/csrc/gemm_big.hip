@@ -29,6 +29,8 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 1 : 2) void gemm_big_k
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, wv = tid >> 6, l = tid & 63;
     const int wm = wv / WN, wn = wv - wm * WN;
+    unsigned long long* tl = p.timeline ? p.timeline + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 : nullptr;
+    if (tl && tid == 0) tl[0] = __builtin_amdgcn_s_memrealtime();
 
     const int nblk = p.nbm * p.nbn;
     int bid = blockIdx.x;
@@ -236,6 +238,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 1 : 2) void gemm_big_k
     if (nk > 1) { issue_stage(STAGE_BYTES); __builtin_amdgcn_s_waitcnt(enc_vmcnt(LOADS)); }
     else __builtin_amdgcn_s_waitcnt(enc_vmcnt(0));
     __builtin_amdgcn_s_barrier();
+    if (tl && tid == 0) tl[1] = __builtin_amdgcn_s_memrealtime();
     load_frags(I0{}, I0{}, I0{});
 
     // register double-buffering of the fragments only where the accumulators leave room (128 x 64 wave tile)
@@ -290,6 +293,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 1 : 2) void gemm_big_k
     constexpr int LDT = 36;                                      // transposed patch: [64 n][32 m + 4]
     const bool trans = p.flags & ICD_GEMM_OUT_TRANS;
     __syncthreads();
+    if (tl && tid == 0) tl[2] = __builtin_amdgcn_s_memrealtime();
     float* wst = reinterpret_cast<float*>(smem) + wv * (trans ? 64 * LDT : 32 * LDW);
     float* part = p.ksplit > 1 ? p.partial + (long long)split * p.M * p.N : nullptr;
 #pragma unroll
@@ -415,6 +419,10 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 1 : 2) void gemm_big_k
                 }
             }
         }
+    }
+    if (tl) {                                    // last wave out writes the end stamp (stores of this wave are issued, not drained)
+        __syncthreads();
+        if (tid == 0) tl[3] = __builtin_amdgcn_s_memrealtime();
     }
 }
 

@@ -18,6 +18,7 @@ struct GemmK {
     int zdiv; long long a_bs0, a_bs1, w_bs0, w_bs1, o_bs0, o_bs1;
     float alpha; int flags;
     int nbm, nbn, ksplit, kt_per_split;
+    unsigned long long* timeline;                // diagnostics (icd_debug_gemm_timeline): 4 s_memrealtime stamps per block, or null
 };
 
 __device__ __forceinline__ int swz_off(int row, int chunk) {        // byte offset inside a [rows][64] half tile

@@ -617,14 +617,20 @@ extern "C" int icd_unet_finalize(icd_unet* u) {
     return ICD_OK;
 }
 
-extern "C" int64_t icd_unet_workspace_bytes(const icd_unet* u, int32_t batch, int32_t H, int32_t W, int32_t n_ctx) {
-    if (!u || batch <= 0 || H <= 0 || W <= 0 || n_ctx <= 0) return -1;
+extern "C" int64_t icd_unet_workspace_bytes_ex(const icd_unet* u, int32_t batch, int32_t H, int32_t W, int32_t n_ctx,
+                                               int32_t probs_mode) {
+    if (!u || batch <= 0 || H <= 0 || W <= 0 || n_ctx <= 0 || probs_mode < 0 || probs_mode > 2) return -1;
     long long peak = 0;
     std::vector<std::string> missing;
-    // sized for the worst shipped-controller case: probabilities materialised on every cross layer and every layer
-    // with <= 32^2 queries (utils/p2p.py:147); the fused-only requirement is a subset of it.
-    dry_walk(const_cast<icd_unet*>(u), batch, H, W, n_ctx, 2, &missing, &peak);
+    dry_walk(const_cast<icd_unet*>(u), batch, H, W, n_ctx, probs_mode, &missing, &peak);
     return peak + 4096;
+}
+
+// Worst case (any hook may ask for the probabilities of any layer); callers that know their controller's rule use the
+// _ex form: mode 0 (no hook) and mode 1 (shipped controllers, utils/p2p.py:147) need far less - the fp32 score chunk of
+// a materialised 64x64 self-attention layer alone is 1 GiB.
+extern "C" int64_t icd_unet_workspace_bytes(const icd_unet* u, int32_t batch, int32_t H, int32_t W, int32_t n_ctx) {
+    return icd_unet_workspace_bytes_ex(u, batch, H, W, n_ctx, 2);
 }
 
 extern "C" int icd_unet_forward(icd_unet* u, const icd_unet_io* io, void* stream) {

@@ -113,12 +113,17 @@ def _build_text_encoders(comp, device, dtype, xl):
 
 
 def load_models(model_id, device, reverse_checkpoint, forward_checkpoint, r=64, w_embed_dim=0, teacher_checkpoint=None,
-                dtype='fp32', components=None):
+                dtype='fp32', components=None, unet_config=None):
     """SD1.5: (ldm_stable, reverse_cons_model, forward_cons_model).  `components` may supply real
     {'vae','tokenizer','text_encoder'} objects or 'vae_state_dict' (AutoencoderKL weights, run on the HIP kernels);
-    otherwise labelled synthetic stand-ins are attached."""
+    otherwise labelled synthetic stand-ins are attached.  `unet_config` (not in the reference) overrides the SD1.5
+    architecture (reduced-width checkpoints in tests).
+
+    dtype: the reference's default 'fp32' runs diffusers in fp32 (utils/loading.py:34,38).  This executor always computes
+    fp16 x fp16 -> fp32-accumulate MFMA with fp16 activation storage; 'fp32' selects fp32 latents / eps at the UNet
+    boundary and fp32 boundary-step arithmetic only (DESIGN.md section 6 states the measured distance to an fp32 run)."""
     tdtype = torch.float32 if dtype == 'fp32' else torch.float16
-    cfg = dataclasses.replace(SD15, time_cond_proj_dim=int(w_embed_dim))
+    cfg = dataclasses.replace(unet_config or SD15, time_cond_proj_dim=int(w_embed_dim))
     if w_embed_dim > 0:
         print(f'Forward CD is initialized with guidance embedding, dim {w_embed_dim}')
     comp = dict(components or {})
@@ -146,9 +151,10 @@ def load_models(model_id, device, reverse_checkpoint, forward_checkpoint, r=64, 
     return tuple(out)
 
 
-def load_models_xl(model_id, reverse_checkpoint, forward_checkpoint, teacher_checkpoint, device="cuda", components=None):
+def load_models_xl(model_id, reverse_checkpoint, forward_checkpoint, teacher_checkpoint, device="cuda", components=None,
+                   unet_config=None):
     """SDXL: (stable_pipe, pipe, forw_pipe); fp16 UNets, LoRA fused in fp32 (utils/loading.py:122,141)."""
-    cfg = SDXL
+    cfg = unet_config or SDXL
     comp = dict(components or {})
     from .vae import SDXL_VAE
     _build_vae(comp, SDXL_VAE, device, torch.float16)

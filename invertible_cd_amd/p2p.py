@@ -52,26 +52,30 @@ class LocalBlend:
         return mask
 
     def get_mask(self, maps, alpha, use_pool, x_t):
-        k = 1
-        m = (maps * alpha).sum(-1).mean(1)
+        """Word-weighted mean over layers x heads of the 16x16 maps -> (3x3 max-pool) -> nearest resize to the latent ->
+        per-prompt max normalisation -> threshold; every prompt's mask is OR-ed with the base prompt's (utils/p2p.py:20-31)."""
+        heat = (maps * alpha).sum(-1).mean(1)                              # [P, 1, 16, 16]
         if use_pool:
-            m = nnf.max_pool2d(m, (2 * k + 1, 2 * k + 1), (1, 1), padding=(k, k))
-        m = nnf.interpolate(m, size=(x_t.shape[2:]))
-        m = m / m.max(2, keepdims=True)[0].max(3, keepdims=True)[0]
-        m = m.gt(self.th[1 - int(use_pool)])
-        return m[:1] + m
+            heat = nnf.max_pool2d(heat, kernel_size=3, stride=1, padding=1)
+        heat = nnf.interpolate(heat, size=(x_t.shape[2:]))
+        heat = heat / heat.amax(dim=(2, 3), keepdim=True)
+        on = heat.gt(self.th[1 - int(use_pool)])
+        return on[:1] + on
 
     def __call__(self, x_t, attention_store):
+        """`x_t[e] <- x_t[0] + mask[e] * (x_t[e] - x_t[0])` from the accumulated 16x16 cross-attention maps of
+        down_cross[2:4] + up_cross[:3] (utils/p2p.py:33-44)."""
         self.counter += 1
         if self.counter <= self.start_blend:
             return x_t
-        picked = attention_store["down_cross"][2:4] + attention_store["up_cross"][:3]
-        maps = torch.cat([m.reshape(self.alpha_layers.shape[0], -1, 1, 16, 16, MAX_NUM_WORDS) for m in picked], dim=1)
+        n_prompts = self.alpha_layers.shape[0]
+        layers = attention_store["down_cross"][2:4] + attention_store["up_cross"][:3]
+        maps = torch.cat([m.reshape(n_prompts, -1, 1, 16, 16, MAX_NUM_WORDS) for m in layers], dim=1)
         mask = self.get_mask(maps, self.alpha_layers, True, x_t)
         if self.substruct_layers is not None:
             mask = mask * ~self.get_mask(maps, self.substruct_layers, False, x_t)
-        mask = mask.float()
-        return x_t[:1] + mask * (x_t - x_t[:1])
+        base = x_t[:1]
+        return base + mask.float() * (x_t - base)
 
 
 # ------------------------------------------------------------------------------------------- controllers
@@ -369,8 +373,26 @@ class HookAdapter:
         self.c = controller
         self.cond_only = cond_only
         self.dev = dev
-        self.native = isinstance(controller, (AttentionControl, EmptyControl))
+        self.native = self._trusts_needs_probs(controller)
+        # arena sizing hint for the executor (icd_unet_workspace_bytes_ex): 1 = the shipped controllers' rule, 2 = any layer
+        self.probs_mode = 1 if self.native else 2
         self.pending = None
+
+    @staticmethod
+    def _trusts_needs_probs(c):
+        """`needs_probs` may only short-cut a layer when it describes the `forward` that will actually run: the shipped
+        forwards (this module), or a subclass that overrides `forward` AND states its own `needs_probs` at or below it in
+        the MRO.  A reference-style subclass that only overrides `forward` gets every layer, as utils/p2p.py:336 gives it."""
+        if isinstance(c, EmptyControl):
+            return True
+        if not isinstance(c, AttentionControl):
+            return False
+        mro = type(c).__mro__
+        fwd_owner = next(k for k in mro if "forward" in k.__dict__)
+        np_owner = next(k for k in mro if "needs_probs" in k.__dict__)
+        if fwd_owner.__module__ == __name__:
+            return True
+        return mro.index(np_owner) <= mro.index(fwd_owner)
 
     def query(self, layer, is_cross, place, bh, nq, nk, ld):
         c = self.c
@@ -396,59 +418,48 @@ class HookAdapter:
 
 # ------------------------------------------------------------------------------------------- word / schedule helpers
 def get_word_inds(text: str, word_place, tokenizer):
-    """Token positions (1-based, after BOS) of a word given by value or by index (utils/p2p.py:422-440)."""
-    words = text.split(" ")
-    if type(word_place) is str:
-        word_place = [i for i, w in enumerate(words) if w == word_place]
-    elif type(word_place) is int:
-        word_place = [word_place]
-    found = []
-    if len(word_place) > 0:
-        pieces = [tokenizer.decode([tok]).strip("#") for tok in tokenizer.encode(text)][1:-1]
-        consumed, wi = 0, 0
-        for ti, piece in enumerate(pieces):
-            consumed += len(piece)
-            if wi in word_place:
-                found.append(ti + 1)
-            if consumed >= len(words[wi]):
-                wi += 1
-                consumed = 0
-    return np.array(found)
+    """Token positions (1-based, after BOS) of a word given by value or by index (utils/p2p.py:422-440): one
+    implementation, shared with the aligner."""
+    return seq_aligner.get_word_inds(text, word_place, tokenizer)
+
+
+def _step_gate(bounds, n_rows):
+    """0/1 column over the n_rows = num_steps + 1 schedule rows: 1 on [int(lo * n_rows), int(hi * n_rows))."""
+    lo, hi = (0.0, bounds) if type(bounds) is float else bounds
+    rows = torch.arange(n_rows)
+    return ((rows >= int(lo * n_rows)) & (rows < int(hi * n_rows))).float()
 
 
 def update_alpha_time_word(alpha, bounds, prompt_ind: int, word_inds: Optional[torch.Tensor] = None):
-    if type(bounds) is float:
-        bounds = 0, bounds
-    start, end = int(bounds[0] * alpha.shape[0]), int(bounds[1] * alpha.shape[0])
-    if word_inds is None:
-        word_inds = torch.arange(alpha.shape[2])
-    alpha[:start, prompt_ind, word_inds] = 0
-    alpha[start:end, prompt_ind, word_inds] = 1
-    alpha[end:, prompt_ind, word_inds] = 0
+    """Set alpha[:, prompt_ind, word_inds] to the step gate of `bounds` (utils/p2p.py:388-399); all words when None."""
+    gate = _step_gate(bounds, alpha.shape[0])
+    cols = slice(None) if word_inds is None else torch.as_tensor(np.asarray(word_inds), dtype=torch.int64)
+    alpha[:, prompt_ind, cols] = gate[:, None]
     return alpha
 
 
 def get_time_words_attention_alpha(prompts, num_steps, cross_replace_steps, tokenizer, max_num_words=77):
-    """[num_steps+1, n_edits, 1, 1, 77] step/word gate of the cross-attention injection (utils/p2p.py:402-420)."""
-    if type(cross_replace_steps) is not dict:
-        cross_replace_steps = {"default_": cross_replace_steps}
-    if "default_" not in cross_replace_steps:
-        cross_replace_steps["default_"] = (0., 1.)
-    n_edits = len(prompts) - 1
-    alpha = torch.zeros(num_steps + 1, n_edits, max_num_words)
-    for i in range(n_edits):
-        alpha = update_alpha_time_word(alpha, cross_replace_steps["default_"], i)
-    for word, bounds in cross_replace_steps.items():
+    """[num_steps+1, n_edits, 1, 1, 77] step x word gate of the cross-attention injection (utils/p2p.py:402-420): the
+    "default_" window for every token, overridden per word where a word-specific window is given."""
+    windows = dict(cross_replace_steps) if type(cross_replace_steps) is dict else {"default_": cross_replace_steps}
+    if type(cross_replace_steps) is dict:
+        cross_replace_steps.setdefault("default_", (0., 1.))          # the reference adds the key to the caller's dict
+    windows.setdefault("default_", (0., 1.))
+    n_edits, rows = len(prompts) - 1, num_steps + 1
+    alpha = _step_gate(windows["default_"], rows)[:, None, None].repeat(1, n_edits, max_num_words)
+    for word, bounds in windows.items():
         if word == "default_":
             continue
-        for i in range(n_edits):
-            ind = get_word_inds(prompts[i + 1], word, tokenizer)
-            if len(ind) > 0:
-                alpha = update_alpha_time_word(alpha, bounds, i, ind)
-    return alpha.reshape(num_steps + 1, n_edits, 1, 1, max_num_words)
+        gate = _step_gate(bounds, rows)
+        for e in range(n_edits):
+            cols = get_word_inds(prompts[e + 1], word, tokenizer)
+            if len(cols) > 0:
+                alpha[:, e, torch.as_tensor(cols, dtype=torch.int64)] = gate[:, None]
+    return alpha.reshape(rows, n_edits, 1, 1, max_num_words)
 
 
 def get_equalizer(text: str, word_select, values):
+    """[1, 77] per-token scale: `values[k]` on the tokens of word `word_select[k]`, 1 elsewhere (utils/p2p.py:443-453)."""
     if type(word_select) is int or type(word_select) is str:
         word_select = (word_select,)
     eq = torch.ones(1, 77)

@@ -1,8 +1,9 @@
 """Duck-typed pipeline containers: exactly the attributes the iCD sampler reads from diffusers' pipelines
 (SURVEY.md section 8b "Attributes of model/pipe the reference touches").
 
-They hold the native UNet plus the out-of-path components (VAE, tokenizer, text encoder - SURVEY.md section 8f ranks
-1 and 3, not rebuilt in this round: pass real ones in, or the labelled synthetic stand-ins of synthetic.py).
+They hold the native UNet plus the components either side of it: the HIP AutoencoderKL (vae.py) and CLIP text encoders
+(clip.py) of this package, or caller-supplied objects; tokenizers need a BPE vocabulary that is not available offline, so
+callers pass token ids / `compute_embeddings_fn` (labelled synthetic stand-ins live in synthetic.py).
 """
 import types
 
@@ -39,8 +40,41 @@ class _ImageProcessor:
         arr = (image.cpu().permute(0, 2, 3, 1).float().numpy() * 255).round().astype("uint8")
         return [Image.fromarray(a) for a in arr]
 
-    def preprocess(self, image):
-        return image
+    def __init__(self, vae_scale_factor=8):
+        self.vae_scale_factor = vae_scale_factor
+
+    def preprocess(self, image, height=None, width=None):
+        """diffusers VaeImageProcessor.preprocess as running/sdxl/edit.py:198-199 uses it: PIL image(s) / HWC numpy in
+        [0,1] / NCHW tensor -> float32 NCHW in [-1,1], size rounded down to a multiple of the VAE scale factor.  Tensors
+        that already have 4 latent channels, or that already contain negative values, pass through un-normalised."""
+        import numpy as np
+        if torch.is_tensor(image) or (isinstance(image, (list, tuple)) and len(image) and torch.is_tensor(image[0])):
+            x = image if torch.is_tensor(image) else torch.cat([i if i.dim() == 4 else i[None] for i in image], 0)
+            if x.dim() == 3:
+                x = x[None]
+            if x.shape[1] == 4:
+                return x
+            h = (height or x.shape[2]) // self.vae_scale_factor * self.vae_scale_factor
+            w = (width or x.shape[3]) // self.vae_scale_factor * self.vae_scale_factor
+            if (h, w) != tuple(x.shape[2:]):
+                x = torch.nn.functional.interpolate(x, size=(h, w))
+            return x if float(x.min()) < 0 else 2.0 * x - 1.0
+        imgs = list(image) if isinstance(image, (list, tuple)) else [image]
+        arrs = []
+        for im in imgs:
+            if isinstance(im, np.ndarray):
+                a = im if im.ndim == 4 else im[None]
+            else:                                          # PIL
+                w0, h0 = im.size
+                h = (height or h0) // self.vae_scale_factor * self.vae_scale_factor
+                w = (width or w0) // self.vae_scale_factor * self.vae_scale_factor
+                if (w, h) != (w0, h0):
+                    from PIL import Image
+                    im = im.resize((w, h), resample=Image.LANCZOS)
+                a = np.asarray(im.convert("RGB"), dtype=np.float32)[None] / 255.0
+            arrs.append(a.astype(np.float32))
+        x = torch.from_numpy(np.concatenate(arrs, 0)).permute(0, 3, 1, 2).contiguous()
+        return 2.0 * x - 1.0
 
 
 class StableDiffusionXLPipeline:
@@ -83,14 +117,27 @@ class StableDiffusionXLPipeline:
 class StableDiffusionXLImg2ImgPipeline(StableDiffusionXLPipeline):
     def prepare_latents(self, image, timestep, batch_size, num_images_per_prompt, dtype, device, generator=None,
                         add_noise=True):
-        """img2img: (VAE-encode unless the input already has 4 latent channels) + add_noise at `timestep`."""
+        """diffusers 0.25.1 StableDiffusionXLImg2ImgPipeline.prepare_latents, the call of utils/generation_sdxl.py:273-276:
+        image (PIL / list / [B,3,H,W] in [-1,1]) -> VAE encode in fp32 -> latent_dist.sample(generator) * scaling_factor
+        (4-channel inputs are taken as latents), repeated to batch_size, + add_noise(randn, timestep).  Both draws come
+        from `generator` in this order, as in diffusers."""
+        if not torch.is_tensor(image):
+            image = self.image_processor.preprocess(image)
         image = image.to(device=device, dtype=dtype)
+        batch_size = batch_size * num_images_per_prompt
         if image.shape[1] == 4:
             init = image
         else:
             if self.vae is None:
-                raise RuntimeError("no VAE attached: pass 4-channel latents or attach a VAE (out of the U-Net hot path)")
-            init = self.vae.encode(image.float()).latent_dist.sample(generator).to(dtype) * self.vae.config.scaling_factor
+                raise RuntimeError("no VAE attached: pass 4-channel latents or attach a VAE (components['vae_state_dict'])")
+            self.vae.to(torch.float32)                       # force_upcast, as diffusers does for the SDXL VAE
+            init = self.vae.encode(image.float()).latent_dist.sample(generator)
+            self.vae.to(dtype)
+            init = init.to(dtype) * self.vae.config.scaling_factor
+        if batch_size > init.shape[0]:
+            if batch_size % init.shape[0] != 0:
+                raise ValueError(f"Cannot duplicate `image` of batch size {init.shape[0]} to {batch_size} text prompts.")
+            init = torch.cat([init] * (batch_size // init.shape[0]), dim=0)
         if not add_noise:
             return init
         noise = self._randn(init.shape, generator, device, dtype)

@@ -175,6 +175,7 @@ class UNet2DConditionModel:
         assert self.num_attention_layers == cfg.num_attention_layers
         self._ws = None
         self._ws_key = None
+        self._ws_mode = 0
         # p2p plugin state (set by p2p.register_attention_control / Generator.get_noise_pred)
         self.attn_controller = None
         self.attn_cond_only = False
@@ -203,21 +204,23 @@ class UNet2DConditionModel:
             pass
 
     # ------------------------------------------------------------------ forward
-    def _workspace(self, B, H, W, n_ctx):
+    def _workspace(self, B, H, W, n_ctx, probs_mode):
+        """Arena for one forward, sized by the materialisation rule of the attached controller (0 none, 1 the shipped
+        controllers' rule, 2 any layer): only grows, so switching controllers does not thrash the allocator."""
         key = (B, H, W, n_ctx)
-        if self._ws_key != key:
-            nbytes = self._lib.icd_unet_workspace_bytes(self._h, B, H, W, n_ctx)
+        if self._ws_key != key or probs_mode > self._ws_mode:
+            nbytes = self._lib.icd_unet_workspace_bytes_ex(self._h, B, H, W, n_ctx, probs_mode)
             if nbytes <= 0:
                 raise RuntimeError("icd_unet_workspace_bytes failed")
             self._ws = None
             self._ws = torch.empty((nbytes,), dtype=torch.uint8, device=self.device)
-            self._ws_key = key
+            self._ws_key, self._ws_mode = key, probs_mode
         return self._ws
 
     def _make_hook(self, errors):
         ctrl = self.attn_controller
         if ctrl is None:
-            return _lib.ATTN_HOOK(0)
+            return _lib.ATTN_HOOK(0), 0
         from . import p2p
         adapter = p2p.HookAdapter(ctrl, self.attn_cond_only, self.device)
         live = self._live
@@ -236,7 +239,7 @@ class UNet2DConditionModel:
             except BaseException as e:       # never let an exception cross the C boundary
                 errors.append(e)
                 return -1
-        return _lib.ATTN_HOOK(hook)
+        return _lib.ATTN_HOOK(hook), adapter.probs_mode
 
     @torch.no_grad()
     def __call__(self, sample, timestep, encoder_hidden_states=None, class_labels=None, timestep_cond=None,
@@ -285,9 +288,9 @@ class UNet2DConditionModel:
             keep += [te, ti]
             io.text_embeds, io.time_ids = te.data_ptr(), ti.data_ptr()
         eps = torch.empty_like(x)
-        ws = self._workspace(B, H, W, n_ctx)
         errors = []
-        hook = self._make_hook(errors)
+        hook, probs_mode = self._make_hook(errors)
+        ws = self._workspace(B, H, W, n_ctx, probs_mode)
         io.sample, io.timesteps, io.context, io.eps = x.data_ptr(), t.data_ptr(), ctx.data_ptr(), eps.data_ptr()
         io.workspace, io.workspace_bytes = ws.data_ptr(), ws.numel()
         io.batch, io.H, io.W, io.n_ctx = B, H, W, n_ctx

@@ -14,7 +14,7 @@ fused flash kernel when the head dim is <= 160), first / last convs through `icd
 `icd_conv_out_n`.  Host-side algebra done once at load, all exact in real arithmetic:
   * post_quant_conv (1x1 + bias) is folded into decoder.conv_in; its bias rides on a ones-channel of the packed latent
     so the 3x3 conv's zero padding still sees zeros outside the image;
-  * quant_conv is folded into encoder.conv_out and only the 4 mean channels are computed (`latent_dist.mean`);
+  * quant_conv is folded into encoder.conv_out (mean rows and log-variance rows as two 4-channel output convs);
   * the V bias of the attention is folded into the output projection's bias (softmax rows sum to one).
 Activations are fp16 token-major [B*H*W, C] with fp32 accumulation, like the UNet.  The reference upcasts the SDXL VAE to
 fp32 (utils/generation_sdxl.py:465) because real SDXL-VAE activations overflow fp16; this module keeps fp16 storage, so
@@ -106,17 +106,32 @@ class _Out(dict):
 
 
 class LatentDist:
-    """`DiagonalGaussianDistribution` as far as the path uses it: the mean (utils/generation.py:277,282)."""
+    """diffusers' `DiagonalGaussianDistribution` over the 8 moment channels of quant_conv(encoder(x)).
 
-    def __init__(self, mean):
+    The SD1.5 path reads `.mean` (utils/generation.py:277,282); the SDXL img2img `prepare_latents` the reference calls at
+    utils/generation_sdxl.py:273-276 draws `.sample(generator)`: mean + exp(0.5 * clamp(logvar, -30, 20)) * randn, the
+    noise drawn like diffusers' randn_tensor (a CPU generator draws on the CPU in the parameters' dtype, then moves)."""
+
+    def __init__(self, mean, logvar=None):
         self.mean = mean
+        self.logvar = None if logvar is None else torch.clamp(logvar, -30.0, 20.0)
+        self.deterministic = logvar is None
+        if self.logvar is not None:
+            self.std = torch.exp(0.5 * self.logvar)
+            self.var = torch.exp(self.logvar)
+        else:
+            self.std = self.var = torch.zeros_like(mean)
 
     def mode(self):
         return self.mean
 
     def sample(self, generator=None):
-        raise NotImplementedError("latent_dist.sample() needs the log-variance channels; the iCD path only reads .mean "
-                                  "(utils/generation.py:277,282) - see DESIGN.md section 9")
+        gen_dev = generator.device.type if generator is not None else self.mean.device.type
+        if gen_dev == "cpu":
+            noise = torch.randn(self.mean.shape, generator=generator, device="cpu", dtype=self.mean.dtype).to(self.mean.device)
+        else:
+            noise = torch.randn(self.mean.shape, generator=generator, device=self.mean.device, dtype=self.mean.dtype)
+        return self.mean + self.std * noise
 
 
 def pack_vae_state_dict(cfg: VAEConfig, sd, device="cuda"):
@@ -171,6 +186,10 @@ def pack_vae_state_dict(cfg: VAEConfig, sd, device="cuda"):
     w4 = torch.zeros(4, wo.shape[1], 3, 3); w4[:zc] = wm
     b4 = torch.zeros(4); b4[:zc] = wq[:zc] @ bo + bq[:zc]
     P["encoder.conv_out_mean.weight"], P["encoder.conv_out_mean.bias"] = half(ops.pack_conv_weight(w4)), full(b4)
+    wl = torch.einsum("om,mchw->ochw", wq[zc:], wo)                          # log-variance rows (latent_dist.sample / .std)
+    w4 = torch.zeros(4, wo.shape[1], 3, 3); w4[:zc] = wl
+    b4 = torch.zeros(4); b4[:zc] = wq[zc:] @ bo + bq[zc:]
+    P["encoder.conv_out_logvar.weight"], P["encoder.conv_out_logvar.bias"] = half(ops.pack_conv_weight(w4)), full(b4)
     # ---- decoder
     wpq, bpq = f32("post_quant_conv.weight").reshape(zc, zc), f32("post_quant_conv.bias")
     wi = f32("decoder.conv_in.weight")
@@ -296,8 +315,10 @@ class AutoencoderKL:
         if x.dtype not in (torch.float16, torch.float32):
             x = x.float()
         outs = [self._encode_chunk(x[i:i + self.max_chunk].contiguous()) for i in range(0, x.shape[0], self.max_chunk)]
-        mean = (outs[0] if len(outs) == 1 else torch.cat(outs)).to(self.dtype)
-        return _Out(latent_dist=LatentDist(mean)) if return_dict else (LatentDist(mean),)
+        mean = torch.cat([o[0] for o in outs]).to(self.dtype)
+        logvar = torch.cat([o[1] for o in outs]).to(self.dtype)
+        dist = LatentDist(mean, logvar)
+        return _Out(latent_dist=dist) if return_dict else (dist,)
 
     def _encode_chunk(self, img):
         w, cfg = self.w, self.cfg
@@ -315,5 +336,7 @@ class AutoencoderKL:
         x = self._mid("encoder.mid_block.", x, B, H, W)
         x = ops.groupnorm(x, B, H * W, w["encoder.conv_norm_out.weight"], w["encoder.conv_norm_out.bias"], EPS, True,
                           groups=cfg.norm_num_groups)
-        return ops.conv_out(x, B, H, W, w["encoder.conv_out_mean.weight"], w["encoder.conv_out_mean.bias"],
-                            out_dtype=torch.float32 if self.dtype == torch.float32 else torch.float16, cout=4)
+        od = torch.float32 if self.dtype == torch.float32 else torch.float16
+        mean = ops.conv_out(x, B, H, W, w["encoder.conv_out_mean.weight"], w["encoder.conv_out_mean.bias"], out_dtype=od, cout=4)
+        logvar = ops.conv_out(x, B, H, W, w["encoder.conv_out_logvar.weight"], w["encoder.conv_out_logvar.bias"], out_dtype=od, cout=4)
+        return mean, logvar

@@ -223,17 +223,19 @@ def _transformer(w, p, x, ctx, heads, depth, linear_proj, groups, place, hook):
 def time_embedding(w, cfg, t, batch, timestep_cond=None, added_cond=None):
     """Timesteps -> (+cond_proj(w_emb)) -> Linear -> SiLU -> Linear  (+ SDXL text_time add_embedding)."""
     ch0 = cfg["block_out_channels"][0]
-    tt = torch.as_tensor(t, dtype=torch.float32).reshape(-1)
+    ref = w["time_embedding.linear_1.weight"]          # fp32 on the CPU for the oracle proper; fp16 on a GPU for the noise floor
+    dt, dev = ref.dtype, ref.device
+    tt = torch.as_tensor(t, dtype=torch.float32).reshape(-1).cpu()
     tt = tt.expand(batch) if tt.numel() == 1 else tt
-    e = sinusoid(tt, ch0)
+    e = sinusoid(tt, ch0).to(dev, dt)                  # diffusers: time_proj in fp32, then cast to the sample dtype
     if timestep_cond is not None:
-        e = e + F.linear(timestep_cond.float(), w["time_embedding.cond_proj.weight"])
+        e = e + F.linear(timestep_cond.to(dev, dt), w["time_embedding.cond_proj.weight"])
     e = F.linear(e, w["time_embedding.linear_1.weight"], w["time_embedding.linear_1.bias"])
     e = F.linear(F.silu(e), w["time_embedding.linear_2.weight"], w["time_embedding.linear_2.bias"])
     if cfg["add_in_dim"]:
-        tid = added_cond["time_ids"].float()
-        te = sinusoid(tid.flatten(), cfg["addition_time_embed_dim"]).reshape(batch, -1)
-        a = torch.cat([added_cond["text_embeds"].float(), te], dim=-1)
+        tid = added_cond["time_ids"].float().cpu()
+        te = sinusoid(tid.flatten(), cfg["addition_time_embed_dim"]).reshape(batch, -1).to(dev, dt)
+        a = torch.cat([added_cond["text_embeds"].to(dev, dt), te], dim=-1)
         a = F.linear(a, w["add_embedding.linear_1.weight"], w["add_embedding.linear_1.bias"])
         a = F.linear(F.silu(a), w["add_embedding.linear_2.weight"], w["add_embedding.linear_2.bias"])
         e = e + a
@@ -245,12 +247,17 @@ def unet_forward(w, cfg, sample, t, encoder_hidden_states, timestep_cond=None, a
                  taps=None):
     """eps = UNet(sample[B,4,H,W], t, ctx[B,77,D], w_emb[B,512], {text_embeds,time_ids}) in fp32 on CPU.
 
+    The arithmetic runs in the dtype / on the device of the weight dict `w`: fp32 CPU tensors give the oracle; the parity
+    tests also call it once with fp16 weights on the GPU (stock torch fp16 ops, like the reference's fp16 diffusers path) to
+    measure how far an fp16 pipeline sits from fp32 by construction - the "noise floor" printed next to the product's error.
+
     hook(probs[B*heads,N,M], is_cross, place) is called once per Attention module in module-execution order
     (self then cross per block; down -> mid -> up), exactly where utils/p2p.py:336 calls the controller.
     taps: optional dict filled with named intermediate activations (for kernel-level parity tests).
     """
-    x = sample.float()
-    ctx = encoder_hidden_states.float()
+    wref = w["conv_in.weight"]                         # compute dtype / device follow the weights (fp32 CPU = the oracle;
+    x = sample.to(wref.device, wref.dtype)             # fp16 weights on a GPU = the "fp16 torch" noise-floor run of the tests)
+    ctx = encoder_hidden_states.to(wref.device, wref.dtype)
     B = x.shape[0]
     G = cfg["norm_groups"]
     ch = cfg["block_out_channels"]

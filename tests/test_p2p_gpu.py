@@ -98,3 +98,33 @@ def test_reweight_chained_on_device(g):
 def test_three_prompt_group_on_device(g):
     c = p2p.make_controller(["a cat sitting on a bench", "a dog sitting on a bench", "a cat sitting on a sofa"], True, 0.5, 0.25)
     _run(g, "replace3", c, 3, 104, steps=2)
+
+
+def test_local_blend_values_on_device(g):
+    """LocalBlend (utils/p2p.py:18-70) on the device: the fp16 probability walk runs on the GPU (fused cross-edit kernel,
+    device-side store accumulation) and the word-localised latent blend is applied to device latents after every step;
+    the blended latents are compared with the vectors captured from the reference.  The mask is a threshold of fp16 maps,
+    so a handful of border pixels may flip: at most 0.5 % of the elements may differ, and none in the base prompt's row."""
+    c = p2p.make_controller(["a cat sitting on a bench", "a fluffy cat sitting on a red bench"], False,
+                            {"default_": 0.8, "fluffy": (0.0, 0.4)}, 0.4, blend_words=(("cat",), ("cat",)))
+    assert c.local_blend is not None and c.local_blend.alpha_layers.is_cuda
+    walk = list(zip(g["walk_place"].tolist(), [bool(x) for x in g["walk_cross"]], g["walk_n"].tolist()))
+    c.num_att_layers = len(walk)
+    gen = torch.Generator().manual_seed(102)
+    lat = torch.from_numpy(g["refine_lat_in"]).cuda()
+    outs = []
+    for step in range(4):
+        for place, is_cross, n in walk:
+            m = 77 if is_cross else n
+            P = torch.softmax(torch.randn(2 * 2 * HEADS, n, m, generator=gen) * 2.0, dim=-1).half().cuda()
+            assert c(P, is_cross, place) is P
+        lat = c.step_callback(lat)
+        assert lat.is_cuda
+        outs.append(lat.float().cpu())
+    got, want = torch.stack(outs).numpy(), g["refine_latents"]
+    assert got.shape == want.shape
+    bad = np.abs(got - want) > 1e-5
+    print(f"[local blend on device] mismatching elements: {bad.mean() * 100:.4f} %")
+    assert bad.mean() < 5e-3
+    assert not bad[:, 0].any()                                   # base prompt row is never blended
+    assert np.abs(got - g["refine_lat_in"][None]).max() > 0      # and the blend did change the edited row

@@ -93,9 +93,9 @@ def test_sd15_reverse_with_attention_store(eliminate):
     ref = _oracle_loop(E, sd, cfg, lat.clone(), ctx, list(zip(REV_T, REV_S)), [[gs] * B] * 4, controller=ref_store)
     err = rel_l2(outs[-1], ref)
     print(f"[sd15 reverse, eliminate={eliminate}] rel-L2(latents) = {err:.3e}")
-    assert err < 5e-3
+    assert err < 1e-3                                # measured 4.1e-4 (profiles/r02_parity.txt); bar <= 2.5x for box-to-box plan changes
     assert store.cur_step == ref_store.cur_step == 4
-    n_checked = 0
+    n_checked, worst = 0, 0.0
     for key, refs in ref_store.attention_store.items():
         got = store.attention_store[key]
         assert len(got) == len(refs), key
@@ -103,8 +103,10 @@ def test_sd15_reverse_with_attention_store(eliminate):
             gc = g                                   # both modes store the conditional rows only (utils/p2p.py:106-107)
             assert tuple(gc.shape) == tuple(r.shape), (key, gc.shape, r.shape)
             e = rel_l2(gc, r)
+            worst = max(worst, e)
             assert e < 2e-3, (key, e)
             n_checked += 1
+    print(f"[sd15 reverse, eliminate={eliminate}] worst attention-store tensor rel-L2 = {worst:.3e}")
     # latent 32x32 -> query counts 1024,1024,256,256,64,64 down; 16 mid; up 64x3,256x3,1024x3: all <= 32^2 -> all 32 stored
     assert n_checked == 32
 
@@ -127,7 +129,7 @@ def test_sd15_inversion_then_replace_edit():
     ref_inv = _oracle_loop(E, sd, cfg, x0.clone(), ctx, list(zip(FWD_T, FWD_S)), [[0.0, 0.0]] * 4)
     e_inv = rel_l2(inv[0], ref_inv)
     print(f"[sd15 inversion] rel-L2 = {e_inv:.3e}")
-    assert e_inv < 5e-3
+    assert e_inv < 2.5e-3                            # measured 1.36e-3
     # ---- edit: replace controller (cross 0.5 / self 0.5), dynamic guidance tau = 0.8, gs = 19
     p2p.tokenizer = E["synthetic"].SyntheticTokenizer()
     p2p.NUM_DDIM_STEPS = 4
@@ -146,11 +148,14 @@ def test_sd15_inversion_then_replace_edit():
     ref = _oracle_loop(E, sd, cfg, start.clone(), ctx, list(zip(REV_T, REV_S)), ws, controller=ref_ctrl)
     e = rel_l2(outs[-1], ref)
     print(f"[sd15 replace edit] rel-L2 = {e:.3e}")
-    assert e < 8e-3
+    assert e < 3e-3                                  # measured 1.68e-3 (8 UNet evaluations deep, edited probabilities)
     assert ctrl.cur_step == 4
+    worst = 0.0
     for key, refs in ref_ctrl.attention_store.items():
         for g, r in zip(ctrl.attention_store[key], refs):
+            worst = max(worst, rel_l2(g, r))
             assert rel_l2(g, r) < 3e-3, key
+    print(f"[sd15 replace edit] worst attention-store tensor rel-L2 = {worst:.3e}")
 
 
 def test_sdxl_reverse_and_dynamic_edit_pipeline():
@@ -176,7 +181,7 @@ def test_sdxl_reverse_and_dynamic_edit_pipeline():
     ref = _oracle_loop_xl(E, sd, cfg, lat.clone(), ctx, pairs, [[7.0] * B] * 4, added)
     e4 = rel_l2(out, ref)
     print(f"[sdxl reverse] rel-L2 = {e4:.3e}")
-    assert e4 < 5e-3
+    assert e4 < 1.2e-3                               # measured 6.1e-4
     # cfg 5: forward 3 steps (w = 0) from noised latents at t = 19, then reverse 3 steps with tau = 0.7, gs = 19
     fwd, start = X.inverse_sample_deterministic(fpipe, lat.cuda().half(), ["x"] * B, num_inference_steps=3, timesteps=[19, 339, 699],
                                                 guidance_scale=0.0, is_sdxl=True, compute_embeddings_fn=emb, seed=3,
@@ -189,7 +194,7 @@ def test_sdxl_reverse_and_dynamic_edit_pipeline():
     ref_f = _oracle_loop_xl(E, sd, cfg, x0, ctx, list(zip([19, 339, 699], [339, 699, 999])), [[0.0] * B] * 3, added)
     e5f = rel_l2(fwd, ref_f)
     print(f"[sdxl forward] rel-L2 = {e5f:.3e}")
-    assert e5f < 5e-3
+    assert e5f < 3.5e-3                              # measured 2.03e-3 (forward model from t = 19: small eps, noise dominated)
     _, rev = X.sample_deterministic(pipe, ["x"] * B, latents=ref_f.cuda().half(), num_inference_steps=3, guidance_scale=19.0,
                                     is_sdxl=True, timesteps=[339, 699, 999], compute_embeddings_fn=emb, return_latent=True,
                                     use_dynamic_guidance=True, tau1=0.7, tau2=0.7)
@@ -198,7 +203,7 @@ def test_sdxl_reverse_and_dynamic_edit_pipeline():
     ref_r = _oracle_loop_xl(E, sd, cfg, ref_f.half().float(), ctx, list(zip([999, 699, 339], [699, 339, 0])), ws, added)
     e5r = rel_l2(rev, ref_r)
     print(f"[sdxl dynamic reverse] rel-L2 = {e5r:.3e}")
-    assert e5r < 5e-3
+    assert e5r < 3e-3                                # measured 1.85e-3
 
 
 def _oracle_loop_xl(E, sd, cfg, x, ctx, pairs, w_vals, added):

@@ -1,0 +1,148 @@
+"""BASELINE configs 4 and 5 at their per-GPU size: full-width SDXL UNet (2.57 G parameters), 128x128 latents.
+
+  * config 4: 4-step reverse, 8 images per GPU (utils/generation_sdxl.py:324-473, running/sdxl/generate.py:160-203)
+  * config 5: 3-step forward inversion + 3-step reverse with dynamic guidance tau = 0.7, 16 images per GPU
+    (running/sdxl/edit.py:196-226, running/sdxl/launch_editing_iCD_sdxl.sh:11-18)
+The CPU oracle cannot run these sizes in seconds, so they are checked through size-independent properties (bit
+reproducibility, batch independence = exact data-parallel sharding, the dynamic-guidance w sequence, finiteness); one
+full-width forward at 64x64 is compared with the oracle, and the image -> latent entry of the inversion is exercised
+with a full-width SDXL VAE at 1024x1024 from a tensor and from a PIL image.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_l2
+
+pytestmark = [pytest.mark.gpu, pytest.mark.slow]
+
+
+@pytest.fixture(scope="module")
+def sdxl():
+    from invertible_cd_amd import synthetic, unet
+    from invertible_cd_amd.pipelines import StableDiffusionXLImg2ImgPipeline, StableDiffusionXLPipeline
+    from invertible_cd_amd.schedulers import DDIMScheduler
+    from invertible_cd_amd.unet_config import SDXL
+    sd = synthetic.synthetic_state_dict(SDXL, seed=0, device="cuda", dtype=torch.float16)
+    u = unet.UNet2DConditionModel(SDXL, sd, device="cuda", dtype=torch.float16)
+    del sd
+    torch.cuda.empty_cache()
+    pipe = StableDiffusionXLPipeline(u, DDIMScheduler.sdxl(), device="cuda")
+    fwd = StableDiffusionXLImg2ImgPipeline(u, DDIMScheduler.sdxl(), device="cuda")      # same weights: properties only
+    return SDXL, pipe, fwd
+
+
+def _embeds(cfg, B, seed):
+    from invertible_cd_amd import synthetic
+    inp = synthetic.synthetic_inputs(cfg, B, 128, 128, seed=seed, device="cpu")
+    emb = {"prompt_embeds": inp["context"].cuda().half(), "text_embeds": inp["text_embeds"].cuda().half(),
+           "time_ids": inp["time_ids"].cuda()}
+    return inp["latents"].cuda().half(), emb
+
+
+def _fn(emb, rows=None):
+    def f(prompts, sizes, crops):
+        e = {k: (v if rows is None else v[rows]) for k, v in emb.items()}
+        assert e["prompt_embeds"].shape[0] == len(prompts)
+        return dict(e)
+    return f
+
+
+def test_config4_sdxl_b8_4step_reverse_properties(sdxl):
+    from invertible_cd_amd import generation_sdxl as G
+    cfg, pipe, _ = sdxl
+    B = 8
+    lat, emb = _embeds(cfg, B, seed=11)
+    run = lambda l, f, n: G.sample_deterministic(pipe, ["x"] * n, latents=l, num_inference_steps=4, guidance_scale=7.0, is_sdxl=True,
+                                                 timesteps=[249, 499, 699, 999], compute_embeddings_fn=f, return_latent=True)[1]
+    a = run(lat, _fn(emb), B)
+    b = run(lat, _fn(emb), B)
+    assert a.shape == (B, 4, 128, 128) and a.dtype == torch.float16 and torch.isfinite(a).all()
+    assert torch.equal(a, b)                                                   # bit reproducible
+    assert float(a.float().std()) > 0.05
+    sub = run(lat[2:4].contiguous(), _fn(emb, slice(2, 4)), 2)                 # rows 2..3 alone == rows 2..3 of the batch
+    e = rel_l2(sub, a[2:4])
+    print(f"[sdxl cfg4] batch independence rel-L2 = {e:.3e}")
+    assert e < 2e-3                                                            # different tile plans: fp rounding only
+
+
+def test_config5_sdxl_b16_3plus3_dynamic_guidance(sdxl, monkeypatch):
+    from invertible_cd_amd import generation_sdxl as G
+    cfg, pipe, fwd = sdxl
+    B = 16
+    lat, emb = _embeds(cfg, B, seed=12)
+    seen = []
+    orig = G._w_embedding
+    monkeypatch.setattr(G, "_w_embedding", lambda vals, dev, dt: (seen.append(tuple(float(v) for v in vals)), orig(vals, dev, dt))[1])
+
+    def edit(l, f, n):
+        inv = G.inverse_sample_deterministic(fwd, l, ["src"] * n, num_inference_steps=3, timesteps=[19, 339, 699],
+                                             guidance_scale=0.0, is_sdxl=True, compute_embeddings_fn=f, seed=3)
+        out = G.sample_deterministic(pipe, ["dst"] * n, latents=inv, num_inference_steps=3, guidance_scale=19.0, is_sdxl=True,
+                                     timesteps=[339, 699, 999], compute_embeddings_fn=f, use_dynamic_guidance=True, tau1=0.7,
+                                     tau2=0.7, return_latent=True)[1]
+        return inv, out
+
+    inv, out = edit(lat, _fn(emb), B)
+    assert inv.shape == out.shape == (B, 4, 128, 128) and torch.isfinite(inv).all() and torch.isfinite(out).all()
+    # w sequence: inversion w = 0 for the batch; reverse: the static embedding (gs) is built first, then per step
+    # (t = 999, 699, 339 with tau 0.7): 0, 19, 19 (step rule of a5)
+    assert seen[0] == (0.0,) * B and seen[1] == (19.0,) * B
+    assert [s[0] for s in seen[2:]] == [0.0, 19.0, 19.0] and all(len(s) == B for s in seen)
+    inv2, out2 = edit(lat, _fn(emb), B)
+    assert torch.equal(inv, inv2) and torch.equal(out, out2)
+    # batch independence: the CPU noise of prepare_latents is drawn per call for the whole batch, so compare the reverse
+    # half on identical inverted latents
+    sub = G.sample_deterministic(pipe, ["dst"] * 2, latents=inv[5:7].contiguous(), num_inference_steps=3, guidance_scale=19.0,
+                                 is_sdxl=True, timesteps=[339, 699, 999], compute_embeddings_fn=_fn(emb, slice(5, 7)),
+                                 use_dynamic_guidance=True, tau1=0.7, tau2=0.7, return_latent=True)[1]
+    e = rel_l2(sub, out[5:7])
+    print(f"[sdxl cfg5] batch independence rel-L2 = {e:.3e}")
+    assert e < 2e-3
+
+
+def test_full_sdxl_forward_64x64_vs_oracle():
+    """One full-width SDXL forward at 64x64 (B = 1, 1.7 TFLOP of CPU oracle) - the largest size the oracle checks."""
+    from test_unet_gpu import _run_case
+    from invertible_cd_amd.unet_config import SDXL
+    torch.cuda.empty_cache()
+    _run_case(SDXL, B=1, H=64, W=64, t=499, seed=7, tol=2e-3)
+
+
+def test_sdxl_inversion_from_image_tensor_and_pil(sdxl):
+    """running/sdxl/edit.py:196-207: PIL image -> image_processor.preprocess -> inverse_sample_deterministic ->
+    img2img prepare_latents (fp32 VAE encode, latent_dist.sample(generator) * 0.13025, add_noise at t = 19)."""
+    from PIL import Image
+    from invertible_cd_amd import generation_sdxl as G
+    from invertible_cd_amd import synthetic, vae
+    cfg, _, fwd = sdxl
+    v = vae.AutoencoderKL(vae.SDXL_VAE, synthetic.synthetic_vae_state_dict(vae.SDXL_VAE, seed=0, device="cuda", dtype=torch.float16),
+                          max_chunk=1)
+    fwd.vae = v
+    try:
+        rng = np.random.default_rng(0)
+        pil = Image.fromarray(rng.integers(0, 255, (600, 800, 3), dtype=np.uint8)).resize((1024, 1024))
+        x = fwd.image_processor.preprocess(pil)
+        assert x.shape == (1, 3, 1024, 1024) and x.dtype == torch.float32 and -1.0 <= float(x.min()) < float(x.max()) <= 1.0
+        ref = torch.from_numpy(np.asarray(pil, dtype=np.float32) / 255.0).permute(2, 0, 1)[None] * 2 - 1
+        assert torch.equal(x, ref)
+        _, emb = _embeds(cfg, 1, seed=13)
+        kw = dict(num_inference_steps=3, timesteps=[19, 339, 699], guidance_scale=0.0, is_sdxl=True,
+                  compute_embeddings_fn=_fn(emb), seed=5, return_start_latent=True)
+        lat_a, start_a = G.inverse_sample_deterministic(fwd, x, ["a photo"], **kw)
+        assert lat_a.shape == start_a.shape == (1, 4, 128, 128) and lat_a.dtype == torch.float16
+        assert torch.isfinite(lat_a).all() and torch.isfinite(start_a).all()
+        # the start latent is add_noise(sample * 0.13025, randn) with both draws from Generator().manual_seed(seed) on the CPU
+        v.to(torch.float32)
+        d = v.encode(x.cuda().half().float())["latent_dist"]
+        v.to(torch.float16)
+        g = torch.Generator().manual_seed(5)
+        init = (d.mean.cpu() + d.std.cpu() * torch.randn(d.mean.shape, generator=g)).half() * 0.13025
+        noise = torch.randn(init.shape, generator=g, dtype=torch.float16)
+        want = fwd.scheduler.add_noise(init.cuda(), noise.cuda(), torch.tensor([19]))      # fp16 arithmetic, as diffusers
+        assert torch.equal(start_a, want)
+        # a PIL input takes the same path
+        lat_b, start_b = G.inverse_sample_deterministic(fwd, pil, ["a photo"], **kw)
+        assert torch.equal(start_a, start_b) and torch.equal(lat_a, lat_b)
+    finally:
+        fwd.vae = None

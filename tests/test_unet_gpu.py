@@ -2,10 +2,13 @@
 and inputs.
 
 Tolerance: the product stores activations in fp16 (fp32 accumulate); the oracle is fp32 end to end.  Weights and inputs
-are rounded to fp16 on both sides so the comparison measures the kernels, not the weight quantisation.  Bars:
-  * reduced-width topologies:   rel-L2(eps) <= 2e-3
-  * full-width SD1.5 / SDXL:    rel-L2(eps) <= 3e-3   (~100-300 fp16-rounded layers deep; measured values are printed)
-The fp16 reference (diffusers fp16 on GPU) sits at the same distance from fp32 - see DESIGN.md "numerics".
+are rounded to fp16 on both sides so the comparison measures the kernels, not the weight quantisation.  The north star's
+bar is 1e-3 rel-L2 "of the reference", whose configs 2-5 run diffusers in fp16: every case therefore also runs the oracle's
+own graph in fp16 with stock torch ops on the GPU (the "fp16-torch noise floor": how far ANY fp16-storage pipeline sits
+from fp32 on these weights) and prints it next to the product's error.  Bars:
+  * product error <= 1.5 x the measured fp16-torch floor of the same case (the product may not be worse than fp16 torch), and
+  * absolute: reduced-width <= 2e-3, full-width SD1.5 / SDXL <= 2e-3 (measured 1.1e-3: ~100-300 fp16-rounded layers deep).
+`pytest -s` output of this file is kept as profiles/r02_parity.txt.
 """
 import pytest
 import torch
@@ -52,8 +55,15 @@ def _run_case(cfg, B, H, W, t, seed, tol, with_cond=True, n_ctx=77, f32_io=False
     assert eps.shape == lat.shape and eps.dtype == x.dtype
     assert torch.isfinite(eps).all()
     err = rel_l2(eps, ref)
-    print(f"[{cfg.name} B={B} {H}x{W} t={t}] rel-L2(eps) = {err:.3e}  |ref| rms = {ref.pow(2).mean().sqrt():.3f}")
+    # fp16-torch noise floor: the oracle's graph, fp16 weights / activations, stock torch kernels on the GPU
+    sd16 = {k: v.cuda().half() for k, v in sd.items()}
+    flo = unet_ref.unet_forward(sd16, _oracle_cfg(unet_ref, cfg), lat, t, ctx, timestep_cond=cond, added_cond=added)
+    floor = rel_l2(flo.float().cpu(), ref)
+    del sd16
+    print(f"[{cfg.name} B={B} {H}x{W} t={t}] rel-L2(eps) = {err:.3e}  fp16-torch floor = {floor:.3e}  ratio = {err / floor:.2f}  "
+          f"|ref| rms = {ref.pow(2).mean().sqrt():.3f}")
     assert err < tol
+    assert err <= 1.5 * floor + 1e-4, f"product error {err:.3e} is more than 1.5x the fp16-torch floor {floor:.3e}"
     # second call on the same handle (workspace reuse) must be bit-identical
     eps2 = model(x, torch.tensor(t), encoder_hidden_states=ctx.cuda(), timestep_cond=None if cond is None else cond.cuda(),
                  added_cond_kwargs=None if added is None else {k: v.cuda() for k, v in added.items()}, return_dict=False)[0]
@@ -82,18 +92,18 @@ def test_unet_tiny_sdxl_topology():
 def test_unet_full_sd15_small_latent():
     """Full-width SD1.5 UNet (859.7 M parameters) on a 32x32 latent."""
     _, _, uc, _ = _mods()
-    _run_case(uc.SD15, B=2, H=32, W=32, t=519, seed=4, tol=3e-3)
+    _run_case(uc.SD15, B=2, H=32, W=32, t=519, seed=4, tol=2e-3)
 
 
 @pytest.mark.slow
 def test_unet_full_sd15_64x64():
     """BASELINE config-1 shape: full SD1.5, 64x64 latent (512x512 image), CFG-doubled batch of 2."""
     _, _, uc, _ = _mods()
-    _run_case(uc.SD15, B=2, H=64, W=64, t=999, seed=5, tol=3e-3)
+    _run_case(uc.SD15, B=2, H=64, W=64, t=999, seed=5, tol=2e-3)
 
 
 @pytest.mark.slow
 def test_unet_full_sdxl_small_latent():
     """Full-width SDXL UNet (2.57 G parameters) on a 32x32 latent (oracle: ~0.4 TFLOP)."""
     _, _, uc, _ = _mods()
-    _run_case(uc.SDXL, B=1, H=32, W=32, t=699, seed=6, tol=3e-3)
+    _run_case(uc.SDXL, B=1, H=32, W=32, t=699, seed=6, tol=2e-3)

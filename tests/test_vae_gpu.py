@@ -81,8 +81,8 @@ def test_chunking_and_interface():
         m.decode(torch.zeros(1, 3, 8, 8))
     with pytest.raises(ValueError):
         m.encode(torch.zeros(1, 3, 20, 16))
-    with pytest.raises(NotImplementedError):
-        m.encode(torch.zeros(1, 3, 16, 16))["latent_dist"].sample()
+    smp = m.encode(torch.zeros(1, 3, 16, 16))["latent_dist"].sample(torch.Generator().manual_seed(0))
+    assert smp.shape == (1, 4, 2, 2) and torch.isfinite(smp).all()
     bad = dict(sd); bad.pop("decoder.conv_out.bias")
     with pytest.raises(KeyError):
         vae.AutoencoderKL(cfg, bad)
@@ -101,3 +101,24 @@ def test_full_width_properties():
     assert rel_l2(one.float(), a[1:2].float()) < 2e-3                # other samples in the batch do not matter
     lat = m.encode(a.clamp(-1, 1))["latent_dist"].mean
     assert lat.shape == (3, 4, 64, 64) and torch.isfinite(lat).all()
+
+
+def test_encode_moments_and_sample_match_oracle():
+    """`latent_dist` carries all 8 moment channels (utils/generation_sdxl.py:273-276 draws `.sample(generator)`):
+    mean / logvar vs the oracle's quant_conv(encoder(x)), std = exp(0.5 * clamp(logvar, -30, 20)), and the sample drawn
+    from a CPU generator like diffusers' randn_tensor."""
+    cfg, sd, ocfg, vae, vae_ref = _setup((32, 64, 128, 128), seed=11)
+    m = vae.AutoencoderKL(cfg, sd, dtype=torch.float32)
+    x = (torch.rand(2, 3, 64, 96, generator=torch.Generator().manual_seed(8)) * 2 - 1).half().float()
+    d = m.encode(x.cuda()).latent_dist
+    mom = vae_ref.encode_moments(sd, ocfg, x)
+    e_mean, e_lv = rel_l2(d.mean.cpu(), mom[:, :4]), rel_l2(d.logvar.cpu(), mom[:, 4:].clamp(-30, 20))
+    print(f"[vae moments] mean rel-L2 = {e_mean:.3e}  logvar rel-L2 = {e_lv:.3e}")
+    assert e_mean < 3e-3 and e_lv < 3e-3
+    assert torch.allclose(d.std, torch.exp(0.5 * d.logvar)) and torch.allclose(d.var, torch.exp(d.logvar))
+    s1 = d.sample(torch.Generator().manual_seed(21))
+    noise = torch.randn(d.mean.shape, generator=torch.Generator().manual_seed(21), dtype=d.mean.dtype)
+    assert torch.equal(s1.cpu(), (d.mean + d.std * noise.cuda()).cpu())
+    assert s1.shape == (2, 4, 8, 12) and not torch.equal(s1, d.mean)
+    s2 = d.sample(torch.Generator(device="cuda").manual_seed(21))            # a device generator draws on the device
+    assert s2.is_cuda and torch.isfinite(s2).all() and not torch.equal(s1, s2)

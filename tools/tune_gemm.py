@@ -1,0 +1,139 @@
+#!/usr/bin/env python3
+"""Planner audit: every distinct GEMM / conv shape of one UNet forward, timed under each tile family the planner can
+force (ICD_GEMM_TUNE_*), same process, same clocks.  Output: one row per shape with the planner's own time, the best
+forced configuration and the ratio - the data the cost model in gemm.hip is calibrated against.
+
+    python tools/tune_gemm.py --arch sdxl --batch 8 [--min-us 20]
+"""
+import argparse
+import collections
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from invertible_cd_amd import _lib, synthetic, unet
+from invertible_cd_amd.unet_config import SD15, SDXL
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--arch", default="sd15")
+ap.add_argument("--batch", type=int, default=32)
+ap.add_argument("--min-us", type=float, default=15.0, help="skip shapes whose launches are shorter than this")
+ap.add_argument("--iters", type=int, default=12)
+a = ap.parse_args()
+cfg = SD15 if a.arch == "sd15" else SDXL
+res = 64 if a.arch == "sd15" else 128
+sd = synthetic.synthetic_state_dict(cfg, seed=0, device="cuda", dtype=torch.float16)
+m = unet.UNet2DConditionModel(cfg, sd)
+del sd
+inp = synthetic.synthetic_inputs(cfg, a.batch, res, res, device="cuda")
+kw = dict(encoder_hidden_states=inp["context"].half(), timestep_cond=torch.randn(a.batch, 512, device="cuda").half())
+if a.arch == "sdxl":
+    kw["added_cond_kwargs"] = {"text_embeds": inp["text_embeds"].half(), "time_ids": inp["time_ids"]}
+x = inp["latents"].half()
+m(x, 999, **kw); torch.cuda.synchronize()
+_lib.profile_enable(True)
+m(x, 999, **kw)
+torch.cuda.synchronize()
+recs = _lib.profile_dump()
+_lib.profile_enable(False)
+del m
+torch.cuda.empty_cache()
+agg = collections.OrderedDict()
+for fam, M, N, K, aux, ms, fl in recs:
+    if fam not in ("gemm_conv", "gemm_dense"):
+        continue
+    e = agg.setdefault((fam, M, N, K, aux), [0, 0.0])
+    e[0] += 1; e[1] += ms
+
+CONFIGS = [("plan", 0), ("b256x256", 1 << 24), ("b256x320", 2 << 24), ("b192x256", 3 << 24), ("b128x320", 4 << 24),
+           ("t128x128", 0x40000), ("t256x128", 0x80000)]
+lib = _lib.load()
+g = torch.Generator(device="cuda").manual_seed(0)
+rnd = lambda *s: torch.randn(*s, device="cuda", generator=g).half()
+
+
+def make(fam, M, N, K, aux):
+    d = _lib.GemmDesc()
+    keep = []
+    if fam == "gemm_conv":
+        ks, st, up = aux // 100, (aux // 10) % 10, aux % 10
+        Cin = K // (ks * ks)
+        hw = M // a.batch
+        Ho = int(round(hw ** 0.5)); Wo = hw // Ho
+        Hin, Win = (Ho * st, Wo * st) if not up else (Ho // 2, Wo // 2)
+        xx, w, b = rnd(a.batch * Hin * Win, Cin), rnd(N, K) * K ** -0.5, torch.zeros(N, device="cuda")
+        out = torch.empty((M, N), device="cuda", dtype=torch.float16)
+        d.a0, d.w, d.out, d.bias = xx.data_ptr(), w.data_ptr(), out.data_ptr(), b.data_ptr()
+        d.M, d.N, d.K, d.Nw, d.ldw, d.ldo = M, N, K, N, K, N
+        d.rows_per_sample, d.mode, d.C0, d.Hin, d.Win, d.Hout, d.Wout, d.ksize, d.stride, d.upsample = hw, 1, Cin, Hin, Win, Ho, Wo, ks, st, up
+        d.batch, d.zdiv, d.alpha = 1, 1, 1.0
+        base = 0
+        keep += [xx, w, b, out]
+    else:
+        geglu, trans = aux & 1, aux & 4
+        xx, w, b = rnd(M, K), rnd(N, K) * K ** -0.5, torch.zeros(N, device="cuda")
+        if trans:
+            rps = M // a.batch
+            out = torch.empty((a.batch, N, rps), device="cuda", dtype=torch.float16)
+            ldo = rps
+        else:
+            out = torch.empty((M, N // 2 if geglu else N), device="cuda", dtype=torch.float16)
+            ldo = out.stride(0)
+        res = rnd(M, N) if not (geglu or trans) else None
+        d.a0, d.w, d.out = xx.data_ptr(), w.data_ptr(), out.data_ptr()
+        d.bias = b.data_ptr() if not trans else None
+        d.resid = res.data_ptr() if res is not None else None
+        d.M, d.N, d.K, d.Nw, d.lda, d.ldw, d.ldo, d.ldr = M, N, K, N, K, K, ldo, N
+        d.rows_per_sample = M // a.batch if trans else 0
+        d.mode, d.batch, d.zdiv, d.alpha = 0, 1, 1, 1.0
+        base = aux & 5
+        keep += [xx, w, b, out, res]
+    n = lib.icd_gemm_workspace_bytes(M, N, K)
+    if n > 0 and not (aux & 5 and fam == "gemm_dense"):
+        ws = torch.empty((n,), dtype=torch.uint8, device="cuda")
+        d.splitk_ws, d.splitk_ws_bytes = ws.data_ptr(), n
+        keep.append(ws)
+    return d, base, keep
+
+
+def time_cfg(d, flags):
+    d.flags = flags
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for _ in range(3):
+        if lib.icd_gemm(C.byref(d), st) != 0:
+            return None
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(a.iters):
+        lib.icd_gemm(C.byref(d), st)
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / a.iters * 1e3
+
+
+print(f"# {a.arch} B={a.batch}: us per call, plan = the planner's own choice; * = best")
+print(f"{'family':11s} {'M':>7s} {'N':>6s} {'K':>6s} {'aux':>4s} {'n':>4s} " + " ".join(f"{n:>9s}" for n, _ in CONFIGS) + "   best/plan  saved_us_per_fwd")
+tot_saved = 0.0
+for (fam, M, N, K, aux), (cnt, ms) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+    if ms / cnt * 1e3 < a.min_us:
+        continue
+    d, base, keep = make(fam, M, N, K, aux)
+    ts = []
+    for name, fl in CONFIGS:
+        t = time_cfg(d, base | fl)
+        if t is None:
+            lib.icd_last_error()
+        ts.append(t)
+    t_plan = time_cfg(d, base) or ts[0]                 # planner again, last (first-measurement bias check)
+    ts[0] = min(ts[0], t_plan) if ts[0] else t_plan
+    valid = [t for t in ts if t is not None]
+    best = min(valid)
+    row = " ".join((f"{t:8.1f}{'*' if t == best else ' '}" if t is not None else f"{'-':>9s}") for t in ts)
+    saved = (ts[0] - best) * cnt
+    tot_saved += saved
+    print(f"{fam:11s} {M:7d} {N:6d} {K:6d} {aux:4d} {cnt:4d} {row}   {best / ts[0]:8.3f}  {saved:9.1f}")
+    del d, keep
+print(f"# total time a perfect planner would save per forward: {tot_saved / 1e3:.3f} ms")

@@ -60,7 +60,8 @@ int icd_version(void);
 #define ICD_GEMM_TUNE_FORCE_BIG  0x00100000   /* take a 256-wide tile (gemm_big.hip) whatever the chip fill           */
 #define ICD_GEMM_TUNE_NO_BIG     0x00200000   /* never take one                                                      */
 #define ICD_GEMM_TUNE_BN256      0x00400000   /* big tiles: only the BN = 256 shapes                                 */
-#define ICD_GEMM_TUNE_BIG_CFG(i) (((i) + 1) << 24)   /* force big-tile configuration i (0..3, see gemm_common.h)      */
+#define ICD_GEMM_TUNE_BIG_CFG(i) (((i) + 1) << 24)   /* force big-tile configuration i (0..5, see gemm_common.h; 5 = the     */
+                                                     /* 256x128 two-blocks-per-CU tile of gemm_pp.hip)                      */
 
 /* out = alpha * (A (*) W^T) + bias[n] + rowbias[m / rows_per_sample][n] + resid[m][n]
  * A is either a dense row-major [M, K] matrix (mode 0; Linear, 1x1 conv, attention bmm) or the implicit im2col
@@ -89,6 +90,14 @@ typedef struct {
     int32_t flags;
     void* splitk_ws;          /* optional fp32 scratch for split-K partial tiles (small-M / deep-K shapes); NULL: never split */
     int64_t splitk_ws_bytes;
+    /* LayerNorm fused into the GEMM that consumes it (BasicTransformerBlock: norm1 -> to_q/k/v, norm2 -> attn2.to_q,
+     * norm3 -> ff.net.0.proj): A is the UN-normalised row-major activation, W has the LayerNorm gamma folded into its
+     * columns, ln_stats is fp32 [M][2] = (mean, rstd) per row (icd_layernorm_stats) and ln_colsum fp32 [N] the row sums of
+     * the gamma-scaled W; the epilogue computes  rstd_m * (alpha * (A W^T)[m][n] - mean_m * ln_colsum[n]) + bias[n] ...
+     * with (W beta + original bias) passed as `bias`.  Exactly LN(A) W^T + bias in real arithmetic; the normalised
+     * activation is never written.  Both NULL: plain GEMM.  Dense (mode 0), batch 1, fp16 output only. */
+    const float* ln_stats;
+    const float* ln_colsum;
 } icd_gemm_desc;
 
 int icd_gemm(const icd_gemm_desc* d, void* stream);
@@ -106,6 +115,9 @@ int64_t icd_groupnorm_ws_floats(int32_t B, int32_t HW, int32_t groups);
 /* LayerNorm over the last dim of [rows, C] fp16 (eps 1e-5, affine).  Replaces torch layer_norm in BasicTransformerBlock. */
 int icd_layernorm(const void* x, int64_t rows, int32_t C, const float* gamma, const float* beta, float eps, void* out,
                   void* stream);
+/* Statistics half of LayerNorm: stats[r] = (mean, 1/sqrt(var + eps)) of row r (fp32 [rows][2], exact two-pass variance);
+ * the normalisation itself is applied by the consuming GEMM (icd_gemm_desc.ln_stats). */
+int icd_layernorm_stats(const void* x, int64_t rows, int32_t C, float eps, float* stats, void* stream);
 
 /* Row softmax: P[r, 0:cols] = softmax(scale * S[r, 0:cols]) (fp32 in, fp16 out, pad columns [cols, ld) zeroed).
  * Replaces Attention.get_attention_scores' softmax (utils/p2p.py:335). */
@@ -292,6 +304,11 @@ int icd_profile_dump(icd_profile_record* recs, int32_t max_recs);
  * is registered, every block of the 256-wide GEMM tiles stamps s_memrealtime (100 MHz) at: start, first k-tile landed,
  * main loop done, epilogue done.  NULL switches it off.  No reference counterpart. */
 int icd_debug_gemm_timeline(void* buf);
+/* m-tiles per L2 group of the GEMM block -> tile map (0: default).  A/B tuning only; results are unchanged. */
+int icd_debug_gemm_group_m(int32_t gm);
+/* Planner calibration of the two-blocks-per-CU tile (gemm_pp.hip): enable = may the planner pick it; tk / fixed_* > 0
+ * replace the cost-model constants (units: one k-tile of a 256x256x64 block).  A/B tuning only. */
+int icd_debug_gemm_pp(int32_t enable, double tk, double fixed_alone, double fixed_pair);
 
 #ifdef __cplusplus
 }

@@ -29,6 +29,7 @@ class GemmDesc(C.Structure):
         ("a_bs0", C.c_int64), ("a_bs1", C.c_int64), ("w_bs0", C.c_int64), ("w_bs1", C.c_int64),
         ("o_bs0", C.c_int64), ("o_bs1", C.c_int64), ("alpha", C.c_float), ("flags", C.c_int32),
         ("splitk_ws", C.c_void_p), ("splitk_ws_bytes", C.c_int64),
+        ("ln_stats", C.c_void_p), ("ln_colsum", C.c_void_p),
     ]
 
 
@@ -78,6 +79,7 @@ SIGNATURES = {
     "icd_groupnorm_ws_floats": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
     "icd_layernorm": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p,
                                 C.c_void_p]),
+    "icd_layernorm_stats": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]),
     "icd_softmax_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_int32,
                                    C.c_void_p]),
     "icd_attention_fused": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
@@ -111,6 +113,8 @@ SIGNATURES = {
     "icd_conv_out_n": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
                                  C.c_void_p, C.c_int32, C.c_void_p]),
     "icd_debug_gemm_timeline": (C.c_int, [C.c_void_p]),
+    "icd_debug_gemm_group_m": (C.c_int, [C.c_int32]),
+    "icd_debug_gemm_pp": (C.c_int, [C.c_int32, C.c_double, C.c_double, C.c_double]),
     "icd_profile_enable": (C.c_int, [C.c_int32]),
     "icd_profile_read": (C.c_int, [C.POINTER(ProfileRow), C.c_int32]),
     "icd_profile_dump": (C.c_int, [C.POINTER(ProfileRecord), C.c_int32]),

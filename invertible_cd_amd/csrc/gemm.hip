@@ -45,15 +45,12 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_kernel(GemmK p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, wv = tid >> 6, l = tid & 63;
     const int wm = wv >> 1, wn = wv & 1;
+    unsigned long long* tl = p.timeline ? p.timeline + (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 : nullptr;
+    if (tl && tid == 0) { tl[0] = __builtin_amdgcn_s_memrealtime(); tl[1] = tl[0]; }
 
     // ---- XCD-aware tile id ------------------------------------------------------------------------------
-    const int nblk = p.nbm * p.nbn;
-    int bid = blockIdx.x;
-    {
-        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    }
-    const int mt = bid / p.nbn, nt = bid - mt * p.nbn;
+    int mt, nt;
+    tile_of_block(blockIdx.x, p.nbm, p.nbn, p.gm, mt, nt);
     const int m0 = mt * BM, n0 = nt * BN;
     const int split = blockIdx.y;
     const int nk_total = (p.K + BK - 1) / BK;
@@ -269,6 +266,7 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_kernel(GemmK p) {
 #undef ICD_GLDS4
 
     // ---- epilogue: fp32 staging through LDS, one 64-row slab (one wave row) at a time ----------------------
+    if (tl && tid == 0) tl[2] = __builtin_amdgcn_s_memrealtime();
     float* stage = reinterpret_cast<float*>(smem);
     const bool geglu = p.flags & ICD_GEMM_GEGLU;
     const bool out_f32 = p.flags & ICD_GEMM_OUT_F32;
@@ -315,11 +313,22 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_kernel(GemmK p) {
                 const float* sp = stage + nl * EPI_LD_T + mc;
                 f32x4 v0 = *reinterpret_cast<const f32x4*>(sp), v1 = *reinterpret_cast<const f32x4*>(sp + 4);
                 float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] *= p.alpha;
+                if (p.ln_stats) {
+                    const float sn = p.ln_s[n];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (m + e < p.M) {
+                            const f32x2 st = *reinterpret_cast<const f32x2*>(p.ln_stats + 2 * (long long)(m + e));
+                            v[e] = st[1] * (v[e] - st[0] * sn);
+                        }
+                }
                 const int b = m / p.rps, key = m - b * p.rps;
                 if (key + 8 <= p.rps && m + 8 <= p.M && (key & 7) == 0 && (p.ldo & 7) == 0) {
                     f16x8 o;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] = (half_t)(v[e] * p.alpha);
+                    for (int e = 0; e < 8; ++e) o[e] = (half_t)v[e];
                     *reinterpret_cast<f16x8*>(out + ((long long)b * p.N + n) * p.ldo + key) = o;
                     if (key + 8 == p.rps)
                         for (int kk = p.rps; kk < p.ldo; ++kk) out[((long long)b * p.N + n) * p.ldo + kk] = (half_t)0.f;
@@ -329,7 +338,7 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_kernel(GemmK p) {
                         if (mm >= p.M) break;
                         const int bb = mm / p.rps, kk = mm - bb * p.rps;
                         half_t* row = out + ((long long)bb * p.N + n) * p.ldo;
-                        row[kk] = (half_t)(v[e] * p.alpha);
+                        row[kk] = (half_t)v[e];
                         if (kk == p.rps - 1)
                             for (int k2 = p.rps; k2 < p.ldo; ++k2) row[k2] = (half_t)0.f;
                     }
@@ -349,6 +358,17 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_kernel(GemmK p) {
                 f32x4 g0 = *reinterpret_cast<const f32x4*>(sp + 32), g1 = *reinterpret_cast<const f32x4*>(sp + 36);
                 float hv[8] = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
                 float gv[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
+                if (p.ln_stats) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { hv[e] *= p.alpha; gv[e] *= p.alpha; }
+                    ln_correct8(hv, p.ln_stats, p.ln_s, m, n0 + hcol);
+                    ln_correct8(gv, p.ln_stats, p.ln_s, m, n0 + hcol + 32);
+                    if (p.bias) {
+                        const float* bp = p.bias + n0 + hcol;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { hv[e] += bp[e]; gv[e] += bp[32 + e]; }
+                    }
+                } else
                 if (p.bias) {
                     const float* bp = p.bias + n0 + hcol;
                     f32x4 b0 = *reinterpret_cast<const f32x4*>(bp), b1 = *reinterpret_cast<const f32x4*>(bp + 4);
@@ -379,6 +399,7 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_kernel(GemmK p) {
                 float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] *= p.alpha;
+                if (p.ln_stats) ln_correct8(v, p.ln_stats, p.ln_s, m, n);
                 if (p.bias) {
                     f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n), b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
 #pragma unroll
@@ -407,6 +428,10 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_kernel(GemmK p) {
             }
         }
     }
+    if (tl) {
+        __syncthreads();
+        if (tid == 0) tl[3] = __builtin_amdgcn_s_memrealtime();
+    }
 }
 
 // split-K second pass: out = alpha * sum_s partial[s] + bias + rowbias + resid   (thread = 8 consecutive columns)
@@ -424,6 +449,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmK p) {
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] *= p.alpha;
+    if (p.ln_stats) ln_correct8(v, p.ln_stats, p.ln_s, m, n);
     if (p.bias) {
         f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n), b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
 #pragma unroll
@@ -513,6 +539,20 @@ extern "C" int64_t icd_gemm_workspace_bytes(int32_t M, int32_t N, int32_t K) {
     return need;
 }
 
+// Planner constants of the two-blocks-per-CU tile (gemm_pp.hip), in k-tiles of a 256 x 256 x 64 block like BIG_TILES:
+// PP_TK = one 32-deep k-tile of one 256 x 128 block with a co-resident partner; fixed = prologue + exposed epilogue.
+static double PP_TK = 0.30, PP_FIXED_ALONE = 8.0, PP_FIXED_PAIR = 4.0;
+static int g_pp_auto = 0;                        // 1: the planner may pick the tile on its own (set once it is calibrated)
+extern "C" int icd_debug_gemm_pp(int32_t enable, double tk, double fixed_alone, double fixed_pair) {
+    g_pp_auto = enable;
+    if (tk > 0) { PP_TK = tk; PP_FIXED_ALONE = fixed_alone; PP_FIXED_PAIR = fixed_pair; }
+    return ICD_OK;
+}
+
+static int g_group_m = 0;
+// Tuning override of the L2 grouping of the block -> tile map (0: the planner's default); results never change.
+extern "C" int icd_debug_gemm_group_m(int32_t gm) { g_group_m = gm; return ICD_OK; }
+
 static unsigned long long* g_timeline = nullptr;
 // Diagnostics: while a buffer is registered, every big-tile GEMM block writes four s_memrealtime stamps (100 MHz:
 // block start, first k-tile landed, main loop done, epilogue done) to buf[4 * linear block id].  buf == NULL: off.
@@ -528,7 +568,7 @@ extern "C" int icd_gemm(const icd_gemm_desc* d, void* stream) {
     const bool trans = d->flags & ICD_GEMM_OUT_TRANS;
     const bool geglu = d->flags & ICD_GEMM_GEGLU;
     ICD_CHECK_ARG(!(trans && (geglu || (d->flags & ICD_GEMM_OUT_F32) || d->bias || d->resid || d->rowbias)),
-                  "icd_gemm: transposed output supports alpha only");
+                  "icd_gemm: transposed output supports alpha (and the fused LayerNorm) only");
     ICD_CHECK_ARG(!(geglu && (d->resid || d->rowbias || (d->flags & ICD_GEMM_OUT_F32) || d->N % 64 != 0)),
                   "icd_gemm: GEGLU needs N %% 64 == 0 and no resid/rowbias/f32 output");
     if (d->rowbias || trans) ICD_CHECK_ARG(d->rows_per_sample > 0, "icd_gemm: rows_per_sample required");
@@ -545,6 +585,11 @@ extern "C" int icd_gemm(const icd_gemm_desc* d, void* stream) {
     k.a_bs0 = d->a_bs0; k.a_bs1 = d->a_bs1; k.w_bs0 = d->w_bs0; k.w_bs1 = d->w_bs1; k.o_bs0 = d->o_bs0; k.o_bs1 = d->o_bs1;
     k.alpha = d->alpha; k.flags = d->flags;
     k.timeline = g_timeline;
+    k.gm = g_group_m > 0 ? g_group_m : 1;        // the planner widens it below for launches with many n-tiles
+    k.ln_stats = d->ln_stats; k.ln_s = d->ln_colsum;
+    ICD_CHECK_ARG((d->ln_stats == nullptr) == (d->ln_colsum == nullptr), "icd_gemm: ln_stats and ln_colsum go together");
+    ICD_CHECK_ARG(!(d->ln_stats && (d->mode != 0 || (d->batch > 1) || (d->flags & ICD_GEMM_OUT_F32))),
+                  "icd_gemm: the fused LayerNorm applies to dense, unbatched, fp16-output GEMMs");
     const int batch = d->batch > 0 ? d->batch : 1;
     int wm = 2, ks = 1;
     const bool allow_split = !trans && !geglu && batch == 1 && d->splitk_ws != nullptr && d->splitk_ws_bytes > 0;
@@ -566,6 +611,7 @@ extern "C" int icd_gemm(const icd_gemm_desc* d, void* stream) {
         for (int ci = 0; ci < NUM_BIG_TILES && base_ok; ++ci) {
             const BigTile& c = BIG_TILES[ci];
             if (forced >= 0 && ci != forced) continue;
+            if (ci == PP_CFG) continue;                                                     // planned below
             if (ci == 4 && (d->mode != 0 || (nk_total & 1) || nk_total < 2)) continue;     // asm tile: dense, even k-tile count
             if (d->N % c.bn != 0 || (geglu && !c.geglu_ok) || ((d->flags & ICD_GEMM_TUNE_BN256) && c.bn != 256)) continue;
             const long long b0 = (long long)((d->M + c.bm - 1) / c.bm) * (d->N / c.bn);
@@ -590,9 +636,55 @@ extern "C" int icd_gemm(const icd_gemm_desc* d, void* stream) {
                 if (cost < best) { best = cost; cfg = ci; s = sx; best_fill = (double)bt / (double)(((bt + 255) / 256) * 256); }
             }
         }
+        // ---- two-blocks-per-CU tile (gemm_pp.hip): 256 x 128 x 32 ------------------------------------------------------------
+        {
+            const bool conv32 = d->mode == 1 && ((d->C0 + d->C1) % 32 == 0) && (d->C0 % 32 == 0);
+            const bool pp_ok = batch == 1 && trans_ok && (d->mode == 0 || conv32) && d->M >= 256 && (d->Nw <= 0 || d->Nw >= d->N) &&
+                               (d->K % 32 == 0) && (!geglu || d->N % 128 == 0) && (!trans || d->N % 64 == 0);
+            const bool pp_forced = forced == PP_CFG;
+            const bool pp_auto = forced < 0 && g_pp_auto && !(d->flags & (ICD_GEMM_TUNE_NO_BIG | ICD_GEMM_TUNE_BN256));
+            if (pp_ok && (pp_forced || pp_auto)) {
+                const int nk32 = d->K / 32;
+                const long long b0 = (long long)((d->M + 255) / 256) * ((d->N + 127) / 128);
+                int sx = 1;
+                if (allow_split && b0 < 384 && nk32 >= 32) {                     // 512 slots on the chip
+                    sx = (int)((512 + b0 - 1) / b0);
+                    sx = sx > 8 ? 8 : sx;
+                    while (sx > 1 && nk32 / sx < 16) --sx;
+                    while (sx > 1 && (long long)sx * d->M * d->N * 4 > d->splitk_ws_bytes) --sx;
+                }
+                const long long bt = b0 * sx;
+                // cost in the same unit (k-tiles of a 256 x 256 x 64 block): two resident blocks share a CU's matrix pipe, a
+                // block's fixed costs overlap the other's MFMAs once more than one block per CU is queued
+                const double per_cu = (double)((bt + 255) / 256);                // blocks a CU processes (ceil)
+                const int kps = (nk32 + sx - 1) / sx;
+                double cost = per_cu * kps * PP_TK + (bt <= 256 ? PP_FIXED_ALONE : PP_FIXED_PAIR);
+                if (sx > 1) cost += (double)(sx + 1) * d->M * d->N * 4.0 / 3.5e12 / 1.5e-6 + 4.0;
+                if (pp_forced || cost < best) {
+                    k.nbm = (d->M + 255) / 256; k.nbn = (d->N + 127) / 128;
+                    if (g_group_m <= 0 && k.nbn >= 16) k.gm = 8;
+                    k.kt_per_split = (nk32 + sx - 1) / sx;
+                    k.ksplit = (nk32 + k.kt_per_split - 1) / k.kt_per_split;
+                    if (d->mode == 1) {
+                        ICD_CHECK_ARG(d->ksize == 1 || d->ksize == 3, "icd_gemm: conv ksize must be 1 or 3");
+                        ICD_CHECK_ARG(d->K == d->ksize * d->ksize * (d->C0 + d->C1), "icd_gemm: K != taps*Cin");
+                        ICD_CHECK_ARG((d->C1 == 0) == (d->a1 == nullptr), "icd_gemm: a1/C1 mismatch");
+                    } else {
+                        k.ksize = 0; k.Hout = 0;
+                        ICD_CHECK_ARG(d->lda % 8 == 0, "icd_gemm: lda must be a multiple of 8");
+                    }
+                    const int rc = launch_pp(k, st);
+                    if (rc != ICD_OK) return rc;
+                    if (k.ksplit > 1) return launch_reduce(k, st);
+                    return ICD_OK;
+                }
+            }
+            ICD_CHECK_ARG(!pp_forced, "icd_gemm: the forced 256x128 two-per-CU tile does not support this shape");
+        }
         if (cfg >= 0 && (best_fill >= 0.45 || forced >= 0 || (d->flags & ICD_GEMM_TUNE_FORCE_BIG))) {
             const BigTile& c = BIG_TILES[cfg];
             k.nbm = (d->M + c.bm - 1) / c.bm; k.nbn = d->N / c.bn;
+            if (g_group_m <= 0 && k.nbn >= 16) k.gm = 8;        // measured: +5 % on N = 10240 (40 n-tiles), nothing to gain on few n-tiles
             k.kt_per_split = (nk_total + s - 1) / s;
             k.ksplit = (nk_total + k.kt_per_split - 1) / k.kt_per_split;
             if (d->mode == 1) {
@@ -616,6 +708,7 @@ extern "C" int icd_gemm(const icd_gemm_desc* d, void* stream) {
     k.kt_per_split = (nk_total + ks - 1) / ks;
     k.ksplit = (nk_total + k.kt_per_split - 1) / k.kt_per_split;      // no empty splits
     k.nbm = (d->M + wm * 64 - 1) / (wm * 64); k.nbn = (d->N + BN - 1) / BN;
+    if (g_group_m <= 0 && k.nbn >= 16) k.gm = 8;
     if (d->mode == 1) {
         ICD_CHECK_ARG(d->ksize == 1 || d->ksize == 3, "icd_gemm: conv ksize must be 1 or 3");
         ICD_CHECK_ARG(d->stride == 1 || d->stride == 2, "icd_gemm: conv stride must be 1 or 2");

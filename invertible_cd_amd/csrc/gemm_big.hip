@@ -12,6 +12,7 @@
 //   * Loader, swizzle, epilogue and split-K are those of gemm.hip (same LDS image, same epilogue arithmetic).
 #include <type_traits>
 #include "gemm_common.h"
+#include "gemm_epilogue.h"
 
 using namespace icd_gemm_detail;
 
@@ -32,13 +33,8 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 1 : 2) void gemm_big_k
     unsigned long long* tl = p.timeline ? p.timeline + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 : nullptr;
     if (tl && tid == 0) tl[0] = __builtin_amdgcn_s_memrealtime();
 
-    const int nblk = p.nbm * p.nbn;
-    int bid = blockIdx.x;
-    {
-        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    }
-    const int mt = bid / p.nbn, nt = bid - mt * p.nbn;
+    int mt, nt;
+    tile_of_block(blockIdx.x, p.nbm, p.nbn, p.gm, mt, nt);
     const int m0 = mt * BM, n0 = nt * BNt;
     const int split = blockIdx.y;
     const int nk_total = (p.K + BK - 1) / BK;
@@ -282,144 +278,8 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 1 : 2) void gemm_big_k
     }
 
     }
-    // ---- epilogue: every wave transposes its own accumulators through a private LDS patch ----------------------------
-    // A block owns its CU alone (128+ KiB of LDS), so nothing overlaps the epilogue: it has to be short.  No block-wide
-    // slabs / barriers: after one barrier (all fragment reads done) each wave stages 32 rows x 64 columns of fp32 at a
-    // time in its own 8.5 KiB patch and streams them out as 128-B row segments; the 8 waves hide each other's
-    // residual-load / store latency.
-    const bool geglu = p.flags & ICD_GEMM_GEGLU;
-    const bool out_f32 = p.flags & ICD_GEMM_OUT_F32;
-    constexpr int LDW = 68;                                      // floats per staged row (64 + 4: conflict-free b128 writes)
-    constexpr int LDT = 36;                                      // transposed patch: [64 n][32 m + 4]
-    const bool trans = p.flags & ICD_GEMM_OUT_TRANS;
-    __syncthreads();
-    if (tl && tid == 0) tl[2] = __builtin_amdgcn_s_memrealtime();
-    float* wst = reinterpret_cast<float*>(smem) + wv * (trans ? 64 * LDT : 32 * LDW);
-    float* part = p.ksplit > 1 ? p.partial + (long long)split * p.M * p.N : nullptr;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int mrow0 = m0 + (wm * TM + i) * 32;
-#pragma unroll
-        for (int j0 = 0; j0 < TN; j0 += 2) {
-            const int jn = (TN - j0) >= 2 ? 2 : 1;               // j-tiles in this group (compile-time after unrolling)
-            if (trans) {
-                // V^T epilogue: out[(b*N + n)*ldo + key], (b, key) = divmod(m, rows_per_sample).  The patch is staged
-                // transposed ([n][m]); lane l then owns column n = l with the 32 consecutive keys of this i-tile
-                // (the planner guarantees rows_per_sample % 32 == 0 and M % 32 == 0: a tile never straddles samples).
-#pragma unroll
-                for (int jj = 0; jj < 2; ++jj) {
-                    if (jj >= jn) break;
-#pragma unroll
-                    for (int e = 0; e < 16; ++e)
-                        wst[(jj * 32 + 8 * (e >> 2) + 4 * lh + (e & 3)) * LDT + lr] = acc[i][j0 + jj][e];
-                }
-                const int n = (wn * TN + j0) * 32 + l;               // column inside the block tile
-                if (l < jn * 32 && n0 + n < p.N && mrow0 < p.M) {
-                    const int b = mrow0 / p.rps, key0 = mrow0 - b * p.rps;
-                    half_t* dst = reinterpret_cast<half_t*>(p.out) + ((long long)b * p.N + n0 + n) * p.ldo + key0;
-                    const float* sp = wst + l * LDT;
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        f32x4 v0 = *reinterpret_cast<const f32x4*>(sp + 8 * c), v1 = *reinterpret_cast<const f32x4*>(sp + 8 * c + 4);
-                        f16x8 o = {(half_t)(v0[0] * p.alpha), (half_t)(v0[1] * p.alpha), (half_t)(v0[2] * p.alpha), (half_t)(v0[3] * p.alpha),
-                                   (half_t)(v1[0] * p.alpha), (half_t)(v1[1] * p.alpha), (half_t)(v1[2] * p.alpha), (half_t)(v1[3] * p.alpha)};
-                        *reinterpret_cast<f16x8*>(dst + 8 * c) = o;
-                    }
-                }
-                continue;
-            }
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj) {
-                if (jj >= jn) break;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const f32x16& a = acc[i][j0 + jj];
-                    f32x4 v = {a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]};
-                    *reinterpret_cast<f32x4*>(wst + lr * LDW + jj * 32 + 8 * g + 4 * lh) = v;
-                }
-            }
-            const int ncol0 = n0 + (wn * TN + j0) * 32;
-            if (geglu) {                                         // 64 staged columns = [32 h | 32 gate] -> 32 outputs
-                half_t* out = reinterpret_cast<half_t*>(p.out);
-#pragma unroll
-                for (int pass = 0; pass < 2; ++pass) {           // 32 rows x 4 chunks of 8 outputs
-                    const int item = pass * 64 + l;
-                    const int r = item >> 2, oc = (item & 3) * 8;
-                    const int m = mrow0 + r;
-                    if (m >= p.M || ncol0 + oc >= p.N) continue;
-                    const float* sp = wst + r * LDW + oc;
-                    f32x4 h0 = *reinterpret_cast<const f32x4*>(sp), h1 = *reinterpret_cast<const f32x4*>(sp + 4);
-                    f32x4 g0 = *reinterpret_cast<const f32x4*>(sp + 32), g1 = *reinterpret_cast<const f32x4*>(sp + 36);
-                    float hv[8] = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
-                    float gv[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
-                    if (p.bias) {
-                        const float* bp = p.bias + ncol0 + oc;
-                        f32x4 b0 = *reinterpret_cast<const f32x4*>(bp), b1 = *reinterpret_cast<const f32x4*>(bp + 4);
-                        f32x4 c0 = *reinterpret_cast<const f32x4*>(bp + 32), c1 = *reinterpret_cast<const f32x4*>(bp + 36);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            hv[e] = hv[e] * p.alpha + b0[e]; hv[4 + e] = hv[4 + e] * p.alpha + b1[e];
-                            gv[e] = gv[e] * p.alpha + c0[e]; gv[4 + e] = gv[4 + e] * p.alpha + c1[e];
-                        }
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) { hv[e] *= p.alpha; gv[e] *= p.alpha; }
-                    }
-                    f16x8 o;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] = (half_t)(hv[e] * gelu_fast(gv[e]));
-                    *reinterpret_cast<f16x8*>(out + (long long)m * p.ldo + (ncol0 >> 1) + oc) = o;
-                }
-            } else {
-                const int chs = jn == 2 ? 3 : 2;                 // log2(8-wide chunks per staged row)
-                const int npass = jn == 2 ? 4 : 2;
-#pragma unroll
-                for (int pass = 0; pass < 4; ++pass) {
-                    if (pass >= npass) break;
-                    const int item = pass * 64 + l;
-                    const int r = item >> chs, c8 = (item & ((1 << chs) - 1)) * 8;
-                    const int m = mrow0 + r, n = ncol0 + c8;
-                    if (m >= p.M || n >= p.N) continue;
-                    const float* sp = wst + r * LDW + c8;
-                    f32x4 v0 = *reinterpret_cast<const f32x4*>(sp), v1 = *reinterpret_cast<const f32x4*>(sp + 4);
-                    if (part) {
-                        float* dst = part + (long long)m * p.N + n;
-                        *reinterpret_cast<f32x4*>(dst) = v0;
-                        *reinterpret_cast<f32x4*>(dst + 4) = v1;
-                        continue;
-                    }
-                    float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] *= p.alpha;
-                    if (p.bias) {
-                        f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n), b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
-                    }
-                    if (p.rowbias) {
-                        f16x8 rb = *reinterpret_cast<const f16x8*>(p.rowbias + (long long)(m / p.rps) * p.ld_rowbias + n);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] += (float)rb[e];
-                    }
-                    if (p.resid) {
-                        f16x8 rs = *reinterpret_cast<const f16x8*>(p.resid + (long long)m * p.ldr + n);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] += (float)rs[e];
-                    }
-                    if (out_f32) {
-                        float* out = reinterpret_cast<float*>(p.out) + (long long)m * p.ldo + n;
-                        *reinterpret_cast<f32x4*>(out) = (f32x4){v[0], v[1], v[2], v[3]};
-                        *reinterpret_cast<f32x4*>(out + 4) = (f32x4){v[4], v[5], v[6], v[7]};
-                    } else {
-                        f16x8 o;
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) o[e] = (half_t)v[e];
-                        *reinterpret_cast<f16x8*>(reinterpret_cast<half_t*>(p.out) + (long long)m * p.ldo + n) = o;
-                    }
-                }
-            }
-        }
-    }
+    // ---- epilogue (gemm_epilogue.h): per-wave LDS patches, no block-wide slabs -----------------------------------------
+    wave_epilogue<TM, TN>(p, acc, smem, wv, wm, wn, l, m0, n0, split, tl);
     if (tl) {                                    // last wave out writes the end stamp (stores of this wave are issued, not drained)
         __syncthreads();
         if (tid == 0) tl[3] = __builtin_amdgcn_s_memrealtime();

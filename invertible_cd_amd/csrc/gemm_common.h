@@ -18,8 +18,26 @@ struct GemmK {
     int zdiv; long long a_bs0, a_bs1, w_bs0, w_bs1, o_bs0, o_bs1;
     float alpha; int flags;
     int nbm, nbn, ksplit, kt_per_split;
+    int gm;                                      // m-tiles per L2 group of the block -> tile map (tile_of_block)
+    const float* ln_stats;                       // fused LayerNorm: fp32 [M][2] = (mean, rstd) of the A rows, or null
+    const float* ln_s;                           //                  fp32 [N] = row sums of the gamma-scaled weights
     unsigned long long* timeline;                // diagnostics (icd_debug_gemm_timeline): 4 s_memrealtime stamps per block, or null
 };
+
+// block id -> (m-tile, n-tile).  Block b runs on XCD b % 8 (observed, speed only): every XCD gets a contiguous range of
+// the tile sequence, and inside it tiles are ordered in groups of `gm` m-tiles with the n-tile index outermost, so the
+// ~32 blocks an XCD runs concurrently cover gm x (32 / gm) tiles: they share gm activation tiles and 32 / gm weight tiles
+// through that XCD's L2 (12 operand tiles instead of 33 for gm = 8), and most global -> LDS loads become L2 hits.
+__device__ __forceinline__ void tile_of_block(int bid, int nbm, int nbn, int gm, int& mt, int& nt) {
+    const int nblk = nbm * nbn;
+    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int per_group = gm * nbn;
+    const int g = bid / per_group, rem = bid - g * per_group;
+    const int rows = min(gm, nbm - g * gm);
+    nt = rem / rows;
+    mt = g * gm + (rem - nt * rows);
+}
 
 __device__ __forceinline__ int swz_off(int row, int chunk) {        // byte offset inside a [rows][64] half tile
     return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
@@ -38,6 +56,19 @@ __device__ __forceinline__ float erf_fast(float x) {
 }
 __device__ __forceinline__ float gelu_fast(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752f)); }
 
+// LayerNorm folded into the GEMM that consumes it (icd_gemm_desc.ln_stats): with W' = W * gamma (folded at load time),
+// LN(x) @ W^T = rstd_m * (x @ W'^T - mean_m * rowsum(W')_n) + (W @ beta)_n - the last term travels in `bias`.
+// v[0..8) are 8 consecutive output columns n.. of row m (already scaled by alpha).
+__device__ __forceinline__ void ln_correct8(float (&v)[8], const float* ln_stats, const float* ln_s, int m, int n) {
+    const f32x2 st = *reinterpret_cast<const f32x2*>(ln_stats + 2 * (long long)m);
+    const f32x4 s0 = *reinterpret_cast<const f32x4*>(ln_s + n), s1 = *reinterpret_cast<const f32x4*>(ln_s + n + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        v[e] = st[1] * (v[e] - st[0] * s0[e]);
+        v[4 + e] = st[1] * (v[4 + e] - st[0] * s1[e]);
+    }
+}
+
 
 // gemm_big.hip tile configurations and their measured cost (tools/gemm_bench.py with forced configurations, one box):
 // one launch costs rounds x (k-tiles x tk + fixed) where a block owns its CU (1 block / CU), tk = one k-tile of one
@@ -45,7 +76,7 @@ __device__ __forceinline__ float gelu_fast(float x) { return 0.5f * x * (1.0f + 
 // chip (about 1.3 - 1.7 us depending on the box's clocks).  tk_full applies when >= 200 CUs are busy (chip-level
 // ceiling: the same block runs about 10 - 20 % slower), tk_part when <= 160.
 struct BigTile { int bm, bn; bool geglu_ok; double tk_part, tk_full, fixed; };
-constexpr int NUM_BIG_TILES = 5;
+constexpr int NUM_BIG_TILES = 6;
 constexpr BigTile BIG_TILES[NUM_BIG_TILES] = {
     {256, 256, true, 1.00, 1.08, 9.5},
     {256, 320, false, 1.07, 1.30, 15.3},
@@ -53,7 +84,11 @@ constexpr BigTile BIG_TILES[NUM_BIG_TILES] = {
     {128, 320, false, 0.72, 0.80, 7.2},
     {256, 256, true, 99.0, 99.0, 9.5},      // [4] generated asm main loop, 4 waves of 128 x 128 (dense, even k-tile count, no split-K):
                                             //     forced only - measured equal per k-tile, slower per launch
+    {256, 128, true, 99.0, 99.0, 0.0},      // [5] gemm_pp.hip: 4 waves of 128 x 64, BK = 32, three stages, TWO blocks per CU; k-tiles are
+                                            //     32 deep; cost handled separately in the planner (PP_* below)
 };
+constexpr int PP_CFG = 5;
 int launch_big(const GemmK& k, int cfg, hipStream_t st);     // cfg = index into BIG_TILES
+int launch_pp(const GemmK& k, hipStream_t st);               // gemm_pp.hip
 
 }  // namespace icd_gemm_detail

@@ -315,21 +315,26 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const half_t* __restrict
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int LN_ITERS = 4;
 
-template <int LPR, int CPL>
+// STATS: write (mean, rstd) per row to `stats` instead of the normalised rows - the LayerNorm itself is then applied
+// inside the consuming GEMM (gamma folded into its weights, mean / rstd as a rank-1 epilogue correction; icd_gemm_desc
+// ln_stats / ln_colsum): the normalised tensor is never written or re-read.
+template <int LPR, int CPL, bool STATS = false>
 __global__ __launch_bounds__(256) void layernorm_multi_kernel(const half_t* __restrict__ x, long long rows, int C,
                                                                const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, float eps,
-                                                               half_t* __restrict__ out) {
+                                                               half_t* __restrict__ out, float* __restrict__ stats) {
     constexpr int RPW = 64 / LPR;
     const int l = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int sub = l % LPR, rw = l / LPR;
     const long long row0 = ((long long)blockIdx.x * 4 + wv) * (RPW * LN_ITERS) + rw;
     f32x4 g[CPL][2], bt[CPL][2];
+    if (!STATS) {
 #pragma unroll
     for (int i = 0; i < CPL; ++i) {
         const int c = (sub + i * LPR) * 8;
         g[i][0] = *reinterpret_cast<const f32x4*>(gamma + c); g[i][1] = *reinterpret_cast<const f32x4*>(gamma + c + 4);
         bt[i][0] = *reinterpret_cast<const f32x4*>(beta + c); bt[i][1] = *reinterpret_cast<const f32x4*>(beta + c + 4);
+    }
     }
     const float invC = 1.0f / (float)C;
     f16x8 v[2][CPL];
@@ -360,6 +365,10 @@ __global__ __launch_bounds__(256) void layernorm_multi_kernel(const half_t* __re
 #pragma unroll
             for (int e = 0; e < 8; ++e) { const float d = (float)v[cur][i][e] - mean; sq += d * d; }
         const float rstd = rsqrtf(group_sum<LPR>(sq) * invC + eps);
+        if (STATS) {
+            if (row < rows && sub == 0) *reinterpret_cast<f32x2*>(stats + row * 2) = (f32x2){mean, rstd};
+            continue;
+        }
         if (row < rows) {
             half_t* orow = out + row * C;
 #pragma unroll
@@ -378,10 +387,44 @@ __global__ __launch_bounds__(256) void layernorm_multi_kernel(const half_t* __re
 
 template <int LPR, int CPL>
 void launch_ln_multi(const half_t* x, long long rows, int C, const float* gamma, const float* beta, float eps, half_t* out,
-                     hipStream_t st) {
+                     float* stats, hipStream_t st) {
     const long long rows_per_block = 4LL * (64 / LPR) * LN_ITERS;
-    hipLaunchKernelGGL((layernorm_multi_kernel<LPR, CPL>), dim3((unsigned)((rows + rows_per_block - 1) / rows_per_block)), dim3(256),
-                       0, st, x, rows, C, gamma, beta, eps, out);
+    const dim3 grid((unsigned)((rows + rows_per_block - 1) / rows_per_block));
+    if (stats) hipLaunchKernelGGL((layernorm_multi_kernel<LPR, CPL, true>), grid, dim3(256), 0, st, x, rows, C, gamma, beta, eps, out, stats);
+    else hipLaunchKernelGGL((layernorm_multi_kernel<LPR, CPL, false>), grid, dim3(256), 0, st, x, rows, C, gamma, beta, eps, out, stats);
+}
+
+// generic width: one wave per row, stats only
+__global__ __launch_bounds__(256) void layernorm_stats_kernel(const half_t* __restrict__ x, long long rows, int C, float eps,
+                                                               float* __restrict__ stats) {
+    const int l = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nchunk = C >> 3;
+    const half_t* xr = x + row * C;
+    f16x8 v[4];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = l + i * 64;
+        if (c < nchunk) {
+            v[i] = *reinterpret_cast<const f16x8*>(xr + c * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sum += (float)v[i][e];
+        }
+    }
+    const float mean = wave_sum(sum) / (float)C;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = l + i * 64;
+        if (c < nchunk) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = (float)v[i][e] - mean; sq += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(sq) / (float)C + eps);
+    if (l == 0) *reinterpret_cast<f32x2*>(stats + row * 2) = (f32x2){mean, rstd};
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -506,13 +549,28 @@ extern "C" int icd_layernorm(const void* x, int64_t rows, int32_t C, const float
     half_t* oh = (half_t*)out;
     const int nchunk = C / 8;
     // widths with 5 chunks per lane group (C = 320 * 2^k) take the multi-row kernel; anything else the generic one
-    if (nchunk == 40) launch_ln_multi<8, 5>(xh, rows, C, gamma, beta, eps, oh, st);
-    else if (nchunk == 80) launch_ln_multi<16, 5>(xh, rows, C, gamma, beta, eps, oh, st);
-    else if (nchunk == 160) launch_ln_multi<32, 5>(xh, rows, C, gamma, beta, eps, oh, st);
+    if (nchunk == 40) launch_ln_multi<8, 5>(xh, rows, C, gamma, beta, eps, oh, nullptr, st);
+    else if (nchunk == 80) launch_ln_multi<16, 5>(xh, rows, C, gamma, beta, eps, oh, nullptr, st);
+    else if (nchunk == 160) launch_ln_multi<32, 5>(xh, rows, C, gamma, beta, eps, oh, nullptr, st);
     else
         hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, xh, (long long)rows, C, gamma,
                            beta, eps, oh);
     ICD_CHECK_LAUNCH("icd_layernorm");
+    return ICD_OK;
+}
+
+extern "C" int icd_layernorm_stats(const void* x, int64_t rows, int32_t C, float eps, float* stats, void* stream) {
+    ICD_CHECK_ARG(x && stats, "icd_layernorm_stats: null pointer");
+    ICD_CHECK_ARG(C > 0 && C % 8 == 0 && C <= 2048, "icd_layernorm_stats: C must be a multiple of 8 and <= 2048 (got %d)", C);
+    ICD_CHECK_ARG(rows > 0, "icd_layernorm_stats: empty input");
+    hipStream_t st = (hipStream_t)stream;
+    const half_t* xh = (const half_t*)x;
+    const int nchunk = C / 8;
+    if (nchunk == 40) launch_ln_multi<8, 5>(xh, rows, C, nullptr, nullptr, eps, nullptr, stats, st);
+    else if (nchunk == 80) launch_ln_multi<16, 5>(xh, rows, C, nullptr, nullptr, eps, nullptr, stats, st);
+    else if (nchunk == 160) launch_ln_multi<32, 5>(xh, rows, C, nullptr, nullptr, eps, nullptr, stats, st);
+    else hipLaunchKernelGGL(layernorm_stats_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, xh, (long long)rows, C, eps, stats);
+    ICD_CHECK_LAUNCH("icd_layernorm_stats");
     return ICD_OK;
 }
 

@@ -173,9 +173,11 @@ struct Exec {
     }
     // dense: out[M,N] (ldo) = a[M,K](lda) @ w[N,K]^T + bias + resid
     void linear(const half_t* a, int lda, int M, int K, const half_t* w, int N, const float* bias, const half_t* resid,
-                int ldr, half_t* out, int ldo, int flags = 0, int rps = 0) {
+                int ldr, half_t* out, int ldo, int flags = 0, int rps = 0, const float* ln_stats = nullptr,
+                const float* ln_colsum = nullptr) {
         icd_gemm_desc d; memset(&d, 0, sizeof(d));
         d.a0 = a; d.w = w; d.bias = bias; d.resid = resid; d.out = out;
+        d.ln_stats = ln_stats; d.ln_colsum = ln_colsum;
         d.M = M; d.N = N; d.K = K; d.Nw = N; d.lda = lda; d.ldw = K; d.ldo = ldo; d.ldr = ldr;
         d.rows_per_sample = rps; d.mode = 0; d.batch = 1; d.zdiv = 1; d.alpha = 1.f; d.flags = flags;
         gemm_desc(d);
@@ -198,10 +200,11 @@ struct Exec {
         ProfScope ps(true, st, ICD_PROF_GROUPNORM, 0.0, 6.0 * B * (double)HW * (x0.C + (x1 ? x1->C : 0)));
         run(icd_groupnorm(x0.p, x0.C, x1 ? x1->p : nullptr, x1 ? x1->C : 0, B, HW, u->cfg.norm_groups, g, b, eps, silu, out, gn_ws, st));
     }
-    void layernorm(const half_t* x, long long rows, int C, const float* g, const float* b, half_t* out) {
+    // LayerNorm statistics only (2 B / element read): the normalisation is applied by the consuming GEMMs' epilogues
+    void ln_stats(const half_t* x, long long rows, int C, float* stats) {
         if (!ok() || dry) return;
-        ProfScope ps(true, st, ICD_PROF_LAYERNORM, 0.0, 4.0 * (double)rows * C);
-        run(icd_layernorm(x, rows, C, g, b, 1e-5f, out, st));
+        ProfScope ps(true, st, ICD_PROF_LAYERNORM, 0.0, 2.0 * (double)rows * C);
+        run(icd_layernorm_stats(x, rows, C, 1e-5f, stats, st));
     }
 
     // ---------------------------------------------------------------------------------------------- blocks
@@ -303,39 +306,44 @@ struct Exec {
         half_t* h = alloc<half_t>(M * C);
         linear(n, C, (int)M, C, Wh(p + ".proj_in.weight", (long long)C * C), C, Wf(p + ".proj_in.bias", C), nullptr, 0, h, C);
         release(n);
+        // LayerNorm is never materialised: per-row (mean, rstd) from a statistics pass over the residual stream, gamma
+        // folded into the consuming projection's weights at load time (unet.py), the rank-1 correction in its epilogue.
+        float* lnst = alloc<float>(M * 2);
         for (int kb = 0; kb < depth && ok(); ++kb) {
             const std::string b = p + ".transformer_blocks." + std::to_string(kb);
             // ---- self attention ----
-            half_t* ln = alloc<half_t>(M * C);
-            layernorm(h, M, C, Wf(b + ".norm1.weight", C), Wf(b + ".norm1.bias", C), ln);
+            ln_stats(h, M, C, lnst);
             half_t* qk = alloc<half_t>(M * 2 * C);
-            linear(ln, C, (int)M, C, Wh(b + ".attn1.to_qk.weight", 2LL * C * C), 2 * C, nullptr, nullptr, 0, qk, 2 * C);
+            linear(h, C, (int)M, C, Wh(b + ".attn1.to_qk.weight", 2LL * C * C), 2 * C, Wf(b + ".attn1.to_qk.lnbias", 2 * C), nullptr, 0, qk,
+                   2 * C, 0, 0, lnst, Wf(b + ".attn1.to_qk.lnsum", 2 * C));
             half_t* vt = alloc<half_t>((long long)B * C * ldv_self);
-            linear(ln, C, (int)M, C, Wh(b + ".attn1.to_v.weight", (long long)C * C), C, nullptr, nullptr, 0, vt, ldv_self,
-                   ICD_GEMM_OUT_TRANS, HW);
-            half_t* ao = ln;     // ln is dead once q/k/v^T are enqueued: reuse it for the attention output
+            linear(h, C, (int)M, C, Wh(b + ".attn1.to_v.weight", (long long)C * C), C, nullptr, nullptr, 0, vt, ldv_self,
+                   ICD_GEMM_OUT_TRANS, HW, lnst, Wf(b + ".attn1.to_v.lnsum", C));      // (W_v beta) rides in to_out's bias
+            half_t* ao = alloc<half_t>(M * C);
             attention(false, place, qk, 2 * C, qk + C, 2 * C, vt, ldv_self, (long long)C * ldv_self, heads, HW, HW, d, ao, C);
             release(qk); release(vt);
             linear(ao, C, (int)M, C, Wh(b + ".attn1.to_out.0.weight", (long long)C * C), C, Wf(b + ".attn1.to_out.0.bias", C), h, C, h, C);
             // ---- cross attention ----
-            layernorm(h, M, C, Wf(b + ".norm2.weight", C), Wf(b + ".norm2.bias", C), ln);
+            ln_stats(h, M, C, lnst);
             half_t* q2 = alloc<half_t>(M * C);
-            linear(ln, C, (int)M, C, Wh(b + ".attn2.to_q.weight", (long long)C * C), C, nullptr, nullptr, 0, q2, C);
+            linear(h, C, (int)M, C, Wh(b + ".attn2.to_q.weight", (long long)C * C), C, Wf(b + ".attn2.to_q.lnbias", C), nullptr, 0, q2, C,
+                   0, 0, lnst, Wf(b + ".attn2.to_q.lnsum", C));
             // K and V^T of this layer are column / row slices of the per-forward batched projections
             attention(true, place, q2, C, k_all + kv_off, u->kv_total, vt_all + (long long)kv_off * ldv_cross, ldv_cross,
-                      (long long)u->kv_total * ldv_cross, heads, HW, nctx, d, ln, C);
+                      (long long)u->kv_total * ldv_cross, heads, HW, nctx, d, ao, C);
             kv_off += C;
             release(q2);
-            linear(ln, C, (int)M, C, Wh(b + ".attn2.to_out.0.weight", (long long)C * C), C, Wf(b + ".attn2.to_out.0.bias", C), h, C, h, C);
+            linear(ao, C, (int)M, C, Wh(b + ".attn2.to_out.0.weight", (long long)C * C), C, Wf(b + ".attn2.to_out.0.bias", C), h, C, h, C);
+            release(ao);
             // ---- GEGLU feed-forward ----
-            layernorm(h, M, C, Wf(b + ".norm3.weight", C), Wf(b + ".norm3.bias", C), ln);
+            ln_stats(h, M, C, lnst);
             half_t* ff = alloc<half_t>(M * 4 * C);
-            linear(ln, C, (int)M, C, Wh(b + ".ff.net.0.proj.weight", 8LL * C * C), 8 * C, Wf(b + ".ff.net.0.proj.bias", 8 * C), nullptr, 0,
-                   ff, 4 * C, ICD_GEMM_GEGLU);
-            release(ln);
+            linear(h, C, (int)M, C, Wh(b + ".ff.net.0.proj.weight", 8LL * C * C), 8 * C, Wf(b + ".ff.net.0.proj.bias", 8 * C), nullptr, 0,
+                   ff, 4 * C, ICD_GEMM_GEGLU, 0, lnst, Wf(b + ".ff.net.0.proj.lnsum", 8 * C));
             linear(ff, 4 * C, (int)M, 4 * C, Wh(b + ".ff.net.2.weight", 4LL * C * C), C, Wf(b + ".ff.net.2.bias", C), h, C, h, C);
             release(ff);
         }
+        release(lnst);
         half_t* out = alloc<half_t>(M * C);
         linear(h, C, (int)M, C, Wh(p + ".proj_out.weight", (long long)C * C), C, Wf(p + ".proj_out.bias", C), x.p, C, out, C);
         release(h);

@@ -60,8 +60,9 @@ FORBID_BIG_TILE = 0x200000
 
 
 def gemm(a, w, bias=None, resid=None, rowbias=None, rows_per_sample=0, geglu=False, out=None, alpha=1.0,
-         out_f32=False, debug_flags=0):
-    """out[M, N] = alpha * a[M, K] @ w[N, K]^T (+bias[N] fp32) (+rowbias[m // rps]) (+resid) ; GEGLU halves N."""
+         out_f32=False, debug_flags=0, ln_stats=None, ln_colsum=None):
+    """out[M, N] = alpha * a[M, K] @ w[N, K]^T (+bias[N] fp32) (+rowbias[m // rps]) (+resid) ; GEGLU halves N.
+    ln_stats [M, 2] fp32 + ln_colsum [N] fp32: LayerNorm of `a` fused into the epilogue (w carries gamma, bias carries W beta)."""
     _chk16(a, "a"); _chk16(w, "w")
     M, K = a.shape
     N = w.shape[0]
@@ -80,6 +81,10 @@ def gemm(a, w, bias=None, resid=None, rowbias=None, rows_per_sample=0, geglu=Fal
     d.rows_per_sample = rows_per_sample
     d.mode, d.batch, d.zdiv, d.alpha = 0, 1, 1, alpha
     d.flags = (ICD_GEMM_GEGLU if geglu else 0) | (ICD_GEMM_OUT_F32 if out_f32 else 0) | debug_flags
+    if ln_stats is not None:
+        assert ln_stats.dtype == torch.float32 and ln_stats.is_contiguous() and tuple(ln_stats.shape) == (M, 2)
+        assert ln_colsum.dtype == torch.float32 and ln_colsum.is_contiguous() and ln_colsum.numel() == N
+        d.ln_stats, d.ln_colsum = ln_stats.data_ptr(), ln_colsum.data_ptr()
     ws = _splitk_ws(d, a.device)
     _lib.check(_lib.load().icd_gemm(C.byref(d), _stream()), "icd_gemm")
     return out
@@ -134,6 +139,23 @@ def layernorm(x, gamma, beta, eps=1e-5):
     return out
 
 
+def layernorm_stats(x, eps=1e-5):
+    """(mean, rstd) per row of x [rows, C] -> fp32 [rows, 2]; the normalisation is applied by gemm(..., ln_stats=)."""
+    _chk16(x, "x")
+    rows, Cc = x.shape
+    out = torch.empty((rows, 2), device=x.device, dtype=torch.float32)
+    _lib.check(_lib.load().icd_layernorm_stats(_p(x), rows, Cc, eps, _p(out), _stream()), "icd_layernorm_stats")
+    return out
+
+
+def fold_layernorm(w, gamma, beta, bias=None):
+    """Weights of a Linear that consumes LayerNorm(x; gamma, beta): (fp16 W * gamma, fp32 row sums of it, fp32 W beta + bias)."""
+    w32 = w.float()
+    w16 = (w32 * gamma.float()[None, :]).to(torch.float16).contiguous()
+    t = w32 @ beta.float() + (0 if bias is None else bias.float())
+    return w16, w16.float().sum(1).contiguous(), t.contiguous()
+
+
 def softmax_rows(s, cols, ld_p, scale=1.0):
     assert s.dtype == torch.float32 and s.is_contiguous()
     rows, ld_s = s.shape
@@ -142,7 +164,7 @@ def softmax_rows(s, cols, ld_p, scale=1.0):
     return p
 
 
-def project_vt(x, w, B, n_tokens, ld_keys):
+def project_vt(x, w, B, n_tokens, ld_keys, ln_stats=None, ln_colsum=None):
     """V^T[b, c, key] = (x[b*n_tokens + key] @ w^T)[c]  -> [B, N, ld_keys] (pad columns zero)."""
     _chk16(x, "x"); _chk16(w, "w")
     M, K = x.shape
@@ -154,6 +176,8 @@ def project_vt(x, w, B, n_tokens, ld_keys):
     d.lda, d.ldw, d.ldo = x.stride(0), w.stride(0), ld_keys
     d.rows_per_sample = n_tokens
     d.mode, d.batch, d.zdiv, d.alpha, d.flags = 0, 1, 1, 1.0, ICD_GEMM_OUT_TRANS
+    if ln_stats is not None:
+        d.ln_stats, d.ln_colsum = ln_stats.data_ptr(), ln_colsum.data_ptr()
     _lib.check(_lib.load().icd_gemm(C.byref(d), _stream()), "icd_gemm(V^T)")
     return out
 

@@ -41,6 +41,8 @@ def pack_state_dict(cfg: UNetConfig, sd, device):
 
       conv [O,I,k,k]      -> [O, k*k*I]  (tap-major K of the implicit GEMM; 1x1 convs become plain [O,I])
       attn1.to_q/to_k     -> attn1.to_qk [2C, C]   (one GEMM, q|k column blocks)
+      norm1/2/3 (LayerNorm) -> folded into to_qk / to_v / attn2.to_q / ff.net.0.proj: gamma into the weight columns,
+                             W beta into the bias, plus the row sums the epilogue's mean correction needs
       ff.net.0.proj       -> rows interleaved 32 value / 32 gate so GEGLU is applied in the GEMM epilogue
       *.time_emb_proj     -> ONE [sum(Cout), 4*ch0] matrix in execution order (all resnets' time biases in one GEMM)
       attn2.to_k / to_v   -> attn2_k_cat / attn2_v_cat [sum(C), cross_dim] in execution order (two GEMMs per forward)
@@ -49,6 +51,8 @@ def pack_state_dict(cfg: UNetConfig, sd, device):
 
     def w16(t):
         return t.to(device=device, dtype=torch.float16).contiguous()
+
+    w16_ = w16
 
     def f32(t):
         return t.to(device=device, dtype=torch.float32).contiguous()
@@ -106,18 +110,32 @@ def pack_state_dict(cfg: UNetConfig, sd, device):
         perm = geglu_perm(4 * c).to(device)
         for k in range(depth):
             b = f"{p}.transformer_blocks.{k}"
-            for n in ("norm1", "norm2", "norm3"):
-                affine(f"{b}.{n}")
-            packed[f"{b}.attn1.to_qk.weight"] = w16(torch.cat([take(f"{b}.attn1.to_q.weight").to(device),
-                                                               take(f"{b}.attn1.to_k.weight").to(device)], 0))
-            dense(f"{b}.attn1.to_v", bias=False)
-            dense(f"{b}.attn1.to_out.0")
-            dense(f"{b}.attn2.to_q", bias=False)
+            # LayerNorm folded into the projections that consume it (executor: icd_layernorm_stats + icd_gemm ln_stats):
+            #   LN(x) W^T + bias = rstd * (x (W*gamma)^T - mean * rowsum(W*gamma)) + (W beta + bias)
+            # `.weight` = fp16(W * gamma), `.lnsum` = row sums of exactly those fp16 values, `.lnbias` / `.bias` = W beta (+ bias)
+            ln = {n: (take(f"{b}.{n}.weight").to(device).float(), take(f"{b}.{n}.bias").to(device).float())
+                  for n in ("norm1", "norm2", "norm3")}
+
+            def fold(name, w, norm, bias=None, bias_key="lnbias"):
+                g, be = ln[norm]
+                w = w.to(device).float()
+                w16 = w16_(w * g[None, :])
+                packed[name + ".weight"] = w16
+                packed[name + ".lnsum"] = f32(w16.float().sum(1))
+                packed[name + "." + bias_key] = f32(w @ be + (0 if bias is None else bias.to(device).float()))
+                return w @ be
+
+            fold(f"{b}.attn1.to_qk", torch.cat([take(f"{b}.attn1.to_q.weight").to(device), take(f"{b}.attn1.to_k.weight").to(device)], 0), "norm1")
+            tv = fold(f"{b}.attn1.to_v", take(f"{b}.attn1.to_v.weight"), "norm1")           # W_v beta: a constant over the keys,
+            wo = take(f"{b}.attn1.to_out.0.weight").to(device).float()                          # softmax rows sum to one ->
+            packed[f"{b}.attn1.to_out.0.weight"] = w16(wo)                                      # it moves into to_out's bias
+            packed[f"{b}.attn1.to_out.0.bias"] = f32(take(f"{b}.attn1.to_out.0.bias").to(device).float() + wo @ tv)
+            fold(f"{b}.attn2.to_q", take(f"{b}.attn2.to_q.weight"), "norm2")
             kcat.append(take(f"{b}.attn2.to_k.weight"))        # every cross-attention K / V projection of the UNet
             vcat.append(take(f"{b}.attn2.to_v.weight"))        # is batched into one GEMM per forward (context-only)
             dense(f"{b}.attn2.to_out.0")
-            packed[f"{b}.ff.net.0.proj.weight"] = w16(take(f"{b}.ff.net.0.proj.weight").to(device)[perm])
-            packed[f"{b}.ff.net.0.proj.bias"] = f32(take(f"{b}.ff.net.0.proj.bias").to(device)[perm])
+            fold(f"{b}.ff.net.0.proj", take(f"{b}.ff.net.0.proj.weight").to(device)[perm], "norm3",
+                 bias=take(f"{b}.ff.net.0.proj.bias").to(device)[perm], bias_key="bias")
             dense(f"{b}.ff.net.2")
     packed["attn2_k_cat.weight"] = w16(torch.cat([t.to(device) for t in kcat], 0))
     packed["attn2_v_cat.weight"] = w16(torch.cat([t.to(device) for t in vcat], 0))

@@ -60,8 +60,7 @@ int icd_version(void);
 #define ICD_GEMM_TUNE_FORCE_BIG  0x00100000   /* take a 256-wide tile (gemm_big.hip) whatever the chip fill           */
 #define ICD_GEMM_TUNE_NO_BIG     0x00200000   /* never take one                                                      */
 #define ICD_GEMM_TUNE_BN256      0x00400000   /* big tiles: only the BN = 256 shapes                                 */
-#define ICD_GEMM_TUNE_BIG_CFG(i) (((i) + 1) << 24)   /* force big-tile configuration i (0..5, see gemm_common.h; 5 = the     */
-                                                     /* 256x128 two-blocks-per-CU tile of gemm_pp.hip)                      */
+#define ICD_GEMM_TUNE_BIG_CFG(i) (((i) + 1) << 24)   /* force big-tile configuration i (0..3, see gemm_common.h)      */
 
 /* out = alpha * (A (*) W^T) + bias[n] + rowbias[m / rows_per_sample][n] + resid[m][n]
  * A is either a dense row-major [M, K] matrix (mode 0; Linear, 1x1 conv, attention bmm) or the implicit im2col
@@ -300,15 +299,12 @@ typedef struct {
     double flops;
 } icd_profile_record;
 int icd_profile_dump(icd_profile_record* recs, int32_t max_recs);
-/* Diagnostics for kernel tuning (tools/gemm_timeline.py): while `buf` (device, 4 x uint64 per block of the next launches)
+/* Diagnostics for kernel tuning (tools/gemm_timeline.py): while `buf` (device, 8 x uint64 per block of the next launches)
  * is registered, every block of the 256-wide GEMM tiles stamps s_memrealtime (100 MHz) at: start, first k-tile landed,
  * main loop done, epilogue done.  NULL switches it off.  No reference counterpart. */
 int icd_debug_gemm_timeline(void* buf);
 /* m-tiles per L2 group of the GEMM block -> tile map (0: default).  A/B tuning only; results are unchanged. */
 int icd_debug_gemm_group_m(int32_t gm);
-/* Planner calibration of the two-blocks-per-CU tile (gemm_pp.hip): enable = may the planner pick it; tk / fixed_* > 0
- * replace the cost-model constants (units: one k-tile of a 256x256x64 block).  A/B tuning only. */
-int icd_debug_gemm_pp(int32_t enable, double tk, double fixed_alone, double fixed_pair);
 
 #ifdef __cplusplus
 }

@@ -114,7 +114,6 @@ SIGNATURES = {
                                  C.c_void_p, C.c_int32, C.c_void_p]),
     "icd_debug_gemm_timeline": (C.c_int, [C.c_void_p]),
     "icd_debug_gemm_group_m": (C.c_int, [C.c_int32]),
-    "icd_debug_gemm_pp": (C.c_int, [C.c_int32, C.c_double, C.c_double, C.c_double]),
     "icd_profile_enable": (C.c_int, [C.c_int32]),
     "icd_profile_read": (C.c_int, [C.POINTER(ProfileRow), C.c_int32]),
     "icd_profile_dump": (C.c_int, [C.POINTER(ProfileRecord), C.c_int32]),

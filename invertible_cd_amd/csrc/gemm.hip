@@ -45,7 +45,7 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_kernel(GemmK p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, wv = tid >> 6, l = tid & 63;
     const int wm = wv >> 1, wn = wv & 1;
-    unsigned long long* tl = p.timeline ? p.timeline + (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 : nullptr;
+    unsigned long long* tl = p.timeline ? p.timeline + (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 : nullptr;
     if (tl && tid == 0) { tl[0] = __builtin_amdgcn_s_memrealtime(); tl[1] = tl[0]; }
 
     // ---- XCD-aware tile id ------------------------------------------------------------------------------
@@ -539,16 +539,6 @@ extern "C" int64_t icd_gemm_workspace_bytes(int32_t M, int32_t N, int32_t K) {
     return need;
 }
 
-// Planner constants of the two-blocks-per-CU tile (gemm_pp.hip), in k-tiles of a 256 x 256 x 64 block like BIG_TILES:
-// PP_TK = one 32-deep k-tile of one 256 x 128 block with a co-resident partner; fixed = prologue + exposed epilogue.
-static double PP_TK = 0.30, PP_FIXED_ALONE = 8.0, PP_FIXED_PAIR = 4.0;
-static int g_pp_auto = 0;                        // 1: the planner may pick the tile on its own (set once it is calibrated)
-extern "C" int icd_debug_gemm_pp(int32_t enable, double tk, double fixed_alone, double fixed_pair) {
-    g_pp_auto = enable;
-    if (tk > 0) { PP_TK = tk; PP_FIXED_ALONE = fixed_alone; PP_FIXED_PAIR = fixed_pair; }
-    return ICD_OK;
-}
-
 static int g_group_m = 0;
 // Tuning override of the L2 grouping of the block -> tile map (0: the planner's default); results never change.
 extern "C" int icd_debug_gemm_group_m(int32_t gm) { g_group_m = gm; return ICD_OK; }
@@ -611,8 +601,6 @@ extern "C" int icd_gemm(const icd_gemm_desc* d, void* stream) {
         for (int ci = 0; ci < NUM_BIG_TILES && base_ok; ++ci) {
             const BigTile& c = BIG_TILES[ci];
             if (forced >= 0 && ci != forced) continue;
-            if (ci == PP_CFG) continue;                                                     // planned below
-            if (ci == 4 && (d->mode != 0 || (nk_total & 1) || nk_total < 2)) continue;     // asm tile: dense, even k-tile count
             if (d->N % c.bn != 0 || (geglu && !c.geglu_ok) || ((d->flags & ICD_GEMM_TUNE_BN256) && c.bn != 256)) continue;
             const long long b0 = (long long)((d->M + c.bm - 1) / c.bm) * (d->N / c.bn);
             int smax = 1;
@@ -621,7 +609,6 @@ extern "C" int icd_gemm(const icd_gemm_desc* d, void* stream) {
                 while (smax > 1 && nk_total / smax < 8) --smax;
                 while (smax > 1 && (long long)smax * d->M * d->N * 4 > d->splitk_ws_bytes) --smax;
             }
-            if (ci == 4) smax = 1;
             for (int sx = 1; sx <= smax; ++sx) {
                 const long long bt = b0 * sx;
                 const long long full = bt / 256, rem = bt % 256;
@@ -635,51 +622,6 @@ extern "C" int icd_gemm(const icd_gemm_desc* d, void* stream) {
                 if (sx > 1) cost += (double)(sx + 1) * d->M * d->N * 4.0 / 3.5e12 / 1.5e-6 + 4.0;   // fp32 partials + reduce launch
                 if (cost < best) { best = cost; cfg = ci; s = sx; best_fill = (double)bt / (double)(((bt + 255) / 256) * 256); }
             }
-        }
-        // ---- two-blocks-per-CU tile (gemm_pp.hip): 256 x 128 x 32 ------------------------------------------------------------
-        {
-            const bool conv32 = d->mode == 1 && ((d->C0 + d->C1) % 32 == 0) && (d->C0 % 32 == 0);
-            const bool pp_ok = batch == 1 && trans_ok && (d->mode == 0 || conv32) && d->M >= 256 && (d->Nw <= 0 || d->Nw >= d->N) &&
-                               (d->K % 32 == 0) && (!geglu || d->N % 128 == 0) && (!trans || d->N % 64 == 0);
-            const bool pp_forced = forced == PP_CFG;
-            const bool pp_auto = forced < 0 && g_pp_auto && !(d->flags & (ICD_GEMM_TUNE_NO_BIG | ICD_GEMM_TUNE_BN256));
-            if (pp_ok && (pp_forced || pp_auto)) {
-                const int nk32 = d->K / 32;
-                const long long b0 = (long long)((d->M + 255) / 256) * ((d->N + 127) / 128);
-                int sx = 1;
-                if (allow_split && b0 < 384 && nk32 >= 32) {                     // 512 slots on the chip
-                    sx = (int)((512 + b0 - 1) / b0);
-                    sx = sx > 8 ? 8 : sx;
-                    while (sx > 1 && nk32 / sx < 16) --sx;
-                    while (sx > 1 && (long long)sx * d->M * d->N * 4 > d->splitk_ws_bytes) --sx;
-                }
-                const long long bt = b0 * sx;
-                // cost in the same unit (k-tiles of a 256 x 256 x 64 block): two resident blocks share a CU's matrix pipe, a
-                // block's fixed costs overlap the other's MFMAs once more than one block per CU is queued
-                const double per_cu = (double)((bt + 255) / 256);                // blocks a CU processes (ceil)
-                const int kps = (nk32 + sx - 1) / sx;
-                double cost = per_cu * kps * PP_TK + (bt <= 256 ? PP_FIXED_ALONE : PP_FIXED_PAIR);
-                if (sx > 1) cost += (double)(sx + 1) * d->M * d->N * 4.0 / 3.5e12 / 1.5e-6 + 4.0;
-                if (pp_forced || cost < best) {
-                    k.nbm = (d->M + 255) / 256; k.nbn = (d->N + 127) / 128;
-                    if (g_group_m <= 0 && k.nbn >= 16) k.gm = 8;
-                    k.kt_per_split = (nk32 + sx - 1) / sx;
-                    k.ksplit = (nk32 + k.kt_per_split - 1) / k.kt_per_split;
-                    if (d->mode == 1) {
-                        ICD_CHECK_ARG(d->ksize == 1 || d->ksize == 3, "icd_gemm: conv ksize must be 1 or 3");
-                        ICD_CHECK_ARG(d->K == d->ksize * d->ksize * (d->C0 + d->C1), "icd_gemm: K != taps*Cin");
-                        ICD_CHECK_ARG((d->C1 == 0) == (d->a1 == nullptr), "icd_gemm: a1/C1 mismatch");
-                    } else {
-                        k.ksize = 0; k.Hout = 0;
-                        ICD_CHECK_ARG(d->lda % 8 == 0, "icd_gemm: lda must be a multiple of 8");
-                    }
-                    const int rc = launch_pp(k, st);
-                    if (rc != ICD_OK) return rc;
-                    if (k.ksplit > 1) return launch_reduce(k, st);
-                    return ICD_OK;
-                }
-            }
-            ICD_CHECK_ARG(!pp_forced, "icd_gemm: the forced 256x128 two-per-CU tile does not support this shape");
         }
         if (cfg >= 0 && (best_fill >= 0.45 || forced >= 0 || (d->flags & ICD_GEMM_TUNE_FORCE_BIG))) {
             const BigTile& c = BIG_TILES[cfg];

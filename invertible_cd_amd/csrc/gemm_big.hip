@@ -21,7 +21,7 @@ namespace {
 constexpr int enc_vmcnt(int n) { return ((n >> 4) << 14) | 0x0F70 | (n & 15); }
 
 template <int MODE, int WM, int WN, int TM, int TN>
-__global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 1 : 2) void gemm_big_kernel(GemmK p) {
+__global__ __launch_bounds__(WM * WN * 64, 2) void gemm_big_kernel(GemmK p) {
     constexpr int NT = WM * WN * 64;
     constexpr int BM = WM * TM * 32, BNt = WN * TN * 32;
     constexpr int A_BYTES = BM * 128, W_BYTES = BNt * 128, STAGE_BYTES = A_BYTES + W_BYTES;
@@ -30,7 +30,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 1 : 2) void gemm_big_k
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, wv = tid >> 6, l = tid & 63;
     const int wm = wv / WN, wn = wv - wm * WN;
-    unsigned long long* tl = p.timeline ? p.timeline + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 : nullptr;
+    unsigned long long* tl = p.timeline ? p.timeline + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 : nullptr;
     if (tl && tid == 0) tl[0] = __builtin_amdgcn_s_memrealtime();
 
     int mt, nt;
@@ -160,54 +160,6 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 1 : 2) void gemm_big_k
                 rd_w[st][s4] = st * STAGE_BYTES + A_BYTES + (wn * TN * 32 + lr) * 128 + off;
             }
     }
-    constexpr bool ASM = WM * WN == 4;       // 256 x 256, four waves of 128 x 128: hand-scheduled main loop (gen_gemm_asm.py)
-    if constexpr (ASM) {
-        static_assert(!ASM || (MODE == 0 && TM == 4 && TN == 4 && NAJ == 8 && NWJ == 8), "asm loop: dense 256x256 tile only");
-        // Loader state of the asm loop: 16 global pointers (8 A chunks, 8 W chunks), each biased by -(j&3)*1024 B for the
-        // instruction's immediate offset.  Rows past M are clamped to the last row (never stored), so every pointer
-        // advances by the same 128 B per k-tile and no zero page / per-pointer increment is needed.
-        const half_t* gp[16];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int r = (wv * 8 + j) * 8 + lrow;
-            const int lc = pchunk ^ ((r >> 1) & 7);
-            const int m = min(m0 + r, p.M - 1);
-            gp[j] = p.a0 + (long long)m * p.lda + k_begin + lc * 8 - (j & 3) * 512;
-            gp[8 + j] = p.w + (long long)(n0 + r) * p.ldw + k_begin + lc * 8 - (j & 3) * 512;
-        }
-        int m0b[2][4];
-#pragma unroll
-        for (int st = 0; st < 2; ++st)
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-                m0b[st][g] = __builtin_amdgcn_readfirstlane(st * STAGE_BYTES + (g < 2 ? 0 : A_BYTES) + wv * 8192 + (g & 1) * 4096);
-        // tiles 0 and 1 -> stages 0 and 1
-#pragma unroll
-        for (int st = 0; st < 2; ++st) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                unsigned char* base = smem + m0b[st][g];
-                const int j0 = (g < 2 ? 0 : 8) + (g & 1) * 4;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp[j0 + 0], (__attribute__((address_space(3))) void*)base, 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp[j0 + 1], (__attribute__((address_space(3))) void*)base, 16, 1024, 0);
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp[j0 + 2], (__attribute__((address_space(3))) void*)base, 16, 2048, 0);
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp[j0 + 3], (__attribute__((address_space(3))) void*)base, 16, 3072, 0);
-            }
-#pragma unroll
-            for (int j = 0; j < 16; ++j) gp[j] += BK;
-        }
-        __builtin_amdgcn_s_waitcnt(enc_vmcnt(16));        // tile 0 has landed (this wave's 16 loads of tile 1 may be in flight)
-        __builtin_amdgcn_s_barrier();
-        int ra[2][4], rw[2][4];
-#pragma unroll
-        for (int st = 0; st < 2; ++st)
-#pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) { ra[st][s4] = rd_a[st][s4]; rw[st][s4] = rd_w[st][s4]; }
-        int pairs = __builtin_amdgcn_readfirstlane(nk >> 1);
-        const unsigned long long inc128 = 128;
-        f16x8 fa[2][4], fw[2][4];
-#include "gemm_asm_loop.inc"
-    } else {
     f16x8 af[2][TM], wf[2][TN];               // set 1 is unused (and dead-code eliminated) without DBUF
     auto load_frags = [&](auto st_tag, auto s_tag, auto set_tag) {
         constexpr int ST = decltype(st_tag)::value, S4 = decltype(s_tag)::value, SET = decltype(set_tag)::value;
@@ -234,7 +186,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 1 : 2) void gemm_big_k
     if (nk > 1) { issue_stage(STAGE_BYTES); __builtin_amdgcn_s_waitcnt(enc_vmcnt(LOADS)); }
     else __builtin_amdgcn_s_waitcnt(enc_vmcnt(0));
     __builtin_amdgcn_s_barrier();
-    if (tl && tid == 0) tl[1] = __builtin_amdgcn_s_memrealtime();
+    if (tl && tid == 0) { tl[1] = __builtin_amdgcn_s_memrealtime(); tl[4] = __builtin_amdgcn_s_memtime(); }
     load_frags(I0{}, I0{}, I0{});
 
     // register double-buffering of the fragments only where the accumulators leave room (128 x 64 wave tile)
@@ -277,7 +229,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 1 : 2) void gemm_big_k
         if (t + 1 < nk) k_tile(I1{}, t + 1);
     }
 
-    }
+    if (tl && tid == 0) tl[5] = __builtin_amdgcn_s_memtime();        // shader-clock ticks of the main loop (clock = ticks / time)
     // ---- epilogue (gemm_epilogue.h): per-wave LDS patches, no block-wide slabs -----------------------------------------
     wave_epilogue<TM, TN>(p, acc, smem, wv, wm, wn, l, m0, n0, split, tl);
     if (tl) {                                    // last wave out writes the end stamp (stores of this wave are issued, not drained)
@@ -316,9 +268,6 @@ int launch_big(const GemmK& k, int cfg, hipStream_t st) {
         return conv ? launch_one<1, 2, 4, 3, 2>(k, st) : launch_one<0, 2, 4, 3, 2>(k, st);
     case 3:   // 128 x 320: 4 x 2 waves of 32 x 160
         return conv ? launch_one<1, 4, 2, 1, 5>(k, st) : launch_one<0, 4, 2, 1, 5>(k, st);
-    case 4:   // 256 x 256 dense: 2 x 2 waves of 128 x 128, one wave per SIMD, hand-scheduled loop (gen_gemm_asm.py)
-        if (!conv) return launch_one<0, 2, 2, 4, 4>(k, st);
-        break;
     }
     icd_set_error("icd_gemm: unknown big-tile configuration %d", cfg);
     return ICD_ERR_INVALID_ARG;

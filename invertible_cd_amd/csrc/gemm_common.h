@@ -76,19 +76,17 @@ __device__ __forceinline__ void ln_correct8(float (&v)[8], const float* ln_stats
 // chip (about 1.3 - 1.7 us depending on the box's clocks).  tk_full applies when >= 200 CUs are busy (chip-level
 // ceiling: the same block runs about 10 - 20 % slower), tk_part when <= 160.
 struct BigTile { int bm, bn; bool geglu_ok; double tk_part, tk_full, fixed; };
-constexpr int NUM_BIG_TILES = 6;
+constexpr int NUM_BIG_TILES = 4;
 constexpr BigTile BIG_TILES[NUM_BIG_TILES] = {
     {256, 256, true, 1.00, 1.08, 9.5},
     {256, 320, false, 1.07, 1.30, 15.3},
     {192, 256, true, 0.70, 0.76, 9.6},
     {128, 320, false, 0.72, 0.80, 7.2},
-    {256, 256, true, 99.0, 99.0, 9.5},      // [4] generated asm main loop, 4 waves of 128 x 128 (dense, even k-tile count, no split-K):
-                                            //     forced only - measured equal per k-tile, slower per launch
-    {256, 128, true, 99.0, 99.0, 0.0},      // [5] gemm_pp.hip: 4 waves of 128 x 64, BK = 32, three stages, TWO blocks per CU; k-tiles are
-                                            //     32 deep; cost handled separately in the planner (PP_* below)
 };
-constexpr int PP_CFG = 5;
+// Two further configurations were built, measured and removed in round 2 (tools/gemm_timeline.py): a
+// generated hand-scheduled 4-wave 128 x 128 main loop and a 256 x 128 x 32 tile with two co-resident blocks per CU.  Neither
+// is faster: under a full-chip launch every tile family delivers the same ~4 TFLOP/s per CU because the chip is at its
+// power limit (shader clock 1.3 - 1.7 GHz measured inside the main loop, 2.3 GHz when few CUs are busy).
 int launch_big(const GemmK& k, int cfg, hipStream_t st);     // cfg = index into BIG_TILES
-int launch_pp(const GemmK& k, hipStream_t st);               // gemm_pp.hip
 
 }  // namespace icd_gemm_detail

@@ -33,16 +33,16 @@ d.a0, d.w, d.out, d.bias = x.data_ptr(), w.data_ptr(), out.data_ptr(), b.data_pt
 d.resid = res.data_ptr() if res is not None else None
 d.M, d.N, d.K, d.Nw, d.lda, d.ldw, d.ldo, d.ldr = M, N, K, N, K, K, out.stride(0), N
 d.mode, d.batch, d.zdiv, d.alpha = 0, 1, 1, 1.0
-d.flags = (((a.cfg + 1) << 24) if a.cfg < 4 else {4: 0x80000, 5: 0x40000, 6: 6 << 24}[a.cfg]) | (1 if a.geglu else 0)
-# cfg 4: 256x128 three-stage tile, 5: 128x128 (two blocks per CU), 6: gemm_pp 256x128x32 (two blocks per CU)
+d.flags = (((a.cfg + 1) << 24) if a.cfg < 4 else {4: 0x80000, 5: 0x40000}[a.cfg]) | (1 if a.geglu else 0)
+# cfg 4: 256x128 three-stage tile, 5: 128x128 (two blocks per CU)
 lib.icd_debug_gemm_group_m(a.gm)
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 for _ in range(20):
     _lib.check(lib.icd_gemm(C.byref(d), st))
 torch.cuda.synchronize()
-tiles = {0: (256, 256), 1: (256, 320), 2: (192, 256), 3: (128, 320), 4: (256, 128), 5: (128, 128), 6: (256, 128)}[a.cfg]
+tiles = {0: (256, 256), 1: (256, 320), 2: (192, 256), 3: (128, 320), 4: (256, 128), 5: (128, 128)}[a.cfg]
 nblk = ((M + tiles[0] - 1) // tiles[0]) * ((N + tiles[1] - 1) // tiles[1])
-buf = torch.zeros((nblk, 4), dtype=torch.int64, device="cuda")
+buf = torch.zeros((nblk, 8), dtype=torch.int64, device="cuda")
 lib.icd_debug_gemm_timeline(C.c_void_p(buf.data_ptr()))
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
@@ -60,8 +60,13 @@ q = lambda v: f"min {v.min():7.2f}  p50 {np.median(v):7.2f}  p90 {np.percentile(
 print("  prologue  us: " + q(pro))
 print("  main loop us: " + q(main) + f"   ({np.median(main) / ((K + 63) // 64):.3f} us per k-tile)")
 print("  epilogue  us: " + q(epi))
+raw = buf.cpu().numpy()
+if raw[:, 5].max() > 0:
+    clk = (raw[:, 5] - raw[:, 4]).astype(np.float64) / np.maximum(main, 1e-3) / 1e3        # ticks per us -> GHz
+    print(f"  shader clock during the main loop (s_memtime ticks / s_memrealtime): p50 {np.median(clk):.3f} GHz  min {clk.min():.3f}  max {clk.max():.3f};"
+          f"  main loop = {np.median(raw[:, 5] - raw[:, 4]) / ((K + 63) // 64):.0f} shader cycles per k-tile")
 order = np.argsort(start)
-per_round = 512 if a.cfg in (5, 6) else 256
+per_round = 512 if a.cfg == 5 else 256
 rounds = (nblk + per_round - 1) // per_round
 for r in range(min(rounds, 6)):
     sel = order[r * per_round:(r + 1) * per_round]

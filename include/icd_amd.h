@@ -50,6 +50,7 @@ int icd_version(void);
 #define ICD_GEMM_GEGLU      1   /* out[m, j] = h * gelu_erf(g); weights/bias pre-interleaved in 32-column groups  */
 #define ICD_GEMM_OUT_F32    2   /* out is float (attention scores before softmax)                                   */
 #define ICD_GEMM_OUT_TRANS  4   /* out[(b*N + n)*ldo + (m % rows_per_sample)], b = m / rows_per_sample  (V^T)      */
+#define ICD_GEMM_RESID_F32 16   /* resid is float [M, ldr] (fp32 residual stream of the fp32-fidelity VAE path)             */
 #define ICD_GEMM_PAD_HI     8   /* conv: zero padding on the bottom / right edge only (AutoencoderKL Downsample2D:  */
                                 /* F.pad(x, (0,1,0,1)) + conv3x3 stride 2 pad 0), instead of ksize/2 on every side   */
 
@@ -97,6 +98,18 @@ typedef struct {
      * activation is never written.  Both NULL: plain GEMM.  Dense (mode 0), batch 1, fp16 output only. */
     const float* ln_stats;
     const float* ln_colsum;
+    /* Cross-attention fused behind the query projection (the north-star kernel; replaces to_q -> baddbmm -> softmax -> bmm
+     * of utils/p2p.py:321-342 on layers whose controller does not need the probabilities).  When xattn_k is set, A W^T
+     * (+ fused LayerNorm, + bias) is the query q of heads of 64 columns, and out[m, h*64 : (h+1)*64] =
+     * softmax(xattn_scale * q_h[m] . K_h^T) V_h with K = xattn_k [B * xattn_nk rows, xattn_ldk] (head h at column h*64,
+     * sample b at row b * xattn_nk) and V^T = xattn_vt [B][N][xattn_ldvt] (sample stride xattn_vt_bs elements, pad keys
+     * zero).  q never reaches memory.  Needs N %% 128 == 0, rows_per_sample %% 256 == 0, xattn_nk <= 96, dense mode, no
+     * residual. */
+    const void* xattn_k;
+    const void* xattn_vt;
+    int32_t xattn_nk, xattn_ldk, xattn_ldvt;
+    int64_t xattn_vt_bs;
+    float xattn_scale;
 } icd_gemm_desc;
 
 int icd_gemm(const icd_gemm_desc* d, void* stream);
@@ -110,6 +123,19 @@ int icd_groupnorm(const void* x0, int32_t C0, const void* x1, int32_t C1, int32_
                   const float* gamma, const float* beta, float eps, int32_t silu, void* out, float* stats_ws,
                   void* stream);
 int64_t icd_groupnorm_ws_floats(int32_t B, int32_t HW, int32_t groups);
+
+/* fp32-fidelity path of the VAE (reference: vae.to(torch.float32), utils/generation_sdxl.py:465-466).  Activations that can
+ * exceed the fp16 range (conv outputs, residual stream) are fp32 [rows, C]; GEMM operands are fp16 "split3" tensors
+ * [rows, 3C] = [hi | lo | hi] with hi = fp16(v), lo = fp16(v - hi), multiplied against weights packed [w_hi | w_hi | w_lo]
+ * by the unchanged fp16 MFMA kernels (icd_gemm with K = 3 * K0, ICD_GEMM_OUT_F32, ICD_GEMM_RESID_F32).
+ * icd_groupnorm_f32_split: GroupNorm (+SiLU) of an fp32 tensor -> split3.  stats_ws as icd_groupnorm_ws_floats.
+ * icd_split_cast: (x * scale) -> split3 for tensors that reach a conv without a GroupNorm (scale = a power of two keeps the
+ * values inside the fp16 range; the consumer's alpha undoes it exactly). */
+int icd_groupnorm_f32_split(const float* x, int32_t C, int32_t B, int32_t HW, int32_t groups, const float* gamma, const float* beta,
+                            float eps, int32_t silu, void* out_split3, float* stats_ws, void* stream);
+int icd_split_cast(const float* x, int64_t rows, int32_t C, float scale, void* out_split3, void* stream);
+/* *out (device fp32) = max |x[i]|, i < n: the host picks the power-of-two scale of icd_split_cast from it. */
+int icd_absmax(const float* x, int64_t n, float* out, void* stream);
 
 /* LayerNorm over the last dim of [rows, C] fp16 (eps 1e-5, affine).  Replaces torch layer_norm in BasicTransformerBlock. */
 int icd_layernorm(const void* x, int64_t rows, int32_t C, const float* gamma, const float* beta, float eps, void* out,
@@ -141,6 +167,13 @@ int icd_attention_fused(const void* q, const void* k, const void* vt, void* out,
 int icd_attention_fused_ex(const void* q, const void* k, const void* vt, void* out, int32_t B, int32_t H, int32_t Nq,
                            int32_t Nk, int32_t d, int32_t ldq, int32_t ldk, int32_t ldvt, int32_t ldo,
                            int64_t vt_batch_stride, float scale, int32_t flags, void* stream);
+
+/* Materialised attention probabilities in one pass (the layers whose controller reads or edits P, utils/p2p.py:335-338):
+ *   probs[(b*H + h), n, 0:Nk] = softmax_key(scale * q[b,n,h,:] . k[b,:,h,:])   fp16, row stride ldp, columns [Nk, ldp) zero.
+ * Replaces baddbmm -> softmax of Attention.get_attention_scores without the fp32 score tensor in between; the controller
+ * callback and P.V (icd_gemm, batched) follow as before.  q / k layouts as in icd_attention_fused. */
+int icd_attention_probs(const void* q, const void* k, void* probs, int32_t B, int32_t H, int32_t Nq, int32_t Nk, int32_t d,
+                        int32_t ldq, int32_t ldk, int32_t ldp, float scale, void* stream);
 
 /* Sinusoidal embeddings.  kind 0: diffusers Timesteps(dim, flip_sin_to_cos=True, shift=0) -> [cos || sin];
  * kind 1: guidance_scale_embedding (utils/generation.py:96-122) -> [sin || cos] of 1000*w, denominator half-1.
@@ -277,7 +310,8 @@ int icd_unet_forward(icd_unet* u, const icd_unet_io* io, void* stream);
 #define ICD_PROF_LAYERNORM    5
 #define ICD_PROF_SOFTMAX      6
 #define ICD_PROF_MISC         7
-#define ICD_PROF_KINDS        8
+#define ICD_PROF_XATTN        8   /* query projection + cross-attention in one launch (gemm.hip xattn_epilogue) */
+#define ICD_PROF_KINDS        9
 typedef struct {
     int32_t kind;
     int32_t launches;
@@ -305,6 +339,9 @@ int icd_profile_dump(icd_profile_record* recs, int32_t max_recs);
 int icd_debug_gemm_timeline(void* buf);
 /* m-tiles per L2 group of the GEMM block -> tile map (0: default).  A/B tuning only; results are unchanged. */
 int icd_debug_gemm_group_m(int32_t gm);
+/* off != 0: the executor runs the query projection and the cross-attention as two launches again (A/B measurement of the
+ * fused kernel; results differ only by the fp16 rounding of q). */
+int icd_debug_no_xattn_fusion(int32_t off);
 
 #ifdef __cplusplus
 }

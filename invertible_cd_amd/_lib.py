@@ -13,6 +13,7 @@ ICD_GEMM_GEGLU = 1
 ICD_GEMM_OUT_F32 = 2
 ICD_GEMM_OUT_TRANS = 4
 ICD_GEMM_PAD_HI = 8
+ICD_GEMM_RESID_F32 = 16
 ICD_HOOK_QUERY = 0
 ICD_HOOK_PROBS = 1
 
@@ -30,6 +31,8 @@ class GemmDesc(C.Structure):
         ("o_bs0", C.c_int64), ("o_bs1", C.c_int64), ("alpha", C.c_float), ("flags", C.c_int32),
         ("splitk_ws", C.c_void_p), ("splitk_ws_bytes", C.c_int64),
         ("ln_stats", C.c_void_p), ("ln_colsum", C.c_void_p),
+        ("xattn_k", C.c_void_p), ("xattn_vt", C.c_void_p), ("xattn_nk", C.c_int32), ("xattn_ldk", C.c_int32),
+        ("xattn_ldvt", C.c_int32), ("xattn_vt_bs", C.c_int64), ("xattn_scale", C.c_float),
     ]
 
 
@@ -56,7 +59,7 @@ class ProfileRecord(C.Structure):
                 ("flops", C.c_double)]
 
 
-PROF_KINDS = ("gemm_conv", "gemm_dense", "gemm_batched", "attn_fused", "groupnorm", "layernorm", "softmax", "misc")
+PROF_KINDS = ("gemm_conv", "gemm_dense", "gemm_batched", "attn_fused", "groupnorm", "layernorm", "softmax", "misc", "xattn_fused")
 
 
 class UNetIO(C.Structure):
@@ -79,12 +82,17 @@ SIGNATURES = {
     "icd_groupnorm_ws_floats": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
     "icd_layernorm": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p,
                                 C.c_void_p]),
+    "icd_groupnorm_f32_split": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_float,
+                                          C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "icd_absmax": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "icd_split_cast": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]),
     "icd_layernorm_stats": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]),
     "icd_softmax_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_int32,
                                    C.c_void_p]),
     "icd_attention_fused": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                       C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64,
                                       C.c_float, C.c_void_p]),
+    "icd_attention_probs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int32] * 8 + [C.c_float, C.c_void_p]),
     "icd_sinusoid": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "icd_silu": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "icd_conv_in": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
@@ -114,6 +122,7 @@ SIGNATURES = {
                                  C.c_void_p, C.c_int32, C.c_void_p]),
     "icd_debug_gemm_timeline": (C.c_int, [C.c_void_p]),
     "icd_debug_gemm_group_m": (C.c_int, [C.c_int32]),
+    "icd_debug_no_xattn_fusion": (C.c_int, [C.c_int32]),
     "icd_profile_enable": (C.c_int, [C.c_int32]),
     "icd_profile_read": (C.c_int, [C.POINTER(ProfileRow), C.c_int32]),
     "icd_profile_dump": (C.c_int, [C.POINTER(ProfileRecord), C.c_int32]),

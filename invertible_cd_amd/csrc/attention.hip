@@ -519,6 +519,190 @@ __global__ __launch_bounds__(256, 2) void attn_cross_kernel(AttnK p, int tiles_p
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Materialised attention probabilities in ONE pass over the operands (layers whose controller reads or edits P,
+// utils/p2p.py:335-338): P[b*H + h][q][key] = softmax_key(scale * q . k) as fp16, straight from the S^T accumulators -
+// the fp32 score tensor of the old path (QK^T GEMM -> 4 B/element out, 4 B/element back in, softmax kernel) never exists.
+// A wave owns one 32-query tile of one (batch, head): Q fragments in registers, K fragments streamed from global / L2
+// (one k-tile ahead) as the MFMA A operand in the bit-swapped row order that makes a lane's 16 accumulators two runs of 8
+// consecutive keys.  <= 96 keys (cross-attention): the three S^T tiles stay in registers, exact softmax.  More keys
+// (self-attention of the <= 32^2 layers): two sweeps over K - running (max, sum) first, then S^T again and
+// P = exp2(s - max) / sum; recomputing 4*Nq*Nk*d flops is far cheaper than 8 B/element of HBM traffic.  Probabilities
+// leave through a per-wave LDS patch as 128-B row segments; pad columns [Nk, ldp) are written as zeros.
+// ---------------------------------------------------------------------------------------------------------------
+struct ProbsK {
+    const half_t* q; const half_t* k; half_t* p;
+    int B, H, Nq, Nk, d, ldq, ldk, ldp;
+    float scale_log2;
+};
+
+template <int KS>
+__global__ __launch_bounds__(256, 2) void attn_probs_kernel(ProbsK a) {
+    __shared__ __attribute__((aligned(16))) half_t patch_all[4][32 * 72];
+    const int tid = threadIdx.x, l = tid & 63, lr = l & 31, lh = l >> 5;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
+    const int q0 = (blockIdx.x * 4 + wv) * 32;
+    if (q0 >= a.Nq) return;
+    half_t* patch = patch_all[wv];
+    f16x8 z8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) z8[e] = (half_t)0.f;
+    f16x8 qf[KS];
+    {
+        const int qrow = q0 + lr;
+        const half_t* qp = a.q + ((long long)b * a.Nq + qrow) * a.ldq + h * a.d;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int dd = ks * 16 + lh * 8;
+            qf[ks] = (qrow < a.Nq && dd < a.d) ? *reinterpret_cast<const f16x8*>(qp + dd) : z8;
+        }
+    }
+    const half_t* Kb = a.k + (long long)b * a.Nk * a.ldk + h * a.d;
+    const int prow = (lr & 0x13) | ((lr & 4) << 1) | ((lr & 8) >> 1);
+    auto load_k = [&](f16x8 (&kf)[KS], int kt) {
+        const int key = kt * 32 + prow;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int dd = ks * 16 + lh * 8;
+            kf[ks] = (key < a.Nk && dd < a.d) ? *reinterpret_cast<const f16x8*>(Kb + (long long)key * a.ldk + dd) : z8;
+        }
+    };
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const float c = a.scale_log2;
+    auto scores = [&](f32x16& s, const f16x8 (&kf)[KS], int kt) {            // s = log2(e) * scale * q.k, keys past Nk -> -inf
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[ks], qf[ks], ks == 0 ? zero16 : s, 0, 0, 0);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int key = kt * 32 + 16 * (e >> 3) + 8 * lh + (e & 7);
+            s[e] = key < a.Nk ? s[e] * c : -INFINITY;
+        }
+    };
+    auto half_swap_max = [&](float v) {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        return fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+    };
+    auto half_swap_sum = [&](float v) {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        return __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+    };
+    half_t* Pb = a.p + ((long long)bh * a.Nq + q0) * a.ldp;
+    // one k-tile of probabilities (this lane: query lr, keys 32kt + 16j + 8lh .. +7, j = 0, 1) -> patch -> global rows
+    auto emit = [&](const f32x16& pv, int kt) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            f16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (half_t)pv[8 * j + e];
+            *reinterpret_cast<f16x8*>(patch + lr * 72 + (kt & 1) * 32 + 16 * j + 8 * lh) = o;
+        }
+    };
+    auto flush = [&](int kt_first, int ncols) {                                // patch columns [0, ncols) are keys 32*kt_first ...
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            const int r = pass * 8 + (l >> 3), c8 = (l & 7) * 8;
+            const int col = kt_first * 32 + c8;
+            if (c8 < ncols && col < a.ldp && q0 + r < a.Nq)
+                *reinterpret_cast<f16x8*>(Pb + (long long)r * a.ldp + col) = *reinterpret_cast<const f16x8*>(patch + r * 72 + c8);
+        }
+    };
+    const int nt = (a.ldp + 31) >> 5;                      // k-tiles incl. the pad columns (they are written as zeros)
+    if (nt <= 3) {
+        // ---- few keys (cross-attention): all S^T tiles in registers, exact softmax ----
+        f32x16 s[3];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 3; ++kt) {
+            if (kt < nt) {
+                f16x8 kf[KS];
+                load_k(kf, kt);
+                scores(s[kt], kf, kt);
+#pragma unroll
+                for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[kt][e]);
+            }
+        }
+        mx = half_swap_max(mx);
+        float rs = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 3; ++kt)
+            if (kt < nt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) { s[kt][e] = __builtin_amdgcn_exp2f(s[kt][e] - mx); rs += s[kt][e]; }
+        const float inv = 1.0f / half_swap_sum(rs);
+#pragma unroll
+        for (int kt = 0; kt < 3; ++kt) {
+            if (kt < nt) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) s[kt][e] *= inv;
+                emit(s[kt], kt);
+                if ((kt & 1) || kt == nt - 1) flush(kt & ~1, (kt & 1) ? 64 : 32);
+            }
+        }
+        return;
+    }
+    // ---- many keys: sweep 1 = running row maximum and sum, sweep 2 = probabilities ----
+    float m_run = -INFINITY, l_run = 0.f;
+    {
+        f16x8 ka[KS], kb[KS];
+        load_k(ka, 0);
+        for (int kt = 0; kt < nt; kt += 2) {
+            if (kt + 1 < nt) load_k(kb, kt + 1);
+            f32x16 s;
+            scores(s, ka, kt);
+            float tm = -INFINITY;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) tm = fmaxf(tm, s[e]);
+            float mn = fmaxf(m_run, tm);                     // this half-wave's view; the halves are merged after the sweep
+            float acc = 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc += __builtin_amdgcn_exp2f(s[e] - mn);
+            l_run = l_run * __builtin_amdgcn_exp2f(m_run - mn) + acc;
+            m_run = mn;
+            if (kt + 1 < nt) {
+                if (kt + 2 < nt) load_k(ka, kt + 2);
+                scores(s, kb, kt + 1);
+                tm = -INFINITY;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) tm = fmaxf(tm, s[e]);
+                mn = fmaxf(m_run, tm);
+                acc = 0.f;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc += __builtin_amdgcn_exp2f(s[e] - mn);
+                l_run = l_run * __builtin_amdgcn_exp2f(m_run - mn) + acc;
+                m_run = mn;
+            }
+        }
+    }
+    {   // merge the two half-waves (each saw 16 of every 32 keys); a half that saw only masked keys has m = -inf, l = 0
+        const float m_all = half_swap_max(m_run);
+        const float mine = m_run == -INFINITY ? 0.f : l_run * __builtin_amdgcn_exp2f(m_run - m_all);
+        l_run = half_swap_sum(mine);
+        m_run = m_all;
+    }
+    const float inv = 1.0f / l_run;
+    {
+        f16x8 ka[KS], kb[KS];
+        load_k(ka, 0);
+        for (int kt = 0; kt < nt; kt += 2) {
+            if (kt + 1 < nt) load_k(kb, kt + 1);
+            f32x16 s;
+            scores(s, ka, kt);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s[e] = __builtin_amdgcn_exp2f(s[e] - m_run) * inv;
+            emit(s, kt);
+            if (kt + 1 < nt) {
+                if (kt + 2 < nt) load_k(ka, kt + 2);
+                scores(s, kb, kt + 1);
+#pragma unroll
+                for (int e = 0; e < 16; ++e) s[e] = __builtin_amdgcn_exp2f(s[e] - m_run) * inv;
+                emit(s, kt + 1);
+                flush(kt, 64);
+            } else flush(kt, 32);
+        }
+    }
+}
+
 template <int KS, int DT>
 int launch_attn_cross(AttnK k, hipStream_t st) {
     // tiles per wave: amortise the K / V^T fragment loads (24 x 1 KiB per wave from L2) but keep >= ~4 blocks per CU
@@ -551,6 +735,28 @@ int launch_attn(AttnK k, hipStream_t st) {
 extern "C" int icd_attention_fused_ex(const void* q, const void* k, const void* vt, void* out, int32_t B, int32_t H,
                                       int32_t Nq, int32_t Nk, int32_t d, int32_t ldq, int32_t ldk, int32_t ldvt, int32_t ldo,
                                       int64_t vt_batch_stride, float scale, int32_t flags, void* stream);
+
+extern "C" int icd_attention_probs(const void* q, const void* k, void* probs, int32_t B, int32_t H, int32_t Nq, int32_t Nk,
+                                   int32_t d, int32_t ldq, int32_t ldk, int32_t ldp, float scale, void* stream) {
+    ICD_CHECK_ARG(q && k && probs, "icd_attention_probs: null pointer");
+    ICD_CHECK_ARG(B > 0 && H > 0 && Nq > 0 && Nk > 0, "icd_attention_probs: empty shape");
+    ICD_CHECK_ARG(d > 0 && d % 8 == 0 && d <= 160, "icd_attention_probs: head dim must be a multiple of 8, <= 160 (got %d)", d);
+    ICD_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldp % 8 == 0 && ldp >= Nk, "icd_attention_probs: leading dims must be 16-byte aligned, ldp >= Nk");
+    ICD_CHECK_ARG(scale > 0.f, "icd_attention_probs: scale must be positive");
+    ICD_CHECK_ARG((long long)B * H <= 65535, "icd_attention_probs: B * H exceeds the grid limit");
+    ProbsK a;
+    a.q = (const half_t*)q; a.k = (const half_t*)k; a.p = (half_t*)probs;
+    a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.d = d; a.ldq = ldq; a.ldk = ldk; a.ldp = ldp;
+    a.scale_log2 = scale * 1.4426950408889634f;
+    const dim3 grid((unsigned)((Nq + 127) / 128), (unsigned)(B * H));
+    hipStream_t st = (hipStream_t)stream;
+    if (d <= 48) hipLaunchKernelGGL(attn_probs_kernel<3>, grid, dim3(256), 0, st, a);
+    else if (d <= 80) hipLaunchKernelGGL(attn_probs_kernel<5>, grid, dim3(256), 0, st, a);
+    else if (d <= 128) hipLaunchKernelGGL(attn_probs_kernel<8>, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(attn_probs_kernel<10>, grid, dim3(256), 0, st, a);
+    ICD_CHECK_LAUNCH("icd_attention_probs");
+    return ICD_OK;
+}
 
 extern "C" int icd_attention_fused(const void* q, const void* k, const void* vt, void* out, int32_t B, int32_t H,
                                    int32_t Nq, int32_t Nk, int32_t d, int32_t ldq, int32_t ldk, int32_t ldvt,

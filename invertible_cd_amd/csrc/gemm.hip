@@ -36,7 +36,142 @@ constexpr int BN = 128;
 
 // MODE 0: dense A [M,K] (lda);  MODE 1: conv, Cin % 64 == 0 && C0 % 64 == 0 (tap / concat source are wave-uniform
 // per k-tile and tracked in SGPRs);  MODE 2: conv, any Cin % 8 == 0 (per-lane tap tracking; reduced-width test nets).
-template <int MODE, bool TRANS, int WM, int NSTAGE>
+// ---------------------------------------------------------------------------------------------------------------------
+// Cross-attention as the epilogue of the query projection (the kernel BASELINE.json's north star names, in the only
+// form that changes its roofline: as a stand-alone kernel it moves Q in + O out for 4*N*77*C flops, arithmetic
+// intensity ~77 flop/B).  Here the 256 x 128 tile of  q = LN(h) W_q^T  stays in the accumulators: a wave owns 64 query
+// rows x 64 columns = ONE head (d = 64) of two 32-query tiles, and runs  S^T = K q^T -> softmax over the <= 96 key slots
+// -> O^T = V^T P^T  on them in place; only O is written.  Q is never stored or re-read and the attention launch disappears.
+//   * accumulator -> MFMA B operand without any cross-lane traffic: lane (lr, lh) holds for query lr the head dims
+//     16ks + 8(e >> 2) + 4lh + (e & 3), e = 0..7, of k-step ks in registers 8(ks & 1) + e of acc[i][ks >> 1]; the sum over the
+//     head dim does not care about the order, so the K fragments are simply loaded in the same permuted order (two 8-B
+//     loads per fragment instead of one 16-B load);
+//   * K rows enter bit-swapped (bits 2 and 3 of the key index) so the 8 probabilities a lane feeds to one P^T k-slot are
+//     8 consecutive keys and every V^T fragment is one 16-B load (same trick as attention.hip);
+//   * fused LayerNorm correction, bias, the softmax scale and log2(e) are applied to the accumulators in fp32 before the
+//     single fp16 rounding of q;
+//   * O goes through a private 4.5 KiB LDS patch per wave and leaves as 128-B row segments.
+// Requirements (checked by icd_gemm): head dim 64, N % 128 == 0, rows_per_sample % 256 == 0, keys <= 96.
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void xattn_epilogue(const GemmK& p, f32x16 (&acc)[2][2], unsigned char* smem, int wv, int wm, int wn,
+                                               int l, int m0, int n0) {
+    constexpr int KT = 3, KS = 4, ST = 6, DT = 2;
+    const int lr = l & 31, lh = l >> 5;
+    const int b = m0 / p.rps;                              // the 256 rows of a block lie inside one sample
+    const int ncol = n0 + wn * 64;                         // first column of this wave's head
+    const half_t* Kb = p.xk + (long long)b * p.x_nk * p.x_ldk + ncol;
+    const half_t* Vb = p.xvt + (long long)b * p.x_vt_bs + (long long)ncol * p.x_ldvt;
+    f16x8 z8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) z8[e] = (half_t)0.f;
+    const int prow = (lr & 0x13) | ((lr & 4) << 1) | ((lr & 8) >> 1);
+    f16x8 kf[KT][KS];
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int key = kt * 32 + prow;
+            if (key < p.x_nk) {
+                const half_t* src = Kb + (long long)key * p.x_ldk + ks * 16 + lh * 4;
+                const f16x4 lo = *reinterpret_cast<const f16x4*>(src), hi = *reinterpret_cast<const f16x4*>(src + 8);
+                kf[kt][ks] = (f16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            } else kf[kt][ks] = z8;
+        }
+    f16x8 vf[ST][DT];
+#pragma unroll
+    for (int st = 0; st < ST; ++st)
+#pragma unroll
+        for (int i = 0; i < DT; ++i) {
+            const int row = i * 32 + lr, key = st * 16 + lh * 8;
+            vf[st][i] = key < p.x_ldvt ? *reinterpret_cast<const f16x8*>(Vb + (long long)row * p.x_ldvt + key) : z8;
+        }
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    __syncthreads();                                       // every wave is done with the operand stages: LDS is free
+    half_t* patch = reinterpret_cast<half_t*>(smem) + wv * (32 * 72);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int mrow = m0 + wm * 64 + i * 32;
+        // ---- q = (LN-corrected, biased) accumulators * softmax scale * log2(e), rounded once to fp16 ----
+        f32x2 lst = {0.f, 1.f};
+        if (p.ln_stats) lst = *reinterpret_cast<const f32x2*>(p.ln_stats + 2 * (long long)(mrow + lr));
+        f16x8 qf[KS];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = ncol + j * 32 + 8 * g + 4 * lh;
+                f32x4 s4 = {0.f, 0.f, 0.f, 0.f}, t4 = {0.f, 0.f, 0.f, 0.f};
+                if (p.ln_stats) s4 = *reinterpret_cast<const f32x4*>(p.ln_s + n);
+                if (p.bias) t4 = *reinterpret_cast<const f32x4*>(p.bias + n);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = acc[i][j][4 * g + e] * p.alpha;
+                    v = lst[1] * (v - lst[0] * s4[e]) + t4[e];
+                    qf[2 * j + (g >> 1)][4 * (g & 1) + e] = (half_t)(v * p.x_scale_log2);
+                }
+            }
+        // ---- S^T[key][q] over 96 key slots, exact softmax (element e of s[kt] is key 32kt + 16(e>>3) + 8lh + (e&7)) ----
+        f32x16 s[KT];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt)
+                s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kt][ks], qf[ks], ks == 0 ? zero16 : s[kt], 0, 0, 0);
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int key = kt * 32 + 16 * (e >> 3) + 8 * lh + (e & 7);
+                if (key >= p.x_nk) s[kt][e] = -INFINITY;
+                mx = fmaxf(mx, s[kt][e]);
+            }
+        {
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+            mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+        }
+        float rs = 0.f;
+        f16x8 pf[ST];
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float pv = __builtin_amdgcn_exp2f(s[kt][e] - mx);
+                rs += pv;
+                pf[kt * 2 + (e >> 3)][e & 7] = (half_t)pv;
+            }
+        f32x16 o[DT];
+#pragma unroll
+        for (int st = 0; st < ST; ++st)
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[st][dt], pf[st], st == 0 ? zero16 : o[dt], 0, 0, 0);
+        float l_tot;
+        {
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(rs), __float_as_uint(rs), false, false);
+            l_tot = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+        }
+        const float inv = 1.0f / l_tot;
+        // ---- O tile [32 queries][64 dims] through the wave's LDS patch (row stride 72 halves), out as 128-B rows ----
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f16x4 v = {(half_t)(o[dt][4 * g] * inv), (half_t)(o[dt][4 * g + 1] * inv), (half_t)(o[dt][4 * g + 2] * inv),
+                           (half_t)(o[dt][4 * g + 3] * inv)};
+                *reinterpret_cast<f16x4*>(patch + lr * 72 + dt * 32 + 8 * g + 4 * lh) = v;
+            }
+        half_t* out = reinterpret_cast<half_t*>(p.out);
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            const int r = pass * 8 + (l >> 3), c8 = (l & 7) * 8;
+            const f16x8 v = *reinterpret_cast<const f16x8*>(patch + r * 72 + c8);
+            *reinterpret_cast<f16x8*>(out + (long long)(mrow + r) * p.ldo + ncol + c8) = v;
+        }
+    }
+}
+
+template <int MODE, bool TRANS, int WM, int NSTAGE, bool XATTN = false>
 __global__ __launch_bounds__(WM * 128, 2) void gemm_kernel(GemmK p) {
     constexpr int NT = WM * 128;                 // threads
     constexpr int BM = WM * 64;
@@ -265,6 +400,16 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_kernel(GemmK p) {
     }
 #undef ICD_GLDS4
 
+    if constexpr (XATTN) {
+        static_assert(!XATTN || (MODE == 0 && !TRANS), "fused cross-attention: dense tiles (every wave owns 64 rows x one head)");
+        if (tl && tid == 0) tl[2] = __builtin_amdgcn_s_memrealtime();
+        xattn_epilogue(p, acc, smem, wv, wm, wn, l, m0, n0);
+        if (tl) {
+            __syncthreads();
+            if (tid == 0) tl[3] = __builtin_amdgcn_s_memrealtime();
+        }
+        return;
+    }
     // ---- epilogue: fp32 staging through LDS, one 64-row slab (one wave row) at a time ----------------------
     if (tl && tid == 0) tl[2] = __builtin_amdgcn_s_memrealtime();
     float* stage = reinterpret_cast<float*>(smem);
@@ -411,9 +556,16 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_kernel(GemmK p) {
                     for (int e = 0; e < 8; ++e) v[e] += (float)rb[e];
                 }
                 if (p.resid) {
+                    if (p.flags & ICD_GEMM_RESID_F32) {
+                        const float* rp = reinterpret_cast<const float*>(p.resid) + (long long)m * p.ldr + n;
+                        const f32x4 r0 = *reinterpret_cast<const f32x4*>(rp), r1 = *reinterpret_cast<const f32x4*>(rp + 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
+                    } else {
                     f16x8 rs = *reinterpret_cast<const f16x8*>(p.resid + (long long)m * p.ldr + n);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] += (float)rs[e];
+                    }
                 }
                 if (out_f32) {
                     float* out = reinterpret_cast<float*>(p.out) + o_off + (long long)m * p.ldo + n;
@@ -461,9 +613,16 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmK p) {
         for (int e = 0; e < 8; ++e) v[e] += (float)rb[e];
     }
     if (p.resid) {
+        if (p.flags & ICD_GEMM_RESID_F32) {
+            const float* rp = reinterpret_cast<const float*>(p.resid) + (long long)m * p.ldr + n;
+            const f32x4 r0 = *reinterpret_cast<const f32x4*>(rp), r1 = *reinterpret_cast<const f32x4*>(rp + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
+        } else {
         f16x8 rs = *reinterpret_cast<const f16x8*>(p.resid + (long long)m * p.ldr + n);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] += (float)rs[e];
+        }
     }
     if (p.flags & ICD_GEMM_OUT_F32) {
         float* out = reinterpret_cast<float*>(p.out) + (long long)m * p.ldo + n;
@@ -484,17 +643,17 @@ int launch_reduce(const GemmK& k, hipStream_t st) {
     return ICD_OK;
 }
 
-template <int MODE, bool TRANS, int WM, int NSTAGE>
+template <int MODE, bool TRANS, int WM, int NSTAGE, bool XATTN = false>
 int launch(const GemmK& k, int batch, hipStream_t st) {
     constexpr int smem = NSTAGE * (WM * 64 + BN) * 128;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<MODE, TRANS, WM, NSTAGE>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<MODE, TRANS, WM, NSTAGE, XATTN>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         attr_set = true;
     }
     dim3 grid(k.nbm * k.nbn, k.ksplit, batch);
-    hipLaunchKernelGGL((gemm_kernel<MODE, TRANS, WM, NSTAGE>), grid, dim3(WM * 128), smem, st, k);
+    hipLaunchKernelGGL((gemm_kernel<MODE, TRANS, WM, NSTAGE, XATTN>), grid, dim3(WM * 128), smem, st, k);
     ICD_CHECK_LAUNCH("icd_gemm");
     if (k.ksplit > 1) return launch_reduce(k, st);
     return ICD_OK;
@@ -539,9 +698,15 @@ extern "C" int64_t icd_gemm_workspace_bytes(int32_t M, int32_t N, int32_t K) {
     return need;
 }
 
+static int g_xattn_tile = 0;                    // 0: planner, 2: force 128 x 128, 4: force 256 x 128 (icd_debug_gemm_group_m(-2 / -4))
 static int g_group_m = 0;
 // Tuning override of the L2 grouping of the block -> tile map (0: the planner's default); results never change.
-extern "C" int icd_debug_gemm_group_m(int32_t gm) { g_group_m = gm; return ICD_OK; }
+extern "C" int icd_debug_gemm_group_m(int32_t gm) {
+    if (gm == -2 || gm == -4) { g_xattn_tile = -gm; return ICD_OK; }      // tuning: tile of the fused query-projection + attention kernel
+    if (gm == -1) { g_xattn_tile = 0; return ICD_OK; }
+    g_group_m = gm;
+    return ICD_OK;
+}
 
 static unsigned long long* g_timeline = nullptr;
 // Diagnostics: while a buffer is registered, every big-tile GEMM block writes four s_memrealtime stamps (100 MHz:
@@ -581,6 +746,29 @@ extern "C" int icd_gemm(const icd_gemm_desc* d, void* stream) {
     ICD_CHECK_ARG(!(d->ln_stats && (d->mode != 0 || (d->batch > 1) || (d->flags & ICD_GEMM_OUT_F32))),
                   "icd_gemm: the fused LayerNorm applies to dense, unbatched, fp16-output GEMMs");
     const int batch = d->batch > 0 ? d->batch : 1;
+    k.xk = (const half_t*)d->xattn_k; k.xvt = (const half_t*)d->xattn_vt;
+    k.x_nk = d->xattn_nk; k.x_ldk = d->xattn_ldk; k.x_ldvt = d->xattn_ldvt; k.x_vt_bs = d->xattn_vt_bs;
+    k.x_scale_log2 = d->xattn_scale * 1.4426950408889634f;
+    if (d->xattn_k) {
+        // query projection + cross-attention in one launch: out = softmax(scale (A W^T + ...) K^T) V per 64-wide head
+        ICD_CHECK_ARG(d->xattn_vt && d->xattn_scale > 0.f, "icd_gemm(xattn): xattn_vt and a positive xattn_scale are required");
+        ICD_CHECK_ARG(d->mode == 0 && batch == 1 && !(d->flags & (ICD_GEMM_GEGLU | ICD_GEMM_OUT_F32 | ICD_GEMM_OUT_TRANS)) &&
+                      !d->resid && !d->rowbias, "icd_gemm(xattn): dense fp16 GEMM without residual / rowbias / GEGLU only");
+        ICD_CHECK_ARG(d->N % 128 == 0 && d->K % 64 == 0 && d->lda % 8 == 0 && d->ldo % 8 == 0,
+                      "icd_gemm(xattn): N %% 128, K %% 64 and 16-byte aligned leading dims required (head dim 64)");
+        ICD_CHECK_ARG(d->rows_per_sample > 0 && d->rows_per_sample % 256 == 0 && d->M % d->rows_per_sample == 0,
+                      "icd_gemm(xattn): rows_per_sample must be a multiple of 256 (a 256-row tile stays inside one sample)");
+        ICD_CHECK_ARG(d->xattn_nk > 0 && d->xattn_nk <= 96 && d->xattn_ldk % 4 == 0 && d->xattn_ldvt % 8 == 0 && d->xattn_ldvt >= d->xattn_nk,
+                      "icd_gemm(xattn): 1..96 keys, ldk %% 4 == 0, ldvt %% 8 == 0, ldvt >= keys");
+        k.ksplit = 1; k.kt_per_split = (d->K + BK - 1) / BK;
+        // 128 x 128 tiles with two resident blocks per CU (measured, SDXL 32x32 level: 63.8 us at B = 8 / 98.9 us at B = 16 against
+        // 73.8 / 113.1 us with 256 x 128 tiles, whose partial last round costs a whole tile; the two launches it replaces take
+        // 67.3 / 109.9 us); the 256-row tile stays available for tuning
+        const bool big = g_xattn_tile == 4;
+        k.nbm = d->M / (big ? 256 : 128); k.nbn = d->N / 128;
+        if (g_group_m <= 0 && k.nbn >= 16) k.gm = 8;
+        return big ? launch<0, false, 4, 3, true>(k, 1, (hipStream_t)stream) : launch<0, false, 2, 2, true>(k, 1, (hipStream_t)stream);
+    }
     int wm = 2, ks = 1;
     const bool allow_split = !trans && !geglu && batch == 1 && d->splitk_ws != nullptr && d->splitk_ws_bytes > 0;
     const int nk_total = (d->K + BK - 1) / BK;

@@ -21,6 +21,9 @@ struct GemmK {
     int gm;                                      // m-tiles per L2 group of the block -> tile map (tile_of_block)
     const float* ln_stats;                       // fused LayerNorm: fp32 [M][2] = (mean, rstd) of the A rows, or null
     const float* ln_s;                           //                  fp32 [N] = row sums of the gamma-scaled weights
+    // cross-attention fused behind the query projection (icd_gemm_desc.xattn_*; gemm.hip xattn_epilogue)
+    const half_t* xk; const half_t* xvt;
+    int x_nk, x_ldk, x_ldvt; long long x_vt_bs; float x_scale_log2;
     unsigned long long* timeline;                // diagnostics (icd_debug_gemm_timeline): 4 s_memrealtime stamps per block, or null
 };
 

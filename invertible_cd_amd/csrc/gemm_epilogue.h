@@ -149,9 +149,16 @@ __device__ __forceinline__ void wave_epilogue(const GemmK& p, f32x16 (&acc)[TM][
                         for (int e = 0; e < 8; ++e) v[e] += (float)rb[e];
                     }
                     if (p.resid) {
+                        if (p.flags & ICD_GEMM_RESID_F32) {
+                            const float* rp = reinterpret_cast<const float*>(p.resid) + (long long)m * p.ldr + n;
+                            const f32x4 r0 = *reinterpret_cast<const f32x4*>(rp), r1 = *reinterpret_cast<const f32x4*>(rp + 4);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
+                        } else {
                         f16x8 rs = *reinterpret_cast<const f16x8*>(p.resid + (long long)m * p.ldr + n);
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] += (float)rs[e];
+                        }
                     }
                     if (out_f32) {
                         float* out = reinterpret_cast<float*>(p.out) + (long long)m * p.ldo + n;

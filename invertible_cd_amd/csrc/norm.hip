@@ -256,6 +256,118 @@ __global__ __launch_bounds__(GN_THREADS) void gn_small_kernel(const half_t* __re
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// GroupNorm of the fp32-fidelity VAE path (vae.py `.to(torch.float32)`, the reference's upcast of the SDXL VAE,
+// utils/generation_sdxl.py:465-466): fp32 input [B*HW, C] (the residual stream / conv outputs are kept in fp32 there because
+// real SDXL-VAE activations exceed the fp16 range), statistics in fp32, output in the "split3" operand format of that
+// path: every normalised value v leaves as hi = fp16(v), lo = fp16(v - hi) in a [B*HW, 3C] tensor laid out [hi | lo | hi],
+// so that the unchanged fp16 MFMA GEMMs compute (a_hi + a_lo)(w_hi + w_lo) - a_lo w_lo against weights packed
+// [w_hi | w_hi | w_lo]: ~2^-21 relative operand error instead of 2^-11.  Thread = 4 channels (one 16-B fp32 load).
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(GN_THREADS) void gn_stats_f32_kernel(const float* __restrict__ x, int C, int HW, int groups,
+                                                                   int pix_per_split, float* __restrict__ ws) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float* part = reinterpret_cast<float*>(smem_raw);          // [rpi][C][2]
+    const int nchunk = C >> 2, rpi = GN_THREADS / nchunk;
+    const int tid = threadIdx.x, chunk = tid % nchunk, rsub = tid / nchunk;
+    const int b = blockIdx.y, sp = blockIdx.x, nsplit = gridDim.x;
+    const int p_begin = sp * pix_per_split, p_end = min(HW, p_begin + pix_per_split);
+    if (rsub < rpi) {
+        float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
+        const float* base = x + (long long)b * HW * C + chunk * 4;
+        for (int p = p_begin + rsub; p < p_end; p += rpi) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(base + (long long)p * C);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { s[e] += v[e]; q[e] += v[e] * v[e]; }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { part[((rsub * C) + chunk * 4 + e) * 2] = s[e]; part[((rsub * C) + chunk * 4 + e) * 2 + 1] = q[e]; }
+    }
+    __syncthreads();
+    if (tid < groups) {
+        const int cpg = C / groups;
+        float ss = 0.f, qq = 0.f;
+        for (int r = 0; r < rpi; ++r)
+            for (int c = 0; c < cpg; ++c) { ss += part[((r * C) + tid * cpg + c) * 2]; qq += part[((r * C) + tid * cpg + c) * 2 + 1]; }
+        float* o = ws + (((long long)b * nsplit + sp) * groups + tid) * 2;
+        o[0] = ss; o[1] = qq;
+    }
+}
+
+__device__ __forceinline__ void split_store4(half_t* row, int C, int c, const float (&v)[4]) {
+    f16x4 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { hi[e] = (half_t)v[e]; lo[e] = (half_t)(v[e] - (float)hi[e]); }
+    *reinterpret_cast<f16x4*>(row + c) = hi;
+    *reinterpret_cast<f16x4*>(row + C + c) = lo;
+    *reinterpret_cast<f16x4*>(row + 2 * C + c) = hi;
+}
+
+__global__ __launch_bounds__(GN_THREADS) void gn_apply_split_kernel(const float* __restrict__ x, int C, int HW, int groups, int nsplit,
+                                                                     int pix_per_block, const float* __restrict__ ws,
+                                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                     float eps, int silu, half_t* __restrict__ out) {
+    __shared__ float s_mean[64], s_rstd[64];
+    const int nchunk = C >> 2, rpi = GN_THREADS / nchunk;
+    const int tid = threadIdx.x, b = blockIdx.y;
+    {
+        const int g = tid >> 4, j = tid & 15;
+        float ss = 0.f, qq = 0.f;
+        if (g < groups)
+            for (int sp = j; sp < nsplit; sp += 16) {
+                const float* o = ws + (((long long)b * nsplit + sp) * groups + g) * 2;
+                ss += o[0]; qq += o[1];
+            }
+        ss = group_sum<16>(ss); qq = group_sum<16>(qq);
+        if (g < groups && j == 0) {
+            const float n = (float)HW * (float)(C / groups);
+            const float mean = ss / n;
+            s_mean[g] = mean;
+            s_rstd[g] = rsqrtf(fmaxf(qq / n - mean * mean, 0.f) + eps);
+        }
+    }
+    __syncthreads();
+    const int chunk = tid % nchunk, rsub = tid / nchunk;
+    if (rsub >= rpi) return;
+    const int ch = chunk * 4, cpg = C / groups;
+    float sc[4], sh[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int g = (ch + e) / cpg;
+        sc[e] = s_rstd[g] * gamma[ch + e];
+        sh[e] = beta[ch + e] - s_mean[g] * sc[e];
+    }
+    const float* base = x + (long long)b * HW * C + ch;
+    half_t* ob = out + (long long)b * HW * 3 * C;
+    const int p_begin = blockIdx.x * pix_per_block, p_end = min(HW, p_begin + pix_per_block);
+    for (int p = p_begin + rsub; p < p_end; p += rpi) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(base + (long long)p * C);
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float f = v[e] * sc[e] + sh[e];
+            if (silu) f = f / (1.0f + expf(-f));                 // exact expf: this path trades speed for fp32 fidelity
+            o[e] = f;
+        }
+        split_store4(ob + (long long)p * 3 * C, C, ch, o);
+    }
+}
+
+// x fp32 [rows, C] * scale -> split3 fp16 [rows, 3C]  (raw residual-stream tensors that feed a conv without a GroupNorm in
+// between - Upsample2D / Downsample2D / conv_shortcut inputs, the packed latent / image: scaled by a power of two so that
+// the fp16 range is never exceeded; the consumer multiplies by 1 / scale in its epilogue, which is exact)
+__global__ __launch_bounds__(256) void split_cast_kernel(const float* __restrict__ x, long long rows, int C, float scale,
+                                                          half_t* __restrict__ out) {
+    const int nchunk = C >> 2;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= rows * nchunk) return;
+    const long long r = idx / nchunk;
+    const int c = (int)(idx - r * nchunk) * 4;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + r * C + c);
+    const float o[4] = {v[0] * scale, v[1] * scale, v[2] * scale, v[3] * scale};
+    split_store4(out + r * 3 * C, C, c, o);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // LayerNorm: one wave per token row, row kept in registers (C <= 2048), exact two-pass mean / variance.
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void layernorm_kernel(const half_t* __restrict__ x, long long rows, int C,
@@ -556,6 +668,54 @@ extern "C" int icd_layernorm(const void* x, int64_t rows, int32_t C, const float
         hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, xh, (long long)rows, C, gamma,
                            beta, eps, oh);
     ICD_CHECK_LAUNCH("icd_layernorm");
+    return ICD_OK;
+}
+
+extern "C" int icd_groupnorm_f32_split(const float* x, int32_t C, int32_t B, int32_t HW, int32_t groups, const float* gamma,
+                                       const float* beta, float eps, int32_t silu, void* out_split3, float* stats_ws, void* stream) {
+    ICD_CHECK_ARG(x && out_split3 && stats_ws && gamma && beta, "icd_groupnorm_f32_split: null pointer");
+    ICD_CHECK_ARG(C > 0 && C % 4 == 0 && C / 4 <= GN_THREADS, "icd_groupnorm_f32_split: C must be a multiple of 4, <= %d", 4 * GN_THREADS);
+    ICD_CHECK_ARG(groups > 0 && groups <= 32 && C % groups == 0 && B > 0 && HW > 0, "icd_groupnorm_f32_split: bad shape");
+    hipStream_t st = (hipStream_t)stream;
+    const int pps = gn_pix_per_split(B, HW);
+    const int nsplit = (HW + pps - 1) / pps;
+    const int rpi = GN_THREADS / (C / 4);
+    const size_t smem = (size_t)rpi * C * 2 * sizeof(float);
+    ICD_CHECK_ARG(smem <= 64 * 1024, "icd_groupnorm_f32_split: LDS budget exceeded");
+    hipLaunchKernelGGL(gn_stats_f32_kernel, dim3(nsplit, B), dim3(GN_THREADS), smem, st, x, C, HW, groups, pps, stats_ws);
+    ICD_CHECK_LAUNCH("icd_groupnorm_f32_split(stats)");
+    const int ppb = 64;
+    hipLaunchKernelGGL(gn_apply_split_kernel, dim3((HW + ppb - 1) / ppb, B), dim3(GN_THREADS), 0, st, x, C, HW, groups, nsplit, ppb,
+                       stats_ws, gamma, beta, eps, silu, (half_t*)out_split3);
+    ICD_CHECK_LAUNCH("icd_groupnorm_f32_split(apply)");
+    return ICD_OK;
+}
+
+// max |x| over n fp32 values -> *out (device, fp32; the caller zeroes it): non-negative floats order like their bit patterns,
+// so a device-wide atomicMax on the bits is exact and order independent
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long long n, unsigned* __restrict__ out) {
+    float m = 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+}
+
+extern "C" int icd_absmax(const float* x, int64_t n, float* out, void* stream) {
+    ICD_CHECK_ARG(x && out && n > 0, "icd_absmax: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(out, 0, sizeof(float), st) != hipSuccess) { icd_set_error("icd_absmax: hipMemsetAsync failed"); return ICD_ERR_HIP; }
+    const long long blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, st, x, (long long)n, (unsigned*)out);
+    ICD_CHECK_LAUNCH("icd_absmax");
+    return ICD_OK;
+}
+
+extern "C" int icd_split_cast(const float* x, int64_t rows, int32_t C, float scale, void* out_split3, void* stream) {
+    ICD_CHECK_ARG(x && out_split3 && rows > 0 && C > 0 && C % 4 == 0, "icd_split_cast: bad arguments (C must be a multiple of 4)");
+    const long long n = (long long)rows * (C / 4);
+    hipLaunchKernelGGL(split_cast_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, (long long)rows, C, scale,
+                       (half_t*)out_split3);
+    ICD_CHECK_LAUNCH("icd_split_cast");
     return ICD_OK;
 }
 

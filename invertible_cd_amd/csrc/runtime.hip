@@ -45,6 +45,8 @@ struct ProfScope {
     ~ProfScope() { if (on) (void)hipEventRecord(g_prof[idx].b, st); }
 };
 
+bool g_no_xattn_fusion = false;         // icd_debug_no_xattn_fusion: A/B switch (query projection and cross-attention as two launches)
+
 struct Arena {
     char* base = nullptr;
     long long cap = 0, peak = 0;
@@ -240,21 +242,32 @@ struct Exec {
         return Act{out, Cout};
     }
 
+    // Phase 0 of the plugin protocol for the next Attention module (module-execution order): does the controller want its
+    // probabilities?  Asked BEFORE the query projection is enqueued, because a cross-attention layer that is not
+    // materialised runs as the epilogue of that projection (icd_gemm xattn_*).
+    struct AttnPlan { int layer; bool mat; void* probs; };
+    AttnPlan attn_query(bool is_cross, int place, int heads, int Nq, int Nk) {
+        AttnPlan a{layer++, false, nullptr};
+        const long long ldp = (Nk + 7) / 8 * 8;
+        if (dry) a.mat = probs_mode == 2 || (probs_mode == 1 && (is_cross || Nq <= 1024));
+        else if (io->hook && ok()) {
+            const int r = io->hook(io->hook_user, ICD_HOOK_QUERY, a.layer, is_cross, place, (long long)B * heads, Nq, Nk, ldp, &a.probs);
+            if (r < 0) { icd_set_error("attention hook (query) failed at layer %d", a.layer); status = ICD_ERR_HOOK; return a; }
+            a.mat = r == 1;
+            if (a.mat && !a.probs) { icd_set_error("attention hook returned 1 without a probability buffer (layer %d)", a.layer); status = ICD_ERR_HOOK; }
+        }
+        return a;
+    }
+
     // one attention module: q [B*Nq, ldq] (head h at col h*d), k [B*Nk, ldk], vt [B, C, ldv]; out [B*Nq, C]
-    void attention(bool is_cross, int place, const half_t* q, int ldq, const half_t* k, int ldk, const half_t* vt, int ldv,
-                   long long vt_bs, int heads, int Nq, int Nk, int d, half_t* out, int C) {
-        const int my_layer = layer++;
+    void attention(const AttnPlan& plan, bool is_cross, int place, const half_t* q, int ldq, const half_t* k, int ldk, const half_t* vt,
+                   int ldv, long long vt_bs, int heads, int Nq, int Nk, int d, half_t* out, int C) {
+        const int my_layer = plan.layer;
         const long long ldp = (Nk + 7) / 8 * 8;
         const float scale = 1.0f / sqrtf((float)d);
-        bool mat = false;
-        void* probs = nullptr;
-        if (dry) mat = probs_mode == 2 || (probs_mode == 1 && (is_cross || Nq <= 1024));
-        else if (io->hook && ok()) {
-            const int r = io->hook(io->hook_user, ICD_HOOK_QUERY, my_layer, is_cross, place, (long long)B * heads, Nq, Nk, ldp, &probs);
-            if (r < 0) { icd_set_error("attention hook (query) failed at layer %d", my_layer); status = ICD_ERR_HOOK; return; }
-            mat = r == 1;
-            if (mat && !probs) { icd_set_error("attention hook returned 1 without a probability buffer (layer %d)", my_layer); status = ICD_ERR_HOOK; return; }
-        }
+        const bool mat = plan.mat;
+        void* probs = plan.probs;
+        if (!ok()) return;
         if (!mat) {
             if (ok() && !dry) {
                 ProfScope ps(true, st, ICD_PROF_ATTN_FUSED, 4.0 * B * heads * (double)Nq * Nk * d, 0.0, Nq, Nk, d, heads);
@@ -262,27 +275,13 @@ struct Exec {
             }
             return;
         }
-        // materialised path (utils/p2p.py:335-338): S = scale q.k^T (fp32) -> softmax -> P (fp16) -> hook -> P.V
-        const long long per_b = (long long)heads * Nq * ldp;            // fp32 elements of S per sample
-        int nb = (int)std::max<long long>(1, (1LL << 28) / per_b);      // <= 1 GiB of fp32 scores at a time
-        nb = std::min(nb, B);
-        float* S = alloc<float>(per_b * nb);
-        for (int b0 = 0; b0 < B && ok(); b0 += nb) {
-            const int cb = std::min(nb, B - b0);
-            icd_gemm_desc g; memset(&g, 0, sizeof(g));
-            g.a0 = q + (long long)b0 * Nq * ldq; g.w = k + (long long)b0 * Nk * ldk; g.out = S;
-            g.M = Nq; g.N = (int)ldp; g.K = d; g.Nw = Nk; g.lda = ldq; g.ldw = ldk; g.ldo = (int)ldp;
-            g.mode = 0; g.batch = cb * heads; g.zdiv = heads;
-            g.a_bs0 = (long long)Nq * ldq; g.a_bs1 = d; g.w_bs0 = (long long)Nk * ldk; g.w_bs1 = d;
-            g.o_bs0 = per_b; g.o_bs1 = (long long)Nq * ldp;
-            g.alpha = scale; g.flags = ICD_GEMM_OUT_F32;
-            gemm_desc(g);
-            if (ok() && !dry) {
-                ProfScope ps(true, st, ICD_PROF_SOFTMAX, 0.0, (double)cb * heads * Nq * ldp * 14.0);
-                run(icd_softmax_rows(S, (long long)cb * heads * Nq, Nk, (int)ldp, 1.0f, (half_t*)probs + (long long)b0 * per_b, (int)ldp, st));
-            }
+        // materialised path (utils/p2p.py:335-338): P = softmax(scale q.k^T) as fp16 in ONE pass (icd_attention_probs: no
+        // fp32 score tensor) -> hook (the controller edits / keeps P) -> P.V
+        const long long per_b = (long long)heads * Nq * ldp;            // elements of P per sample
+        if (!dry && ok()) {
+            ProfScope ps(true, st, ICD_PROF_SOFTMAX, 2.0 * B * heads * (double)Nq * Nk * d, (double)B * per_b * 2.0);
+            run(icd_attention_probs(q, k, probs, B, heads, Nq, Nk, d, ldq, ldk, (int)ldp, scale, st));
         }
-        release(S);
         if (!dry && ok()) {
             const int r = io->hook(io->hook_user, ICD_HOOK_PROBS, my_layer, is_cross, place, (long long)B * heads, Nq, Nk, ldp, &probs);
             if (r < 0) { icd_set_error("attention hook (probs) failed at layer %d", my_layer); status = ICD_ERR_HOOK; return; }
@@ -320,19 +319,40 @@ struct Exec {
             linear(h, C, (int)M, C, Wh(b + ".attn1.to_v.weight", (long long)C * C), C, nullptr, nullptr, 0, vt, ldv_self,
                    ICD_GEMM_OUT_TRANS, HW, lnst, Wf(b + ".attn1.to_v.lnsum", C));      // (W_v beta) rides in to_out's bias
             half_t* ao = alloc<half_t>(M * C);
-            attention(false, place, qk, 2 * C, qk + C, 2 * C, vt, ldv_self, (long long)C * ldv_self, heads, HW, HW, d, ao, C);
+            const AttnPlan self_plan = attn_query(false, place, heads, HW, HW);
+            attention(self_plan, false, place, qk, 2 * C, qk + C, 2 * C, vt, ldv_self, (long long)C * ldv_self, heads, HW, HW, d, ao, C);
             release(qk); release(vt);
             linear(ao, C, (int)M, C, Wh(b + ".attn1.to_out.0.weight", (long long)C * C), C, Wf(b + ".attn1.to_out.0.bias", C), h, C, h, C);
             // ---- cross attention ----
             ln_stats(h, M, C, lnst);
-            half_t* q2 = alloc<half_t>(M * C);
-            linear(h, C, (int)M, C, Wh(b + ".attn2.to_q.weight", (long long)C * C), C, Wf(b + ".attn2.to_q.lnbias", C), nullptr, 0, q2, C,
-                   0, 0, lnst, Wf(b + ".attn2.to_q.lnsum", C));
             // K and V^T of this layer are column / row slices of the per-forward batched projections
-            attention(true, place, q2, C, k_all + kv_off, u->kv_total, vt_all + (long long)kv_off * ldv_cross, ldv_cross,
-                      (long long)u->kv_total * ldv_cross, heads, HW, nctx, d, ao, C);
+            const half_t* kx = k_all + kv_off;
+            const half_t* vx = vt_all + (long long)kv_off * ldv_cross;
+            const long long vx_bs = (long long)u->kv_total * ldv_cross;
+            const AttnPlan cross_plan = attn_query(true, place, heads, HW, nctx);
+            const half_t* wq = Wh(b + ".attn2.to_q.weight", (long long)C * C);
+            const float* bq = Wf(b + ".attn2.to_q.lnbias", C);
+            const float* sq = Wf(b + ".attn2.to_q.lnsum", C);
+            if (!cross_plan.mat && d == 64 && C % 128 == 0 && HW % 256 == 0 && nctx <= 96 && !g_no_xattn_fusion) {
+                // the north-star kernel: LN2 -> to_q -> softmax(q K^T / 8) V in ONE launch, q stays in the accumulators
+                if (ok() && !dry) {
+                    icd_gemm_desc g; memset(&g, 0, sizeof(g));
+                    g.a0 = h; g.w = wq; g.bias = bq; g.out = ao;
+                    g.M = (int)M; g.N = C; g.K = C; g.Nw = C; g.lda = C; g.ldw = C; g.ldo = C;
+                    g.rows_per_sample = HW; g.mode = 0; g.batch = 1; g.zdiv = 1; g.alpha = 1.f;
+                    g.ln_stats = lnst; g.ln_colsum = sq;
+                    g.xattn_k = kx; g.xattn_vt = vx; g.xattn_nk = nctx; g.xattn_ldk = u->kv_total; g.xattn_ldvt = ldv_cross;
+                    g.xattn_vt_bs = vx_bs; g.xattn_scale = 1.0f / sqrtf((float)d);
+                    ProfScope ps(true, st, ICD_PROF_XATTN, 2.0 * M * (double)C * C + 4.0 * M * (double)nctx * C, 0.0, (int)M, C, C, heads);
+                    run(icd_gemm(&g, st));
+                }
+            } else {
+                half_t* q2 = alloc<half_t>(M * C);
+                linear(h, C, (int)M, C, wq, C, bq, nullptr, 0, q2, C, 0, 0, lnst, sq);
+                attention(cross_plan, true, place, q2, C, kx, u->kv_total, vx, ldv_cross, vx_bs, heads, HW, nctx, d, ao, C);
+                release(q2);
+            }
             kv_off += C;
-            release(q2);
             linear(ao, C, (int)M, C, Wh(b + ".attn2.to_out.0.weight", (long long)C * C), C, Wf(b + ".attn2.to_out.0.bias", C), h, C, h, C);
             release(ao);
             // ---- GEGLU feed-forward ----
@@ -526,6 +546,8 @@ int temb_total(const icd_unet_config& c) {
 }
 
 }  // namespace
+
+extern "C" int icd_debug_no_xattn_fusion(int32_t off) { g_no_xattn_fusion = off != 0; return ICD_OK; }
 
 extern "C" int icd_profile_enable(int32_t enable) {
     for (auto& r : g_prof) { g_ev_pool.push_back(r.a); g_ev_pool.push_back(r.b); }

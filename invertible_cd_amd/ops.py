@@ -8,7 +8,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import GemmDesc, ICD_GEMM_GEGLU, ICD_GEMM_OUT_F32, ICD_GEMM_OUT_TRANS, ICD_GEMM_PAD_HI
+from ._lib import GemmDesc, ICD_GEMM_GEGLU, ICD_GEMM_OUT_F32, ICD_GEMM_OUT_TRANS, ICD_GEMM_PAD_HI, ICD_GEMM_RESID_F32
 
 
 def _stream():
@@ -81,6 +81,8 @@ def gemm(a, w, bias=None, resid=None, rowbias=None, rows_per_sample=0, geglu=Fal
     d.rows_per_sample = rows_per_sample
     d.mode, d.batch, d.zdiv, d.alpha = 0, 1, 1, alpha
     d.flags = (ICD_GEMM_GEGLU if geglu else 0) | (ICD_GEMM_OUT_F32 if out_f32 else 0) | debug_flags
+    if resid is not None and resid.dtype == torch.float32:
+        d.flags |= ICD_GEMM_RESID_F32
     if ln_stats is not None:
         assert ln_stats.dtype == torch.float32 and ln_stats.is_contiguous() and tuple(ln_stats.shape) == (M, 2)
         assert ln_colsum.dtype == torch.float32 and ln_colsum.is_contiguous() and ln_colsum.numel() == N
@@ -91,16 +93,17 @@ def gemm(a, w, bias=None, resid=None, rowbias=None, rows_per_sample=0, geglu=Fal
 
 
 def conv3x3(x, B, H, W, w_packed, bias=None, x2=None, stride=1, upsample=False, resid=None, rowbias=None, ksize=3,
-            debug_flags=0, pad_hi=False):
+            debug_flags=0, pad_hi=False, out_f32=False, alpha=1.0):
     """Implicit-GEMM conv over NHWC x [B*H*W, C0] (optionally cat with x2 [.., C1]); returns [B*Ho*Wo, Cout].
-    pad_hi: zero padding on the bottom/right edge only (AutoencoderKL Downsample2D)."""
+    pad_hi: zero padding on the bottom/right edge only (AutoencoderKL Downsample2D).  out_f32 / an fp32 `resid` / alpha: the
+    fp32-fidelity VAE path (fp32 conv outputs and residual stream, power-of-two input scaling undone by alpha)."""
     _chk16(x, "x"); _chk16(w_packed, "w")
     C0 = x.shape[-1]
     C1 = x2.shape[-1] if x2 is not None else 0
     Hu, Wu = (H * 2, W * 2) if upsample else (H, W)
     Ho, Wo = (Hu + stride - 1) // stride, (Wu + stride - 1) // stride
     N = w_packed.shape[0]
-    out = torch.empty((B * Ho * Wo, N), device=x.device, dtype=torch.float16)
+    out = torch.empty((B * Ho * Wo, N), device=x.device, dtype=torch.float32 if out_f32 else torch.float16)
     d = GemmDesc()
     d.a0, d.a1, d.w, d.out = x.data_ptr(), (x2.data_ptr() if x2 is not None else None), w_packed.data_ptr(), out.data_ptr()
     d.bias = bias.data_ptr() if bias is not None else None
@@ -113,7 +116,9 @@ def conv3x3(x, B, H, W, w_packed, bias=None, x2=None, stride=1, upsample=False, 
     d.rows_per_sample = Ho * Wo
     d.mode, d.C0, d.C1 = 1, C0, C1
     d.Hin, d.Win, d.Hout, d.Wout, d.ksize, d.stride, d.upsample = H, W, Ho, Wo, ksize, stride, int(upsample)
-    d.batch, d.zdiv, d.alpha, d.flags = 1, 1, 1.0, debug_flags | (ICD_GEMM_PAD_HI if pad_hi else 0)
+    d.batch, d.zdiv, d.alpha, d.flags = 1, 1, alpha, debug_flags | (ICD_GEMM_PAD_HI if pad_hi else 0) | (ICD_GEMM_OUT_F32 if out_f32 else 0)
+    if resid is not None and resid.dtype == torch.float32:
+        d.flags |= ICD_GEMM_RESID_F32
     ws = _splitk_ws(d, x.device)
     _lib.check(_lib.load().icd_gemm(C.byref(d), _stream()), "icd_gemm(conv)")
     return out
@@ -129,6 +134,54 @@ def groupnorm(x, B, HW, gamma, beta, eps, silu, x2=None, groups=32):
     _lib.check(lib.icd_groupnorm(_p(x), C0, _p(x2), C1, B, HW, groups, _p(gamma), _p(beta), eps, int(silu), _p(out),
                                  _p(ws), _stream()), "icd_groupnorm")
     return out
+
+
+def groupnorm_f32_split(x32, B, HW, gamma, beta, eps, silu, groups=32):
+    """GroupNorm (+SiLU) of an fp32 [B*HW, C] tensor -> split3 fp16 [B*HW, 3C] = [hi | lo | hi] (fp32-fidelity VAE path)."""
+    assert x32.is_cuda and x32.dtype == torch.float32 and x32.is_contiguous()
+    Cc = x32.shape[-1]
+    lib = _lib.load()
+    ws = torch.empty((lib.icd_groupnorm_ws_floats(B, HW, groups),), device=x32.device, dtype=torch.float32)
+    out = torch.empty((B * HW, 3 * Cc), device=x32.device, dtype=torch.float16)
+    _lib.check(lib.icd_groupnorm_f32_split(_p(x32), Cc, B, HW, groups, _p(gamma), _p(beta), eps, int(silu), _p(out), _p(ws), _stream()),
+               "icd_groupnorm_f32_split")
+    return out
+
+
+def split_cast(x32, scale=1.0):
+    """fp32 [rows, C] * scale -> split3 fp16 [rows, 3C] = [hi | lo | hi]."""
+    assert x32.is_cuda and x32.dtype == torch.float32 and x32.is_contiguous() and x32.dim() == 2
+    rows, Cc = x32.shape
+    out = torch.empty((rows, 3 * Cc), device=x32.device, dtype=torch.float16)
+    _lib.check(_lib.load().icd_split_cast(_p(x32), rows, Cc, scale, _p(out), _stream()), "icd_split_cast")
+    return out
+
+
+def absmax(x32):
+    """max |x| of an fp32 tensor as a Python float (one small kernel + a host sync: only the fp32-fidelity VAE path uses it)."""
+    assert x32.is_cuda and x32.dtype == torch.float32 and x32.is_contiguous()
+    out = torch.empty((1,), device=x32.device, dtype=torch.float32)
+    _lib.check(_lib.load().icd_absmax(_p(x32), x32.numel(), _p(out), _stream()), "icd_absmax")
+    return float(out.item())
+
+
+def split_cast_guarded(x32, headroom=8192.0):
+    """split3 of a raw (un-normalised) fp32 tensor with a power-of-two scale chosen so that max |x| * scale <= headroom (well
+    inside the fp16 range, and never below 1 for tensors that are already small): returns (split3 tensor, 1 / scale)."""
+    import math
+    m = absmax(x32)
+    if not math.isfinite(m):
+        raise FloatingPointError("non-finite activation in the fp32-fidelity path")
+    scale = 1.0 if m <= headroom else 2.0 ** -math.ceil(math.log2(m / headroom))
+    return split_cast(x32, scale), 1.0 / scale
+
+
+def split_weight(w2d):
+    """fp32 [N, K] (or packed conv [N, taps*Cin] viewed as [N, taps, Cin]) -> fp16 [.., 3*Cin] = [w_hi | w_hi | w_lo] per tap."""
+    w32 = w2d.float()
+    hi = w32.to(torch.float16)
+    lo = (w32 - hi.float()).to(torch.float16)
+    return torch.cat([hi, hi, lo], dim=-1).contiguous()
 
 
 def layernorm(x, gamma, beta, eps=1e-5):
@@ -182,6 +235,31 @@ def project_vt(x, w, B, n_tokens, ld_keys, ln_stats=None, ln_colsum=None):
     return out
 
 
+def query_cross_attention(a, w, k, vt, B, n_tokens, nk, scale, bias=None, ln_stats=None, ln_colsum=None):
+    """Query projection + cross-attention in ONE launch (icd_gemm_desc.xattn_*): q = a[M, K] @ w[C, K]^T (+ fused LayerNorm,
+    + bias), heads of 64 columns; out[m, h*64:(h+1)*64] = softmax(scale * q_h[m] . K_h^T) V_h.  k: [B*nk, ldk] rows (a column
+    slice of a wider matrix is fine), vt: [B, C, ldvt] (V transposed, pad keys zero).  Needs C % 128 == 0, n_tokens % 256 == 0,
+    nk <= 96."""
+    _chk16(a, "a"); _chk16(w, "w"); _chk_rows(k, "k")
+    assert vt.is_cuda and vt.dtype == torch.float16 and vt.dim() == 3 and vt.stride(2) == 1
+    M, K = a.shape
+    N = w.shape[0]
+    out = torch.empty((M, N), device=a.device, dtype=torch.float16)
+    d = GemmDesc()
+    d.a0, d.w, d.out = a.data_ptr(), w.data_ptr(), out.data_ptr()
+    d.bias = bias.data_ptr() if bias is not None else None
+    d.M, d.N, d.K, d.Nw = M, N, K, N
+    d.lda, d.ldw, d.ldo = a.stride(0), w.stride(0), out.stride(0)
+    d.rows_per_sample = n_tokens
+    d.mode, d.batch, d.zdiv, d.alpha, d.flags = 0, 1, 1, 1.0, 0
+    if ln_stats is not None:
+        d.ln_stats, d.ln_colsum = ln_stats.data_ptr(), ln_colsum.data_ptr()
+    d.xattn_k, d.xattn_vt = k.data_ptr(), vt.data_ptr()
+    d.xattn_nk, d.xattn_ldk, d.xattn_ldvt, d.xattn_vt_bs, d.xattn_scale = nk, k.stride(0), vt.stride(1), vt.stride(0), scale
+    _lib.check(_lib.load().icd_gemm(C.byref(d), _stream()), "icd_gemm(xattn)")
+    return out
+
+
 def attention_fused(q, k, vt, B, H, Nq, Nk, d, scale, causal=False):
     """q [B*Nq, H*d], k [B*Nk, H*d], vt [B, H*d, ld] -> out [B*Nq, H*d]; causal: keys after the query are masked."""
     _chk_rows(q, "q"); _chk_rows(k, "k"); _chk16(vt, "vt")
@@ -189,6 +267,17 @@ def attention_fused(q, k, vt, B, H, Nq, Nk, d, scale, causal=False):
     _lib.check(_lib.load().icd_attention_fused_ex(_p(q), _p(k), _p(vt), _p(out), B, H, Nq, Nk, d, q.stride(0), k.stride(0),
                                                   vt.stride(1), out.stride(0), vt.stride(0), scale, 1 if causal else 0, _stream()),
                "icd_attention_fused")
+    return out
+
+
+def attention_probs(q, k, B, H, Nq, Nk, d, scale, ld=None, out=None):
+    """P[b*H+h, n, :Nk] = softmax(scale * q.k) as fp16 [B*H, Nq, ld] in one pass (no fp32 score tensor); pad columns zero."""
+    _chk_rows(q, "q"); _chk_rows(k, "k")
+    ld = ld or (Nk + 7) // 8 * 8
+    if out is None:
+        out = torch.empty((B * H, Nq, ld), device=q.device, dtype=torch.float16)
+    _lib.check(_lib.load().icd_attention_probs(_p(q), _p(k), _p(out), B, H, Nq, Nk, d, q.stride(0), k.stride(0), ld, scale, _stream()),
+               "icd_attention_probs")
     return out
 
 

@@ -16,9 +16,18 @@ fused flash kernel when the head dim is <= 160), first / last convs through `icd
     so the 3x3 conv's zero padding still sees zeros outside the image;
   * quant_conv is folded into encoder.conv_out (mean rows and log-variance rows as two 4-channel output convs);
   * the V bias of the attention is folded into the output projection's bias (softmax rows sum to one).
-Activations are fp16 token-major [B*H*W, C] with fp32 accumulation, like the UNet.  The reference upcasts the SDXL VAE to
-fp32 (utils/generation_sdxl.py:465) because real SDXL-VAE activations overflow fp16; this module keeps fp16 storage, so
-with a real SDXL VAE checkpoint that caveat applies (noted in DESIGN.md section 9).
+Two arithmetic modes, selected like the reference does it, through `vae.to(dtype)`:
+  * fp16 (default, `AutoencoderKL(..., dtype=torch.float16)` / `.to(torch.float16)`): activations are fp16 token-major
+    [B*H*W, C] with fp32 accumulation, like the UNet.
+  * fp32 fidelity (`.to(torch.float32)` - what utils/generation_sdxl.py:465-466 and diffusers' force_upcast ask for,
+    because real SDXL-VAE activations overflow the fp16 range): every tensor that can grow without bound (conv outputs, the
+    residual stream) is stored in fp32; the operands of the matrix cores are "split3" fp16 tensors [hi | lo | hi] against
+    weights packed [w_hi | w_hi | w_lo] (ops.split_weight), i.e. (a_hi + a_lo)(w_hi + w_lo) minus the lo*lo term, ~2^-21
+    relative operand error on the unchanged fp16 MFMA kernels at 3x their work; GroupNorm reads fp32 and writes split3
+    (icd_groupnorm_f32_split); tensors that reach a conv without a GroupNorm (Up/Downsample, conv_shortcut) are scaled by a
+    power of two chosen from their max |x| (icd_absmax) on the way to fp16 and the conv's alpha restores the scale exactly
+    (icd_split_cast).  Only the
+    mid-block attention keeps fp16 q / k / v / P (bounded by construction: they follow a GroupNorm and a softmax).
 """
 from dataclasses import dataclass, replace
 from types import SimpleNamespace
@@ -223,6 +232,8 @@ class AutoencoderKL:
                                       block_out_channels=list(cfg.block_out_channels), in_channels=cfg.in_channels,
                                       out_channels=cfg.out_channels)
         self.w = pack_vae_state_dict(cfg, state_dict, device)
+        self._sd_ref = {k: state_dict[k] for k in cfg.state_dict_shapes()}     # masters of the fp32-fidelity weights (converted lazily)
+        self._ws = None                        # split3 weights of the fp32-fidelity path, packed on first use
         self.max_chunk = max_chunk            # samples per pass (bounds the 512x512x128-channel activations and the scores)
         self.fused_attention = fused_attention    # None: fused flash kernel when the head dim allows it (<= 160)
 
@@ -230,8 +241,155 @@ class AutoencoderKL:
     def to(self, *args, **kw):
         for a in list(args) + [kw.get("dtype")]:
             if isinstance(a, torch.dtype):
-                self.dtype = a                 # output dtype; arithmetic stays fp16 storage / fp32 accumulate
+                self.dtype = a                 # float32 selects the fp32-fidelity arithmetic (module docstring), not just the I/O dtype
         return self
+
+    # ------------------------------------------------------------------ fp32-fidelity path (dtype == torch.float32)
+    def _split_weights(self):
+        """[w_hi | w_hi | w_lo] per tap for every conv / projection whose input is a split3 tensor, from the fp32 masters."""
+        if self._ws is not None:
+            return self._ws
+        sd = {k: v.detach().to("cpu", torch.float32) for k, v in self._sd_ref.items()}
+        dev, cfg = self.device, self.cfg
+        S = {}
+
+        def conv(key, w=None, cin_pad=None):
+            w = sd[key] if w is None else w                                   # [O, I, kh, kw]
+            if cin_pad:
+                wp = torch.zeros(w.shape[0], cin_pad, *w.shape[2:]); wp[:, :w.shape[1]] = w; w = wp
+            o = w.shape[0]
+            S[key] = ops.split_weight(w.permute(0, 2, 3, 1)).reshape(o, -1).to(dev)          # [O, taps * 3I]
+
+        def dense(key, w):
+            S[key] = ops.split_weight(w.reshape(w.shape[0], -1)).to(dev)
+
+        def resnet(p):
+            conv(p + "conv1.weight"); conv(p + "conv2.weight")
+            if p + "conv_shortcut.weight" in sd:
+                conv(p + "conv_shortcut.weight")
+
+        def mid(p):
+            resnet(p + "resnets.0."); resnet(p + "resnets.1.")
+            a = p + "attentions.0."
+            dense(a + "to_qk.weight", torch.cat([sd[a + "to_q.weight"], sd[a + "to_k.weight"]]))
+            dense(a + "to_v.weight", sd[a + "to_v.weight"])
+
+        ch, L, zc = list(cfg.block_out_channels), cfg.layers_per_block, cfg.latent_channels
+        conv("encoder.conv_in.weight", cin_pad=8)
+        for i in range(len(ch)):
+            for j in range(L):
+                resnet(f"encoder.down_blocks.{i}.resnets.{j}.")
+            if i < len(ch) - 1:
+                conv(f"encoder.down_blocks.{i}.downsamplers.0.conv.weight")
+        mid("encoder.mid_block.")
+        wq, wo = sd["quant_conv.weight"].reshape(2 * zc, 2 * zc), sd["encoder.conv_out.weight"]
+        for name, rows in (("mean", wq[:zc]), ("logvar", wq[zc:])):
+            w4 = torch.zeros(4, wo.shape[1], 3, 3); w4[:zc] = torch.einsum("om,mchw->ochw", rows, wo)
+            conv(f"encoder.conv_out_{name}.weight", w=w4)
+        wpq, bpq, wi = sd["post_quant_conv.weight"].reshape(zc, zc), sd["post_quant_conv.bias"], sd["decoder.conv_in.weight"]
+        w8 = torch.zeros(wi.shape[0], 8, 3, 3)
+        w8[:, :zc] = torch.einsum("ochw,cd->odhw", wi, wpq)
+        w8[:, zc] = torch.einsum("ochw,c->ohw", wi, bpq)
+        conv("decoder.conv_in.weight", w=w8)
+        mid("decoder.mid_block.")
+        for i in range(len(ch)):
+            for j in range(L + 1):
+                resnet(f"decoder.up_blocks.{i}.resnets.{j}.")
+            if i < len(ch) - 1:
+                conv(f"decoder.up_blocks.{i}.upsamplers.0.conv.weight")
+        wo = sd["decoder.conv_out.weight"]
+        w4 = torch.zeros(4, wo.shape[1], 3, 3); w4[:cfg.out_channels] = wo
+        conv("decoder.conv_out.weight", w=w4)
+        self._ws = S
+        return S
+
+    def _pack32(self, x_nchw, ones_channel=-1):
+        """NCHW fp32 (<= 8 channels) -> split3 [B*H*W, 24] of the 8-channel token-major packing (data movement + split only)."""
+        B, Cc, H, W = x_nchw.shape
+        t = torch.zeros((B, H, W, 8), device=self.device, dtype=torch.float32)
+        t[..., :Cc] = x_nchw.to(self.device, torch.float32).permute(0, 2, 3, 1)
+        if ones_channel >= 0:
+            t[..., ones_channel] = 1.0
+        return ops.split_cast(t.reshape(B * H * W, 8), 1.0)
+
+    def _resnet32(self, p, x, B, H, W):
+        w, ws, g = self.w, self._ws, self.cfg.norm_num_groups
+        h = ops.groupnorm_f32_split(x, B, H * W, w[p + "norm1.weight"], w[p + "norm1.bias"], EPS, True, groups=g)
+        h = ops.conv3x3(h, B, H, W, ws[p + "conv1.weight"], w[p + "conv1.bias"], out_f32=True)
+        h = ops.groupnorm_f32_split(h, B, H * W, w[p + "norm2.weight"], w[p + "norm2.bias"], EPS, True, groups=g)
+        sc = x
+        if p + "conv_shortcut.weight" in ws:
+            xs, inv = ops.split_cast_guarded(x)
+            sc = ops.gemm(xs, ws[p + "conv_shortcut.weight"], w[p + "conv_shortcut.bias"], out_f32=True, alpha=inv)
+        return ops.conv3x3(h, B, H, W, ws[p + "conv2.weight"], w[p + "conv2.bias"], resid=sc, out_f32=True)
+
+    def _attention32(self, p, x, B, H, W):
+        w, ws, g = self.w, self._ws, self.cfg.norm_num_groups
+        C, N = x.shape[1], H * W
+        h = ops.groupnorm_f32_split(x, B, N, w[p + "group_norm.weight"], w[p + "group_norm.bias"], EPS, False, groups=g)
+        qk = ops.gemm(h, ws[p + "to_qk.weight"], w[p + "to_qk.bias"])                  # fp16: bounded (GroupNorm output x weights)
+        q, k = qk[:, :C], qk[:, C:]
+        ld = (N + 7) // 8 * 8
+        vt = ops.project_vt(h, ws[p + "to_v.weight"], B, N, ld)
+        scale = C ** -0.5
+        fused = self.fused_attention if self.fused_attention is not None else C <= 160
+        if fused:
+            o = ops.attention_fused(q, k, vt, B, 1, N, N, C, scale)
+        else:
+            o = torch.empty((B * N, C), device=x.device, dtype=torch.float16)
+            step = max(1, min(B, (1 << 30) // (N * ld * 4)))
+            for b0 in range(0, B, step):
+                bc = min(step, B - b0)
+                s_ = ops.attention_scores(q[b0 * N:(b0 + bc) * N], k[b0 * N:(b0 + bc) * N], bc, 1, N, N, C, scale, ld)
+                pr = ops.softmax_rows(s_.reshape(bc * N, ld), N, ld).reshape(bc, N, ld)
+                ops.attention_apply(pr, vt[b0:b0 + bc], bc, 1, N, C, out=o[b0 * N:(b0 + bc) * N])
+        return ops.gemm(o, w[p + "to_out.weight"], w[p + "to_out.bias"], resid=x, out_f32=True)
+
+    def _mid32(self, p, x, B, H, W):
+        x = self._resnet32(p + "resnets.0.", x, B, H, W)
+        x = self._attention32(p + "attentions.0.", x, B, H, W)
+        return self._resnet32(p + "resnets.1.", x, B, H, W)
+
+    def _decode_chunk32(self, z):
+        w, ws, cfg = self.w, self._split_weights(), self.cfg
+        B, _, H, W = z.shape
+        x = ops.conv3x3(self._pack32(z, ones_channel=cfg.latent_channels), B, H, W, ws["decoder.conv_in.weight"],
+                        w["decoder.conv_in.bias"], out_f32=True)
+        x = self._mid32("decoder.mid_block.", x, B, H, W)
+        nb = len(cfg.block_out_channels)
+        for i in range(nb):
+            for j in range(cfg.layers_per_block + 1):
+                x = self._resnet32(f"decoder.up_blocks.{i}.resnets.{j}.", x, B, H, W)
+            if i < nb - 1:
+                k = f"decoder.up_blocks.{i}.upsamplers.0.conv."
+                xs, inv = ops.split_cast_guarded(x)
+                x = ops.conv3x3(xs, B, H, W, ws[k + "weight"], w[k + "bias"], upsample=True, out_f32=True, alpha=inv)
+                H, W = 2 * H, 2 * W
+        h = ops.groupnorm_f32_split(x, B, H * W, w["decoder.conv_norm_out.weight"], w["decoder.conv_norm_out.bias"], EPS, True,
+                                    groups=cfg.norm_num_groups)
+        return ops.conv_out(h, B, H, W, ws["decoder.conv_out.weight"], w["decoder.conv_out.bias"], out_dtype=torch.float32,
+                            cout=cfg.out_channels)
+
+    def _encode_chunk32(self, img):
+        w, ws, cfg = self.w, self._split_weights(), self.cfg
+        B, _, H, W = img.shape
+        x = ops.conv3x3(self._pack32(img), B, H, W, ws["encoder.conv_in.weight"], w["encoder.conv_in.bias"], out_f32=True)
+        nb = len(cfg.block_out_channels)
+        for i in range(nb):
+            for j in range(cfg.layers_per_block):
+                x = self._resnet32(f"encoder.down_blocks.{i}.resnets.{j}.", x, B, H, W)
+            if i < nb - 1:
+                k = f"encoder.down_blocks.{i}.downsamplers.0.conv."
+                xs, inv = ops.split_cast_guarded(x)
+                x = ops.conv3x3(xs, B, H, W, ws[k + "weight"], w[k + "bias"], stride=2, pad_hi=True, out_f32=True, alpha=inv)
+                H, W = H // 2, W // 2
+        x = self._mid32("encoder.mid_block.", x, B, H, W)
+        h = ops.groupnorm_f32_split(x, B, H * W, w["encoder.conv_norm_out.weight"], w["encoder.conv_norm_out.bias"], EPS, True,
+                                    groups=cfg.norm_num_groups)
+        mean = ops.conv_out(h, B, H, W, ws["encoder.conv_out_mean.weight"], w["encoder.conv_out_mean.bias"], out_dtype=torch.float32, cout=4)
+        logvar = ops.conv_out(h, B, H, W, ws["encoder.conv_out_logvar.weight"], w["encoder.conv_out_logvar.bias"], out_dtype=torch.float32,
+                              cout=4)
+        return mean, logvar
 
     def eval(self):
         return self
@@ -283,7 +441,8 @@ class AutoencoderKL:
         z = z.to(self.device)
         if z.dtype not in (torch.float16, torch.float32):
             z = z.float()
-        outs = [self._decode_chunk(z[i:i + self.max_chunk].contiguous()) for i in range(0, z.shape[0], self.max_chunk)]
+        chunk = self._decode_chunk32 if self.dtype == torch.float32 else self._decode_chunk
+        outs = [chunk(z[i:i + self.max_chunk].contiguous()) for i in range(0, z.shape[0], self.max_chunk)]
         img = (outs[0] if len(outs) == 1 else torch.cat(outs)).to(self.dtype)
         return _Out(sample=img) if return_dict else (img,)
 
@@ -314,7 +473,8 @@ class AutoencoderKL:
         x = x.to(self.device)
         if x.dtype not in (torch.float16, torch.float32):
             x = x.float()
-        outs = [self._encode_chunk(x[i:i + self.max_chunk].contiguous()) for i in range(0, x.shape[0], self.max_chunk)]
+        chunk = self._encode_chunk32 if self.dtype == torch.float32 else self._encode_chunk
+        outs = [chunk(x[i:i + self.max_chunk].contiguous()) for i in range(0, x.shape[0], self.max_chunk)]
         mean = torch.cat([o[0] for o in outs]).to(self.dtype)
         logvar = torch.cat([o[1] for o in outs]).to(self.dtype)
         dist = LatentDist(mean, logvar)

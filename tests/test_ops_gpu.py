@@ -421,3 +421,66 @@ def test_layernorm_fused_into_gemm(M, C, N, flags):
         vt = ops.project_vt(x.cuda(), w16v.cuda(), Bs, n_tok, n_tok, ln_stats=st, ln_colsum=sv.cuda())
         refv = (F.layer_norm(x.float(), (C,), gamma, None, 1e-5) @ w.float().t()).reshape(Bs, n_tok, N).transpose(1, 2)
         assert rel_l2(vt, refv) < TOL
+
+
+# ------------------------------------------------------------------------------ query projection + cross-attention, one launch
+@pytest.mark.parametrize("B,n_tok,C,X,nk,ln", [(2, 256, 128, 64, 77, False), (1, 1024, 1280, 128, 77, True), (3, 256, 256, 64, 13, True),
+                                               (2, 512, 640, 96, 96, False)])
+def test_query_projection_with_fused_cross_attention(B, n_tok, C, X, nk, ln):
+    """The north-star kernel: q = LN(h) W_q^T never leaves the accumulators; S^T = K q^T, softmax over <= 96 keys and
+    O^T = V^T P^T run in the GEMM's epilogue (heads of 64).  Reference: torch fp32, the op sequence of utils/p2p.py:321-342."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(123)
+    H = C // 64
+    h = (torch.randn(B * n_tok, C, generator=g) * 1.2 + torch.randn(B * n_tok, 1, generator=g)).half()
+    gamma, beta = 1 + 0.2 * torch.randn(C, generator=g), 0.3 * torch.randn(C, generator=g)
+    wq = r16(C, C, seed=124, scale=C ** -0.5 * 3.0)                  # peaky softmax
+    ctx = r16(B * nk, X, seed=125)
+    wk, wv = r16(C, X, seed=126, scale=X ** -0.5 * 2.0), r16(C, X, seed=127, scale=X ** -0.5)
+    scale = 64 ** -0.5
+    x = F.layer_norm(h.float(), (C,), gamma, beta, 1e-5) if ln else h.float()
+    q = (x @ wq.float().t()).reshape(B, n_tok, H, 64).permute(0, 2, 1, 3)
+    kk = (ctx.float() @ wk.float().t()).half().float().reshape(B, nk, H, 64).permute(0, 2, 1, 3)
+    vv = (ctx.float() @ wv.float().t()).half().float().reshape(B, nk, H, 64).permute(0, 2, 1, 3)
+    ref = (torch.softmax(q @ kk.transpose(-1, -2) * scale, -1) @ vv).permute(0, 2, 1, 3).reshape(B * n_tok, C)
+    k_dev = ops.gemm(ctx.cuda(), wk.cuda())                             # [B*nk, C]
+    ld = (nk + 7) // 8 * 8
+    vt_dev = ops.project_vt(ctx.cuda(), wv.cuda(), B, nk, ld)           # [B, C, ld], pad keys zero
+    if ln:
+        st = ops.layernorm_stats(h.cuda())
+        w16, s, t = ops.fold_layernorm(wq, gamma, beta)
+        out = ops.query_cross_attention(h.cuda(), w16.cuda(), k_dev, vt_dev, B, n_tok, nk, scale, bias=t.cuda(), ln_stats=st,
+                                        ln_colsum=s.cuda())
+    else:
+        out = ops.query_cross_attention(h.cuda(), wq.cuda(), k_dev, vt_dev, B, n_tok, nk, scale)
+    e = rel_l2(out, ref)
+    print(f"[xattn fused B={B} n={n_tok} C={C} nk={nk} ln={ln}] rel-L2 = {e:.3e}")
+    assert e < 2e-3                                                    # P is rounded to fp16 before P.V, like attention_fused
+    # and against the unfused kernels of this library on the same operands (q rounded to fp16 in between)
+    qd = ops.gemm(h.cuda(), w16.cuda(), bias=t.cuda(), ln_stats=st, ln_colsum=s.cuda()) if ln else ops.gemm(h.cuda(), wq.cuda())
+    un = ops.attention_fused(qd, k_dev, vt_dev, B, H, n_tok, nk, 64, scale)
+    assert rel_l2(out, un) < 2e-3
+
+
+@pytest.mark.parametrize("B,H,Nq,Nk,d", [(2, 8, 256, 77, 40), (1, 8, 1024, 77, 80), (2, 4, 64, 13, 160), (2, 8, 1024, 1024, 80),
+                                         (1, 8, 256, 256, 160), (3, 2, 100, 90, 64), (1, 2, 200, 333, 48)])
+def test_attention_probs_one_pass(B, H, Nq, Nk, d):
+    """Materialised probabilities without the fp32 score tensor (icd_attention_probs): exact softmax for <= 96 keys, two
+    sweeps (running max / sum, then P) for longer rows; vs torch fp32 softmax(q k^T * scale), pad columns zero."""
+    ops = _ops()
+    q, k = r16(B * Nq, H * d, seed=131, scale=1.5), r16(B * Nk, H * d, seed=132, scale=1.5)
+    scale = d ** -0.5
+    ld = (Nk + 7) // 8 * 8
+    P = ops.attention_probs(q.cuda(), k.cuda(), B, H, Nq, Nk, d, scale, ld)
+    qq = q.float().reshape(B, Nq, H, d).permute(0, 2, 1, 3)
+    kk = k.float().reshape(B, Nk, H, d).permute(0, 2, 1, 3)
+    ref = torch.softmax(qq @ kk.transpose(-1, -2) * scale, -1).reshape(B * H, Nq, Nk)
+    assert P.shape == (B * H, Nq, ld)
+    got = P.float().cpu()
+    assert float(got[:, :, Nk:].abs().max()) == 0.0 if ld > Nk else True
+    assert rel_l2(got[:, :, :Nk], ref) < TOL
+    assert float((got[:, :, :Nk].sum(-1) - 1).abs().max()) < 2e-3
+    # same probabilities as the two-kernel path it replaces (fp32 scores -> row softmax), up to the fp16 rounding of P
+    S = ops.attention_scores(q.cuda(), k.cuda(), B, H, Nq, Nk, d, scale, ld)
+    P2 = ops.softmax_rows(S.reshape(B * H * Nq, ld), Nk, ld).reshape(B * H, Nq, ld)
+    assert float((P.float() - P2.float()).abs().max()) < 2e-3

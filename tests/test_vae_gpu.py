@@ -122,3 +122,48 @@ def test_encode_moments_and_sample_match_oracle():
     assert s1.shape == (2, 4, 8, 12) and not torch.equal(s1, d.mean)
     s2 = d.sample(torch.Generator(device="cuda").manual_seed(21))            # a device generator draws on the device
     assert s2.is_cuda and torch.isfinite(s2).all() and not torch.equal(s1, s2)
+
+
+# ------------------------------------------------------------------------------ fp32-fidelity path (`vae.to(torch.float32)`)
+def test_fp32_fidelity_decode_and_encode_match_oracle_tightly():
+    """`.to(torch.float32)` (utils/generation_sdxl.py:465-466, diffusers force_upcast) selects fp32 storage + split3 fp16
+    operands: the result must sit far below the fp16 path's ~1.3e-3, on fp32 weights that are NOT fp16-representable."""
+    synthetic, vae, vae_ref = _env()
+    cfg = vae.SDXL_VAE.scaled((32, 64, 128, 128))
+    sd = synthetic.synthetic_vae_state_dict(cfg, seed=13)                           # genuine fp32 weights
+    ocfg = dict(vae_ref.SDXL_VAE, block_out_channels=(32, 64, 128, 128))
+    m = vae.AutoencoderKL(cfg, sd).to(torch.float32)
+    z = torch.randn(2, 4, 16, 24, generator=torch.Generator().manual_seed(5)) * 1.5
+    got = m.decode(z.cuda())["sample"]
+    assert got.dtype == torch.float32
+    e_dec = rel_l2(got.cpu(), vae_ref.decode(sd, ocfg, z))
+    x = torch.rand(2, 3, 64, 96, generator=torch.Generator().manual_seed(6)) * 2 - 1
+    d = m.encode(x.cuda()).latent_dist
+    mom = vae_ref.encode_moments(sd, ocfg, x)
+    e_mean, e_lv = rel_l2(d.mean.cpu(), mom[:, :4]), rel_l2(d.logvar.cpu(), mom[:, 4:].clamp(-30, 20))
+    print(f"[vae fp32-fidelity] decode rel-L2 = {e_dec:.3e}  encode mean = {e_mean:.3e}  logvar = {e_lv:.3e}")
+    assert e_dec < 3e-4 and e_mean < 3e-4 and e_lv < 3e-4
+    m.to(torch.float16)                                                              # and back: the fp16 path is untouched
+    e16 = rel_l2(m.decode(z.cuda())["sample"].float().cpu(), vae_ref.decode(sd, ocfg, z))
+    assert 3e-4 < e16 < 4e-3
+
+
+def test_fp32_fidelity_survives_activations_beyond_the_fp16_range():
+    """Real SDXL-VAE weights drive the decoder's residual stream past 65504 (why the reference upcasts it).  Emulated by
+    scaling the residual-branch output convs: the fp16 path overflows to inf / NaN, the fp32-fidelity path stays finite and
+    within 1e-3 of the fp32 oracle."""
+    synthetic, vae, vae_ref = _env()
+    cfg = vae.SDXL_VAE.scaled((32, 64, 64, 64))
+    sd = synthetic.synthetic_vae_state_dict(cfg, seed=14)
+    for k in ("decoder.conv_in.weight", "decoder.conv_in.bias", "post_quant_conv.bias"):
+        sd[k] = sd[k] * 100.0                                   # (the weights themselves stay far inside the fp16 range)
+    ocfg = dict(vae_ref.SDXL_VAE, block_out_channels=(32, 64, 64, 64))
+    z = torch.randn(1, 4, 16, 16, generator=torch.Generator().manual_seed(7)) * 2.0e3     # residual stream ~1e5 - 1e6 from the first conv on
+    ref = vae_ref.decode(sd, ocfg, z)
+    m = vae.AutoencoderKL(cfg, sd)
+    bad = m.decode(z.cuda())["sample"]
+    assert not torch.isfinite(bad).all()                                             # the fp16-storage path cannot hold these
+    good = m.to(torch.float32).decode(z.cuda())["sample"]
+    e = rel_l2(good.cpu(), ref)
+    print(f"[vae fp32-fidelity, overflowing activations] rel-L2 = {e:.3e}  max|ref| = {float(ref.abs().max()):.3e}")
+    assert torch.isfinite(good).all() and e < 1e-3

@@ -12,7 +12,12 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--arch", default="sd15")
 ap.add_argument("--batch", type=int, default=32)
 ap.add_argument("--reps", type=int, default=3)
+ap.add_argument("--no-xattn", action="store_true", help="query projection and cross-attention as two launches (A/B)")
+ap.add_argument("--xattn-tile", type=int, default=0, help="2: force the 128x128 tile of the fused kernel, 4: the 256x128 tile")
 a = ap.parse_args()
+_lib.load().icd_debug_no_xattn_fusion(int(a.no_xattn))
+if a.xattn_tile:
+    _lib.load().icd_debug_gemm_group_m(-a.xattn_tile)
 cfg = SD15 if a.arch == "sd15" else SDXL
 res = 64 if a.arch == "sd15" else 128
 sd = synthetic.synthetic_state_dict(cfg, seed=0, device="cuda", dtype=torch.float16)
@@ -35,6 +40,13 @@ for fam, M, N, K, aux, ms, fl in recs:
     k = (fam, M, N, K, aux)
     e = agg.setdefault(k, [0, 0.0, 0.0])
     e[0] += 1; e[1] += ms; e[2] += fl
+torch.cuda.synchronize()
+import time
+t0 = time.perf_counter()
+for _ in range(5):
+    m(x, 999, **kw)
+torch.cuda.synchronize()
+print(f"wall per forward (no events): {(time.perf_counter() - t0) / 5 * 1e3:.2f} ms")
 tot = sum(e[1] for e in agg.values())
 print(f"{a.arch} B={a.batch}: {tot / a.reps:.2f} ms of kernels per forward")
 print(f"{'family':13s} {'M':>8s} {'N':>6s} {'K':>6s} {'aux':>5s} {'n/fwd':>6s} {'ms/fwd':>8s} {'us/call':>9s} {'TF/s':>7s} {'%':>6s}")

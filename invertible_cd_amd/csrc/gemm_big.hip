@@ -231,7 +231,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_big_kernel(GemmK p) {
 
     if (tl && tid == 0) tl[5] = __builtin_amdgcn_s_memtime();        // shader-clock ticks of the main loop (clock = ticks / time)
     // ---- epilogue (gemm_epilogue.h): per-wave LDS patches, no block-wide slabs -----------------------------------------
-    wave_epilogue<TM, TN>(p, acc, smem, wv, wm, wn, l, m0, n0, split, tl);
+    // (the 256 x 320 conv tile has no registers left for the early-load fast path: 160 accumulators + the im2col loader state)
+    wave_epilogue<TM, TN, !(MODE == 1 && TM * TN > 8)>(p, acc, smem, wv, wm, wn, l, m0, n0, split, tl);
     if (tl) {                                    // last wave out writes the end stamp (stores of this wave are issued, not drained)
         __syncthreads();
         if (tid == 0) tl[3] = __builtin_amdgcn_s_memrealtime();

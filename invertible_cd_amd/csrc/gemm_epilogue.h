@@ -6,9 +6,15 @@
 
 namespace icd_gemm_detail {
 
+// Neutral operands for the branch-free fast path below: a missing bias / residual / time-bias / LayerNorm column sum reads
+// zeros, a missing LayerNorm row statistic reads (mean 0, rstd 1) - so every load is issued unconditionally and early.
+static __device__ __attribute__((aligned(256))) const float icd_epi_zero[16] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f,
+                                                                                0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+static __device__ __attribute__((aligned(16))) const float icd_epi_ln_id[2] = {0.f, 1.f};
+
 // acc[i][j]: 32x32 MFMA tile (i = 32-row group of the wave's rows, j = 32-column group), wave (wm, wn) of a WM x WN grid
 // whose wave tile is (TM*32) x (TN*32); m0 / n0: origin of the block tile.  All waves of the block must call it.
-template <int TM, int TN>
+template <int TM, int TN, bool FAST_OK = true>
 __device__ __forceinline__ void wave_epilogue(const GemmK& p, f32x16 (&acc)[TM][TN], unsigned char* smem, int wv, int wm, int wn,
                                               int l, int m0, int n0, int split, unsigned long long* tl) {
     const int lr = l & 31, lh = l >> 5;
@@ -63,6 +69,61 @@ __device__ __forceinline__ void wave_epilogue(const GemmK& p, f32x16 (&acc)[TM][
                 }
                 continue;
             }
+            // ---- fast path of the common epilogue (fp16 output, optional bias / time-bias / fp16 residual / fused LayerNorm, no
+            // split-K): every global operand of the patch's 4 passes is requested BEFORE the accumulators are staged through
+            // LDS, branch-free (absent operands read a neutral page).  The generic code below waits for each pass's loads in
+            // turn - 16 exposed memory latencies per wave; measured per block (tools/gemm_timeline.py) that epilogue costs
+            // 9 - 23 us of a 40 - 60 us tile.
+            const int ncol0 = n0 + (wn * TN + j0) * 32;
+            const bool fast = FAST_OK && !geglu && !part && !out_f32 && !(p.flags & ICD_GEMM_RESID_F32);
+            const int f_chs = jn == 2 ? 3 : 2, f_npass = jn == 2 ? 4 : 2;
+            const int f_c8 = (l & ((1 << f_chs) - 1)) * 8, f_n = ncol0 + f_c8;
+            constexpr bool PF_ROWBIAS = TM * TN <= 8;            // the 160-accumulator tiles have no registers left for it,
+            constexpr int PF_PASSES = TM * TN <= 8 ? 4 : 2;      // and request only the first two passes early
+            f32x4 f_b0, f_b1, f_s0, f_s1;
+            f16x8 f_rs[4], f_rb[4];
+            f32x2 f_st[4];
+            // GEGLU patches: the same idea - the four column operands (bias and LayerNorm column sums of the value and of the gate
+            // columns) and the two passes' row statistics are requested before the accumulators are staged
+            const int g_oc = (l & 3) * 8;
+            f32x4 g_bh0, g_bh1, g_bg0, g_bg1, g_sh0, g_sh1, g_sg0, g_sg1;
+            f32x2 g_st[2];
+            if (geglu) {
+                const bool ncol_ok = ncol0 + g_oc < p.N;
+                const float* bp = (p.bias && ncol_ok) ? p.bias + ncol0 + g_oc : icd_epi_zero;
+                const float* sp = (p.ln_stats && ncol_ok) ? p.ln_s + ncol0 + g_oc : icd_epi_zero;
+                const int goff = (p.bias && ncol_ok) ? 32 : 0, soff = (p.ln_stats && ncol_ok) ? 32 : 0;
+                g_bh0 = *reinterpret_cast<const f32x4*>(bp); g_bh1 = *reinterpret_cast<const f32x4*>(bp + 4);
+                g_bg0 = *reinterpret_cast<const f32x4*>(bp + goff); g_bg1 = *reinterpret_cast<const f32x4*>(bp + goff + 4);
+                g_sh0 = *reinterpret_cast<const f32x4*>(sp); g_sh1 = *reinterpret_cast<const f32x4*>(sp + 4);
+                g_sg0 = *reinterpret_cast<const f32x4*>(sp + soff); g_sg1 = *reinterpret_cast<const f32x4*>(sp + soff + 4);
+#pragma unroll
+                for (int pass = 0; pass < 2; ++pass) {
+                    const int m = mrow0 + ((pass * 64 + l) >> 2);
+                    const float* lp = (p.ln_stats && m < p.M && ncol_ok) ? p.ln_stats + 2 * (long long)m : icd_epi_ln_id;
+                    g_st[pass] = *reinterpret_cast<const f32x2*>(lp);
+                }
+            }
+            if (fast) {
+                const bool ncol_ok = f_n < p.N;
+                const float* bp = (p.bias && ncol_ok) ? p.bias + f_n : icd_epi_zero;
+                const float* sp = (p.ln_stats && ncol_ok) ? p.ln_s + f_n : icd_epi_zero;
+                f_b0 = *reinterpret_cast<const f32x4*>(bp); f_b1 = *reinterpret_cast<const f32x4*>(bp + 4);
+                f_s0 = *reinterpret_cast<const f32x4*>(sp); f_s1 = *reinterpret_cast<const f32x4*>(sp + 4);
+#pragma unroll
+                for (int pass = 0; pass < PF_PASSES; ++pass) {
+                    if (pass >= f_npass) break;
+                    const int m = mrow0 + ((pass * 64 + l) >> f_chs);
+                    const bool okp = m < p.M && ncol_ok;
+                    const half_t* zp = reinterpret_cast<const half_t*>(icd_epi_zero);
+                    const half_t* rp = (p.resid && okp) ? p.resid + (long long)m * p.ldr + f_n : zp;
+                    const half_t* tp = (p.rowbias && okp) ? p.rowbias + (long long)(m / p.rps) * p.ld_rowbias + f_n : zp;
+                    const float* lp = (p.ln_stats && okp) ? p.ln_stats + 2 * (long long)m : icd_epi_ln_id;
+                    f_rs[pass] = *reinterpret_cast<const f16x8*>(rp);
+                    if (PF_ROWBIAS) f_rb[pass] = *reinterpret_cast<const f16x8*>(tp);
+                    f_st[pass] = *reinterpret_cast<const f32x2*>(lp);
+                }
+            }
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj) {
                 if (jj >= jn) break;
@@ -73,48 +134,58 @@ __device__ __forceinline__ void wave_epilogue(const GemmK& p, f32x16 (&acc)[TM][
                     *reinterpret_cast<f32x4*>(wst + lr * LDW + jj * 32 + 8 * g + 4 * lh) = v;
                 }
             }
-            const int ncol0 = n0 + (wn * TN + j0) * 32;
             if (geglu) {                                         // 64 staged columns = [32 h | 32 gate] -> 32 outputs
                 half_t* out = reinterpret_cast<half_t*>(p.out);
 #pragma unroll
                 for (int pass = 0; pass < 2; ++pass) {           // 32 rows x 4 chunks of 8 outputs
-                    const int item = pass * 64 + l;
-                    const int r = item >> 2, oc = (item & 3) * 8;
+                    const int r = (pass * 64 + l) >> 2;
                     const int m = mrow0 + r;
-                    if (m >= p.M || ncol0 + oc >= p.N) continue;
-                    const float* sp = wst + r * LDW + oc;
-                    f32x4 h0 = *reinterpret_cast<const f32x4*>(sp), h1 = *reinterpret_cast<const f32x4*>(sp + 4);
-                    f32x4 g0 = *reinterpret_cast<const f32x4*>(sp + 32), g1 = *reinterpret_cast<const f32x4*>(sp + 36);
-                    float hv[8] = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
-                    float gv[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
-                    if (p.ln_stats) {
+                    const float* sp = wst + r * LDW + g_oc;
+                    const f32x4 h0 = *reinterpret_cast<const f32x4*>(sp), h1 = *reinterpret_cast<const f32x4*>(sp + 4);
+                    const f32x4 g0 = *reinterpret_cast<const f32x4*>(sp + 32), g1 = *reinterpret_cast<const f32x4*>(sp + 36);
+                    const float mu = g_st[pass][0], rstd = g_st[pass][1];
+                    f16x8 o;
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) { hv[e] *= p.alpha; gv[e] *= p.alpha; }
-                        ln_correct8(hv, p.ln_stats, p.ln_s, m, ncol0 + oc);
-                        ln_correct8(gv, p.ln_stats, p.ln_s, m, ncol0 + oc + 32);
-                        if (p.bias) {
-                            const float* bp = p.bias + ncol0 + oc;
+                    for (int e = 0; e < 4; ++e) {
+                        const float hv0 = rstd * (h0[e] * p.alpha - mu * g_sh0[e]) + g_bh0[e];
+                        const float hv1 = rstd * (h1[e] * p.alpha - mu * g_sh1[e]) + g_bh1[e];
+                        const float gv0 = rstd * (g0[e] * p.alpha - mu * g_sg0[e]) + g_bg0[e];
+                        const float gv1 = rstd * (g1[e] * p.alpha - mu * g_sg1[e]) + g_bg1[e];
+                        o[e] = (half_t)(hv0 * gelu_fast(gv0));
+                        o[4 + e] = (half_t)(hv1 * gelu_fast(gv1));
+                    }
+                    if (m < p.M && ncol0 + g_oc < p.N) *reinterpret_cast<f16x8*>(out + (long long)m * p.ldo + (ncol0 >> 1) + g_oc) = o;
+                }
+            } else if (fast) {
+                half_t* outp = reinterpret_cast<half_t*>(p.out);
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) { hv[e] += bp[e]; gv[e] += bp[32 + e]; }
-                        }
-                    } else
-                    if (p.bias) {
-                        const float* bp = p.bias + ncol0 + oc;
-                        f32x4 b0 = *reinterpret_cast<const f32x4*>(bp), b1 = *reinterpret_cast<const f32x4*>(bp + 4);
-                        f32x4 c0 = *reinterpret_cast<const f32x4*>(bp + 32), c1 = *reinterpret_cast<const f32x4*>(bp + 36);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            hv[e] = hv[e] * p.alpha + b0[e]; hv[4 + e] = hv[4 + e] * p.alpha + b1[e];
-                            gv[e] = gv[e] * p.alpha + c0[e]; gv[4 + e] = gv[4 + e] * p.alpha + c1[e];
-                        }
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) { hv[e] *= p.alpha; gv[e] *= p.alpha; }
+                for (int pass = 0; pass < 4; ++pass) {
+                    if (pass >= f_npass) break;
+                    const int r = (pass * 64 + l) >> f_chs;
+                    const int m = mrow0 + r;
+                    const float* sp = wst + r * LDW + f_c8;
+                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(sp), v1 = *reinterpret_cast<const f32x4*>(sp + 4);
+                    const bool okl = m < p.M && f_n < p.N;
+                    if (!PF_ROWBIAS) {
+                        const half_t* tp = (p.rowbias && okl) ? p.rowbias + (long long)(m / p.rps) * p.ld_rowbias + f_n
+                                                              : reinterpret_cast<const half_t*>(icd_epi_zero);
+                        f_rb[pass] = *reinterpret_cast<const f16x8*>(tp);
+                    }
+                    if (pass >= PF_PASSES) {
+                        const half_t* rp = (p.resid && okl) ? p.resid + (long long)m * p.ldr + f_n : reinterpret_cast<const half_t*>(icd_epi_zero);
+                        const float* lp = (p.ln_stats && okl) ? p.ln_stats + 2 * (long long)m : icd_epi_ln_id;
+                        f_rs[pass] = *reinterpret_cast<const f16x8*>(rp);
+                        f_st[pass] = *reinterpret_cast<const f32x2*>(lp);
                     }
                     f16x8 o;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] = (half_t)(hv[e] * gelu_fast(gv[e]));
-                    *reinterpret_cast<f16x8*>(out + (long long)m * p.ldo + (ncol0 >> 1) + oc) = o;
+                    for (int e = 0; e < 4; ++e) {
+                        const float a0 = f_st[pass][1] * (v0[e] * p.alpha - f_st[pass][0] * f_s0[e]) + f_b0[e];
+                        const float a1 = f_st[pass][1] * (v1[e] * p.alpha - f_st[pass][0] * f_s1[e]) + f_b1[e];
+                        o[e] = (half_t)(a0 + (float)f_rb[pass][e] + (float)f_rs[pass][e]);
+                        o[4 + e] = (half_t)(a1 + (float)f_rb[pass][4 + e] + (float)f_rs[pass][4 + e]);
+                    }
+                    if (m < p.M && f_n < p.N) *reinterpret_cast<f16x8*>(outp + (long long)m * p.ldo + f_n) = o;
                 }
             } else {
                 const int chs = jn == 2 ? 3 : 2;                 // log2(8-wide chunks per staged row)

@@ -10,15 +10,29 @@ Corrections (MI355X_MICROARCH.md, HBM section): counters are in KiB; FETCH_SIZE 
 (calibrated here on a conv with a known 83.9 MB output: 1.08x).  Infinity-Cache hits are included in both, so this is
 an upper bound on DRAM bytes.
 """
-import argparse, collections, csv, glob, json, re
+import argparse, collections, csv, glob, hashlib, json, os, re
+
+
+def kernels_sha():
+    """Same digest bench.py stamps into roofline.kernels_sha: which kernel sources this PMC summary was taken on."""
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "invertible_cd_amd", "csrc")
+    h = hashlib.sha1()
+    for f in sorted(glob.glob(os.path.join(root, "*"))):
+        if f.endswith((".hip", ".h", ".inc", ".cpp")):
+            h.update(open(f, "rb").read())
+    return h.hexdigest()[:12]
 
 
 def family(k):
+    """Kernel name -> the family names of bench.py's in-process profiler (include/icd_amd.h ICD_PROF_*)."""
+    m = re.search(r"gemm_kernel<(\d), (?:false|true), \d, \d, (false|true)", k)
+    if m and m.group(2) == "true":
+        return "xattn_fused"
     m = re.search(r"gemm(?:_big)?_kernel<(\d)", k)
     if m:
         return "gemm_dense" if m.group(1) == "0" else "gemm_conv"
-    for pat, f in (("splitk_reduce", "splitk_reduce"), ("attn_fused", "attn_fused"), ("attn_cross", "attn_fused"), ("gn_", "groupnorm"), ("layernorm", "layernorm"),
-                   ("softmax", "softmax")):
+    for pat, f in (("splitk_reduce", "splitk_reduce"), ("attn_probs", "softmax"), ("attn_fused", "attn_fused"), ("attn_cross", "attn_fused"),
+                   ("gn_", "groupnorm"), ("layernorm", "layernorm"), ("softmax", "softmax")):
         if pat in k:
             return f
     return None
@@ -40,7 +54,7 @@ ap.add_argument("fetch_dir"); ap.add_argument("write_dir")
 ap.add_argument("--arch", required=True); ap.add_argument("--batch", type=int, required=True)
 a = ap.parse_args()
 F, W = collect(a.fetch_dir), collect(a.write_dir)
-out = {"arch": a.arch, "per_gpu_batch": a.batch, "unit": "bytes per launch",
+out = {"arch": a.arch, "per_gpu_batch": a.batch, "unit": "bytes per launch", "kernels_sha": kernels_sha(),
        "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024",
        "families": {}}
 for fam in sorted(set(F) | set(W)):

@@ -1,0 +1,25 @@
+#!/bin/bash
+# Evidence for profiles/: the bench line, the rocprofv3 kernel-trace summary of the same command, the two PMC passes behind
+# roofline.traffic, the -s output of the parity tests.  Run on the GPU box:  bash tools/profile_round.sh r02_x
+# (writes gpurun_out/<tag>/...; copy the summaries you want judged into profiles/).
+set -u
+TAG=${1:-r02}
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+cd "$(dirname "$0")/.."
+export TMPDIR=/tmp
+python bench.py --steps 10 --warmup 3 > $OUT/${TAG}_bench_default.json 2> $OUT/bench_default.err
+for arch in sd15 sdxl; do
+  b=32; [ $arch = sdxl ] && b=8
+  python bench.py --arch $arch --steps 5 --warmup 2 --no-cpu-baseline --no-sdxl > $OUT/${TAG}_bench_${arch}_b${b}.json 2> $OUT/bench_$arch.err
+  rocprofv3 --kernel-trace -d $OUT/prof_$arch -o $arch -- python bench.py --arch $arch --steps 3 --warmup 2 --no-cpu-baseline --no-vae --no-ref-batching --no-sdxl \
+      > $OUT/${TAG}_bench_${arch}_b${b}_under_rocprof.json 2> $OUT/rocprof_$arch.err
+  db=$(find $OUT/prof_$arch -name "*.db" | head -1)
+  python tools/rocpd_stats.py "$db" > $OUT/${TAG}_bench_${arch}_b${b}_kernel_stats.txt 2>> $OUT/rocprof_$arch.err
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmcF_$arch -o p -- python bench.py --arch $arch --steps 1 --warmup 1 --no-cpu-baseline --no-vae --no-ref-batching --no-profile --no-sdxl > /dev/null 2> $OUT/pmcF_$arch.err
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmcW_$arch -o p -- python bench.py --arch $arch --steps 1 --warmup 1 --no-cpu-baseline --no-vae --no-ref-batching --no-profile --no-sdxl > /dev/null 2> $OUT/pmcW_$arch.err
+  python tools/hbm_traffic.py $OUT/pmcF_$arch $OUT/pmcW_$arch --arch $arch --batch $b > $OUT/${TAG}_hbm_traffic_${arch}_b${b}.json 2>> $OUT/pmcF_$arch.err
+  rm -rf $OUT/pmcF_$arch $OUT/pmcW_$arch
+  find $OUT/prof_$arch -name "*.db" -delete
+done
+tail -c 1500 $OUT/${TAG}_bench_default.json

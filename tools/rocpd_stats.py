@@ -35,8 +35,13 @@ def main(path):
     fam = {}
     for n, a in agg.items():
         m = re.search(r"gemm(?:_big)?_kernel<(\d)", n)
-        if m:
+        mx = re.search(r"gemm_kernel<\d, (?:false|true), \d, \d, true", n)
+        if mx:
+            f = "xattn_fused"
+        elif m:
             f = "gemm_dense" if m.group(1) == "0" else "gemm_conv"
+        elif "attn_probs" in n:
+            f = "softmax (one-pass probabilities)"
         elif "splitk_reduce" in n:
             f = "splitk_reduce (bench.py counts it inside the GEMM family that launched it)"
         elif "attn_fused" in n or "attn_cross" in n:

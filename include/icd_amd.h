@@ -339,9 +339,10 @@ int icd_profile_dump(icd_profile_record* recs, int32_t max_recs);
 int icd_debug_gemm_timeline(void* buf);
 /* m-tiles per L2 group of the GEMM block -> tile map (0: default).  A/B tuning only; results are unchanged. */
 int icd_debug_gemm_group_m(int32_t gm);
-/* off != 0: the executor runs the query projection and the cross-attention as two launches again (A/B measurement of the
- * fused kernel; results differ only by the fp16 rounding of q). */
-int icd_debug_no_xattn_fusion(int32_t off);
+/* on != 0: the executor runs LayerNorm -> to_q -> cross-attention of every eligible layer (head dim 64, tokens %% 256 == 0, no
+ * controller asking for the probabilities) as ONE launch (icd_gemm_desc.xattn_*) instead of projection + attention.  Off by
+ * default (measured slower at the SDXL sizes); results differ only by the fp16 rounding of q. */
+int icd_set_xattn_fusion(int32_t on);
 
 #ifdef __cplusplus
 }

@@ -122,7 +122,7 @@ SIGNATURES = {
                                  C.c_void_p, C.c_int32, C.c_void_p]),
     "icd_debug_gemm_timeline": (C.c_int, [C.c_void_p]),
     "icd_debug_gemm_group_m": (C.c_int, [C.c_int32]),
-    "icd_debug_no_xattn_fusion": (C.c_int, [C.c_int32]),
+    "icd_set_xattn_fusion": (C.c_int, [C.c_int32]),
     "icd_profile_enable": (C.c_int, [C.c_int32]),
     "icd_profile_read": (C.c_int, [C.POINTER(ProfileRow), C.c_int32]),
     "icd_profile_dump": (C.c_int, [C.POINTER(ProfileRecord), C.c_int32]),

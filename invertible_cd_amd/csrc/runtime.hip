@@ -45,7 +45,10 @@ struct ProfScope {
     ~ProfScope() { if (on) (void)hipEventRecord(g_prof[idx].b, st); }
 };
 
-bool g_no_xattn_fusion = false;         // icd_debug_no_xattn_fusion: A/B switch (query projection and cross-attention as two launches)
+// icd_set_xattn_fusion: run LN2 -> to_q -> cross-attention as ONE launch (icd_gemm xattn_*).  Off by default: the fused kernel
+// is hosted on the 128-wide tile family, whose main loop is 30 - 40 % slower than the 256-wide tiles the plain projection
+// gets, so at SDXL B = 8 the fused launch (63.8 us) loses to projection (35.4 us) + attention (23.3 us); DESIGN.md section 4.
+bool g_no_xattn_fusion = true;
 
 struct Arena {
     char* base = nullptr;
@@ -547,7 +550,7 @@ int temb_total(const icd_unet_config& c) {
 
 }  // namespace
 
-extern "C" int icd_debug_no_xattn_fusion(int32_t off) { g_no_xattn_fusion = off != 0; return ICD_OK; }
+extern "C" int icd_set_xattn_fusion(int32_t on) { g_no_xattn_fusion = on == 0; return ICD_OK; }
 
 extern "C" int icd_profile_enable(int32_t enable) {
     for (auto& r : g_prof) { g_ev_pool.push_back(r.a); g_ev_pool.push_back(r.b); }

@@ -146,3 +146,30 @@ def test_sdxl_inversion_from_image_tensor_and_pil(sdxl):
         assert torch.equal(start_a, start_b) and torch.equal(lat_a, lat_b)
     finally:
         fwd.vae = None
+
+
+def test_fused_query_projection_cross_attention_inside_the_unet(sdxl):
+    """The north-star kernel switched on in the executor (icd_set_xattn_fusion): full-width SDXL, 64x64 latent (1024- and
+    4096-token levels are eligible: head dim 64, tokens % 256 == 0).  Same result as projection + attention up to the fp16
+    rounding of q that the fused kernel never makes."""
+    from invertible_cd_amd import _lib, synthetic
+    cfg, pipe, _ = sdxl
+    inp = synthetic.synthetic_inputs(cfg, 2, 64, 64, seed=21, device="cpu")
+    kw = dict(encoder_hidden_states=inp["context"].cuda().half(), timestep_cond=torch.randn(2, 512, generator=torch.Generator().manual_seed(1)).cuda().half(),
+              added_cond_kwargs={"text_embeds": inp["text_embeds"].cuda().half(), "time_ids": inp["time_ids"].cuda()})
+    x = inp["latents"].cuda().half()
+    lib = _lib.load()
+    base = pipe.unet(x, 499, **kw).sample
+    _lib.profile_enable(True)
+    try:
+        lib.icd_set_xattn_fusion(1)
+        fused = pipe.unet(x, 499, **kw).sample
+        torch.cuda.synchronize()
+        fam = _lib.profile_read()
+    finally:
+        lib.icd_set_xattn_fusion(0)
+        _lib.profile_enable(False)
+    assert fam["xattn_fused"]["launches"] == 70                  # every cross-attention layer of SDXL took the fused kernel
+    e = rel_l2(fused, base)
+    print(f"[sdxl fused xattn in the executor] rel-L2 vs two launches = {e:.3e}")
+    assert torch.isfinite(fused).all() and e < 1e-3

@@ -33,7 +33,7 @@ d.a0, d.w, d.out, d.bias = x.data_ptr(), w.data_ptr(), out.data_ptr(), b.data_pt
 d.resid = res.data_ptr() if res is not None else None
 d.M, d.N, d.K, d.Nw, d.lda, d.ldw, d.ldo, d.ldr = M, N, K, N, K, K, out.stride(0), N
 d.mode, d.batch, d.zdiv, d.alpha = 0, 1, 1, 1.0
-d.flags = (((a.cfg + 1) << 24) if a.cfg < 4 else {4: 0x80000, 5: 0x40000}[a.cfg]) | (1 if a.geglu else 0)
+d.flags = (((a.cfg + 1) << 24) if a.cfg < 4 else {4: 0x80000 | 0x200000, 5: 0x40000 | 0x200000}[a.cfg]) | (1 if a.geglu else 0)
 # cfg 4: 256x128 three-stage tile, 5: 128x128 (two blocks per CU)
 lib.icd_debug_gemm_group_m(a.gm)
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)

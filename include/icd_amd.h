@@ -61,7 +61,7 @@ int icd_version(void);
 #define ICD_GEMM_TUNE_FORCE_BIG  0x00100000   /* take a 256-wide tile (gemm_big.hip) whatever the chip fill           */
 #define ICD_GEMM_TUNE_NO_BIG     0x00200000   /* never take one                                                      */
 #define ICD_GEMM_TUNE_BN256      0x00400000   /* big tiles: only the BN = 256 shapes                                 */
-#define ICD_GEMM_TUNE_BIG_CFG(i) (((i) + 1) << 24)   /* force big-tile configuration i (0..3, see gemm_common.h)      */
+#define ICD_GEMM_TUNE_BIG_CFG(i) (((i) + 1) << 24)   /* force big-tile configuration i (0..4, see gemm_common.h)      */
 
 /* out = alpha * (A (*) W^T) + bias[n] + rowbias[m / rows_per_sample][n] + resid[m][n]
  * A is either a dense row-major [M, K] matrix (mode 0; Linear, 1x1 conv, attention bmm) or the implicit im2col

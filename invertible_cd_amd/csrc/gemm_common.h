@@ -79,12 +79,13 @@ __device__ __forceinline__ void ln_correct8(float (&v)[8], const float* ln_stats
 // chip (about 1.3 - 1.7 us depending on the box's clocks).  tk_full applies when >= 200 CUs are busy (chip-level
 // ceiling: the same block runs about 10 - 20 % slower), tk_part when <= 160.
 struct BigTile { int bm, bn; bool geglu_ok; double tk_part, tk_full, fixed; };
-constexpr int NUM_BIG_TILES = 4;
+constexpr int NUM_BIG_TILES = 5;
 constexpr BigTile BIG_TILES[NUM_BIG_TILES] = {
     {256, 256, true, 1.00, 1.08, 9.5},
     {256, 320, false, 1.07, 1.30, 15.3},
     {192, 256, true, 0.70, 0.76, 9.6},
     {128, 320, false, 0.72, 0.80, 7.2},
+    {256, 160, false, 9.70, 9.80, 9.0},       // forced-only until calibrated
 };
 // Two further configurations were built, measured and removed in round 2 (tools/gemm_timeline.py): a
 // generated hand-scheduled 4-wave 128 x 128 main loop and a 256 x 128 x 32 tile with two co-resident blocks per CU.  Neither

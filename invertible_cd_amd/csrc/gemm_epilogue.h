@@ -12,6 +12,94 @@ static __device__ __attribute__((aligned(256))) const float icd_epi_zero[16] = {
                                                                                 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 static __device__ __attribute__((aligned(16))) const float icd_epi_ln_id[2] = {0.f, 1.f};
 
+// One staged patch (32 rows x JN*32 columns of one wave) of the common epilogue - fp16 output, optional bias / time-bias /
+// fp16 residual / fused LayerNorm correction, no split-K.  Every global operand of the patch's passes is requested BEFORE the
+// accumulators are staged through LDS (the generic code waits for each pass's loads in turn - 16 exposed memory latencies per
+// wave; measured per block with tools/gemm_timeline.py that epilogue costs 9 - 23 us of a 40 - 60 us tile).  Which operands exist
+// is a template parameter chosen by a wave-uniform switch in the caller (the all-true variant serves every other mix, absent
+// operands reading the neutral page): in the specialised variants an absent operand costs neither a load nor a register
+// (reading a neutral page instead was measured at +7..20 % on plain GEMMs - a 16-B residual read per lane is as much L1 traffic
+// as the output store).  Out-of-range lanes read the neutral page instead of branching around their loads.
+template <int JN, bool R, bool T, bool L, bool PF_ROWBIAS, int PF_PASSES>
+__device__ __forceinline__ void fast_patch(const GemmK& p, const f32x16& acc0, const f32x16& acc1, float* wst, int l, int mrow0,
+                                           int ncol0) {
+    constexpr int LDW = 68;
+    constexpr int CHS = JN == 2 ? 3 : 2, NPASS = JN == 2 ? 4 : 2;
+    const int lr = l & 31, lh = l >> 5;
+    const int c8 = (l & ((1 << CHS) - 1)) * 8, n = ncol0 + c8;
+    const bool ncol_ok = n < p.N;
+    const half_t* zp = reinterpret_cast<const half_t*>(icd_epi_zero);
+    f32x4 b0, b1, s0, s1;
+    f16x8 rs[NPASS], rb[NPASS];
+    f32x2 st[NPASS];
+    {
+        const float* bp = (p.bias && ncol_ok) ? p.bias + n : icd_epi_zero;       // 2 x 16 B per patch: not worth a variant
+        b0 = *reinterpret_cast<const f32x4*>(bp); b1 = *reinterpret_cast<const f32x4*>(bp + 4);
+    }
+    if (L) {
+        const float* sp = (p.ln_stats && ncol_ok) ? p.ln_s + n : icd_epi_zero;
+        s0 = *reinterpret_cast<const f32x4*>(sp); s1 = *reinterpret_cast<const f32x4*>(sp + 4);
+    }
+#pragma unroll
+    for (int pass = 0; pass < NPASS; ++pass) {
+        if (pass >= PF_PASSES) break;
+        const int m = mrow0 + ((pass * 64 + l) >> CHS);
+        const bool okp = m < p.M && ncol_ok;
+        if (R) rs[pass] = *reinterpret_cast<const f16x8*>((p.resid && okp) ? p.resid + (long long)m * p.ldr + n : zp);
+        if (T && PF_ROWBIAS) rb[pass] = *reinterpret_cast<const f16x8*>((p.rowbias && okp) ? p.rowbias + (long long)(m / p.rps) * p.ld_rowbias + n : zp);
+        if (L) st[pass] = *reinterpret_cast<const f32x2*>((p.ln_stats && okp) ? p.ln_stats + 2 * (long long)m : icd_epi_ln_id);
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        *reinterpret_cast<f32x4*>(wst + lr * LDW + 8 * g + 4 * lh) = (f32x4){acc0[4 * g], acc0[4 * g + 1], acc0[4 * g + 2], acc0[4 * g + 3]};
+        if (JN == 2)
+            *reinterpret_cast<f32x4*>(wst + lr * LDW + 32 + 8 * g + 4 * lh) = (f32x4){acc1[4 * g], acc1[4 * g + 1], acc1[4 * g + 2], acc1[4 * g + 3]};
+    }
+    half_t* outp = reinterpret_cast<half_t*>(p.out);
+#pragma unroll
+    for (int pass = 0; pass < NPASS; ++pass) {
+        const int r = (pass * 64 + l) >> CHS;
+        const int m = mrow0 + r;
+        const float* sp = wst + r * LDW + c8;
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(sp), v1 = *reinterpret_cast<const f32x4*>(sp + 4);
+        const bool okl = m < p.M && ncol_ok;
+        if (T && !PF_ROWBIAS) rb[pass] = *reinterpret_cast<const f16x8*>((p.rowbias && okl) ? p.rowbias + (long long)(m / p.rps) * p.ld_rowbias + n : zp);
+        if (pass >= PF_PASSES) {
+            if (R) rs[pass] = *reinterpret_cast<const f16x8*>((p.resid && okl) ? p.resid + (long long)m * p.ldr + n : zp);
+            if (L) st[pass] = *reinterpret_cast<const f32x2*>((p.ln_stats && okl) ? p.ln_stats + 2 * (long long)m : icd_epi_ln_id);
+        }
+        f16x8 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float a0 = v0[e] * p.alpha, a1 = v1[e] * p.alpha;
+            if (L) { a0 = st[pass][1] * (a0 - st[pass][0] * s0[e]); a1 = st[pass][1] * (a1 - st[pass][0] * s1[e]); }
+            a0 += b0[e]; a1 += b1[e];
+            if (T) { a0 += (float)rb[pass][e]; a1 += (float)rb[pass][4 + e]; }
+            if (R) { a0 += (float)rs[pass][e]; a1 += (float)rs[pass][4 + e]; }
+            o[e] = (half_t)a0; o[4 + e] = (half_t)a1;
+        }
+        if (okl) *reinterpret_cast<f16x8*>(outp + (long long)m * p.ldo + n) = o;
+    }
+}
+
+// All patches of one wave through fast_patch (one operand mix per instantiation).
+template <int TM, int TN, bool R, bool T, bool L>
+__device__ __forceinline__ void wave_epilogue_fast(const GemmK& p, f32x16 (&acc)[TM][TN], float* wst, int wm, int wn, int l, int m0,
+                                                   int n0) {
+    constexpr bool PF_ROWBIAS = TM * TN <= 8;                    // the 160-accumulator tiles have no registers left for it,
+    constexpr int PF_PASSES = TM * TN <= 8 ? 4 : 2;              // and request only the first two passes early
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int mrow0 = m0 + (wm * TM + i) * 32;
+#pragma unroll
+        for (int j0 = 0; j0 < TN; j0 += 2) {
+            const int ncol0 = n0 + (wn * TN + j0) * 32;
+            if (TN - j0 >= 2) fast_patch<2, R, T, L, PF_ROWBIAS, PF_PASSES>(p, acc[i][j0], acc[i][j0 + 1 < TN ? j0 + 1 : j0], wst, l, mrow0, ncol0);
+            else fast_patch<1, R, T, L, PF_ROWBIAS, PF_PASSES>(p, acc[i][j0], acc[i][j0], wst, l, mrow0, ncol0);
+        }
+    }
+}
+
 // acc[i][j]: 32x32 MFMA tile (i = 32-row group of the wave's rows, j = 32-column group), wave (wm, wn) of a WM x WN grid
 // whose wave tile is (TM*32) x (TN*32); m0 / n0: origin of the block tile.  All waves of the block must call it.
 template <int TM, int TN, bool FAST_OK = true>
@@ -28,6 +116,17 @@ __device__ __forceinline__ void wave_epilogue(const GemmK& p, f32x16 (&acc)[TM][
     if (tl && tid == 0) tl[2] = __builtin_amdgcn_s_memrealtime();
     float* wst = reinterpret_cast<float*>(smem) + wv * (trans ? 64 * LDT : 32 * LDW);
     float* part = p.ksplit > 1 ? p.partial + (long long)split * p.M * p.N : nullptr;
+    if (FAST_OK && !trans && !geglu && !part && !out_f32 && !(p.flags & ICD_GEMM_RESID_F32)) {
+        // fast path of the common epilogue, specialised by which operands exist (wave-uniform switch around the whole wave tile)
+        switch ((p.resid ? 1 : 0) | (p.rowbias ? 2 : 0) | (p.ln_stats ? 4 : 0)) {
+            case 0: wave_epilogue_fast<TM, TN, false, false, false>(p, acc, wst, wm, wn, l, m0, n0); break;   // plain / bias only
+            case 1: wave_epilogue_fast<TM, TN, true, false, false>(p, acc, wst, wm, wn, l, m0, n0); break;    // + residual
+            case 2: wave_epilogue_fast<TM, TN, false, true, false>(p, acc, wst, wm, wn, l, m0, n0); break;    // + time bias
+            case 4: wave_epilogue_fast<TM, TN, false, false, true>(p, acc, wst, wm, wn, l, m0, n0); break;    // LayerNorm-folded
+            default: wave_epilogue_fast<TM, TN, true, true, true>(p, acc, wst, wm, wn, l, m0, n0); break;     // other mixes
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int mrow0 = m0 + (wm * TM + i) * 32;
@@ -69,20 +168,7 @@ __device__ __forceinline__ void wave_epilogue(const GemmK& p, f32x16 (&acc)[TM][
                 }
                 continue;
             }
-            // ---- fast path of the common epilogue (fp16 output, optional bias / time-bias / fp16 residual / fused LayerNorm, no
-            // split-K): every global operand of the patch's 4 passes is requested BEFORE the accumulators are staged through
-            // LDS, branch-free (absent operands read a neutral page).  The generic code below waits for each pass's loads in
-            // turn - 16 exposed memory latencies per wave; measured per block (tools/gemm_timeline.py) that epilogue costs
-            // 9 - 23 us of a 40 - 60 us tile.
             const int ncol0 = n0 + (wn * TN + j0) * 32;
-            const bool fast = FAST_OK && !geglu && !part && !out_f32 && !(p.flags & ICD_GEMM_RESID_F32);
-            const int f_chs = jn == 2 ? 3 : 2, f_npass = jn == 2 ? 4 : 2;
-            const int f_c8 = (l & ((1 << f_chs) - 1)) * 8, f_n = ncol0 + f_c8;
-            constexpr bool PF_ROWBIAS = TM * TN <= 8;            // the 160-accumulator tiles have no registers left for it,
-            constexpr int PF_PASSES = TM * TN <= 8 ? 4 : 2;      // and request only the first two passes early
-            f32x4 f_b0, f_b1, f_s0, f_s1;
-            f16x8 f_rs[4], f_rb[4];
-            f32x2 f_st[4];
             // GEGLU patches: the same idea - the four column operands (bias and LayerNorm column sums of the value and of the gate
             // columns) and the two passes' row statistics are requested before the accumulators are staged
             const int g_oc = (l & 3) * 8;
@@ -102,26 +188,6 @@ __device__ __forceinline__ void wave_epilogue(const GemmK& p, f32x16 (&acc)[TM][
                     const int m = mrow0 + ((pass * 64 + l) >> 2);
                     const float* lp = (p.ln_stats && m < p.M && ncol_ok) ? p.ln_stats + 2 * (long long)m : icd_epi_ln_id;
                     g_st[pass] = *reinterpret_cast<const f32x2*>(lp);
-                }
-            }
-            if (fast) {
-                const bool ncol_ok = f_n < p.N;
-                const float* bp = (p.bias && ncol_ok) ? p.bias + f_n : icd_epi_zero;
-                const float* sp = (p.ln_stats && ncol_ok) ? p.ln_s + f_n : icd_epi_zero;
-                f_b0 = *reinterpret_cast<const f32x4*>(bp); f_b1 = *reinterpret_cast<const f32x4*>(bp + 4);
-                f_s0 = *reinterpret_cast<const f32x4*>(sp); f_s1 = *reinterpret_cast<const f32x4*>(sp + 4);
-#pragma unroll
-                for (int pass = 0; pass < PF_PASSES; ++pass) {
-                    if (pass >= f_npass) break;
-                    const int m = mrow0 + ((pass * 64 + l) >> f_chs);
-                    const bool okp = m < p.M && ncol_ok;
-                    const half_t* zp = reinterpret_cast<const half_t*>(icd_epi_zero);
-                    const half_t* rp = (p.resid && okp) ? p.resid + (long long)m * p.ldr + f_n : zp;
-                    const half_t* tp = (p.rowbias && okp) ? p.rowbias + (long long)(m / p.rps) * p.ld_rowbias + f_n : zp;
-                    const float* lp = (p.ln_stats && okp) ? p.ln_stats + 2 * (long long)m : icd_epi_ln_id;
-                    f_rs[pass] = *reinterpret_cast<const f16x8*>(rp);
-                    if (PF_ROWBIAS) f_rb[pass] = *reinterpret_cast<const f16x8*>(tp);
-                    f_st[pass] = *reinterpret_cast<const f32x2*>(lp);
                 }
             }
 #pragma unroll
@@ -155,37 +221,6 @@ __device__ __forceinline__ void wave_epilogue(const GemmK& p, f32x16 (&acc)[TM][
                         o[4 + e] = (half_t)(hv1 * gelu_fast(gv1));
                     }
                     if (m < p.M && ncol0 + g_oc < p.N) *reinterpret_cast<f16x8*>(out + (long long)m * p.ldo + (ncol0 >> 1) + g_oc) = o;
-                }
-            } else if (fast) {
-                half_t* outp = reinterpret_cast<half_t*>(p.out);
-#pragma unroll
-                for (int pass = 0; pass < 4; ++pass) {
-                    if (pass >= f_npass) break;
-                    const int r = (pass * 64 + l) >> f_chs;
-                    const int m = mrow0 + r;
-                    const float* sp = wst + r * LDW + f_c8;
-                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(sp), v1 = *reinterpret_cast<const f32x4*>(sp + 4);
-                    const bool okl = m < p.M && f_n < p.N;
-                    if (!PF_ROWBIAS) {
-                        const half_t* tp = (p.rowbias && okl) ? p.rowbias + (long long)(m / p.rps) * p.ld_rowbias + f_n
-                                                              : reinterpret_cast<const half_t*>(icd_epi_zero);
-                        f_rb[pass] = *reinterpret_cast<const f16x8*>(tp);
-                    }
-                    if (pass >= PF_PASSES) {
-                        const half_t* rp = (p.resid && okl) ? p.resid + (long long)m * p.ldr + f_n : reinterpret_cast<const half_t*>(icd_epi_zero);
-                        const float* lp = (p.ln_stats && okl) ? p.ln_stats + 2 * (long long)m : icd_epi_ln_id;
-                        f_rs[pass] = *reinterpret_cast<const f16x8*>(rp);
-                        f_st[pass] = *reinterpret_cast<const f32x2*>(lp);
-                    }
-                    f16x8 o;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float a0 = f_st[pass][1] * (v0[e] * p.alpha - f_st[pass][0] * f_s0[e]) + f_b0[e];
-                        const float a1 = f_st[pass][1] * (v1[e] * p.alpha - f_st[pass][0] * f_s1[e]) + f_b1[e];
-                        o[e] = (half_t)(a0 + (float)f_rb[pass][e] + (float)f_rs[pass][e]);
-                        o[4 + e] = (half_t)(a1 + (float)f_rb[pass][4 + e] + (float)f_rs[pass][4 + e]);
-                    }
-                    if (m < p.M && f_n < p.N) *reinterpret_cast<f16x8*>(outp + (long long)m * p.ldo + f_n) = o;
                 }
             } else {
                 const int chs = jn == 2 ? 3 : 2;                 // log2(8-wide chunks per staged row)

@@ -278,3 +278,44 @@ def test_boundary_step_round_trip_full_size():
             y = ops.x0_step(x, eps, fwd)
             back = ops.x0_step(y, eps, bwd)
             assert rel_l2(back, x) < 1e-5
+
+
+def test_ddim_baseline_loops_match_oracle():
+    """The DDIM baselines that share the UNet (utils/generation.py:183-205,305-371): 3 reverse DDIM steps
+    with classic classifier-free guidance (w_embed_dim = 0 -> `guided_step`, the CFG-doubled batch really is evaluated) and
+    3 forward (inversion) steps at guidance 1, against the oracle UNet + the DDIM update written out."""
+    E = _env()
+    B, H, W, g = 2, 16, 16, 7.5
+    cfg, sd, lat, ctx, model, solver = _sd15_setup(E, B, H, W, seed=31)
+    U = E["unet_ref"]
+    ocfg = _ocfg(U, cfg)
+    ac = model.scheduler.alphas_cumprod.double().numpy()
+    ts = [int(t) for t in model.scheduler.timesteps]
+    assert len(ts) == 50 and ts[0] == 981 and ts[-1] == 1
+    ctx2 = torch.cat([torch.zeros_like(ctx), ctx])
+
+    def ddim_update(x, eps, t_from, t_to):
+        a_f = ac[t_from] if t_from >= 0 else float(model.scheduler.final_alpha_cumprod)
+        a_t = ac[t_to] if t_to >= 0 else float(model.scheduler.final_alpha_cumprod)
+        x0 = (x - (1 - a_f) ** 0.5 * eps) / a_f ** 0.5
+        return a_t ** 0.5 * x0 + (1 - a_t) ** 0.5 * eps
+
+    # ---- reverse: t = 981, 961, 941 -> t - 20
+    outs = solver.ddim_loop(lat.cuda(), 3, is_forward=False, guidance_scale=g)
+    x = lat.clone()
+    for t in ts[:3]:
+        e2 = U.unet_forward(sd, ocfg, torch.cat([x, x]).half().float(), t, ctx2).half().float()
+        eps = e2[:B] + g * (e2[B:] - e2[:B])
+        x = ddim_update(x.double(), eps.double(), t, t - 20).float()
+    e_rev = rel_l2(outs[-1], x)
+    # ---- forward (inversion): t = 1, 21, 41, stepping from t - 20 up to t, guidance 1 (cond prediction only)
+    outs_f = solver.ddim_loop(lat.cuda(), 3, is_forward=True, guidance_scale=1)
+    x = lat.clone()
+    for t in ts[::-1][:3]:
+        e2 = U.unet_forward(sd, ocfg, torch.cat([x, x]).half().float(), t, ctx2).half().float()
+        eps = e2[:B] + 1.0 * (e2[B:] - e2[:B])
+        x = ddim_update(x.double(), eps.double(), min(t - 20, 999), t).float()
+    e_fwd = rel_l2(outs_f[-1], x)
+    print(f"[sd15 DDIM baseline] reverse (CFG 7.5, 3 steps) rel-L2 = {e_rev:.3e}  forward (3 steps) = {e_fwd:.3e}")
+    assert len(outs) == len(outs_f) == 4
+    assert e_rev < 3e-3 and e_fwd < 2e-3

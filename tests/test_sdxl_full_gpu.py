@@ -172,4 +172,6 @@ def test_fused_query_projection_cross_attention_inside_the_unet(sdxl):
     assert fam["xattn_fused"]["launches"] == 70                  # every cross-attention layer of SDXL took the fused kernel
     e = rel_l2(fused, base)
     print(f"[sdxl fused xattn in the executor] rel-L2 vs two launches = {e:.3e}")
-    assert torch.isfinite(fused).all() and e < 1e-3
+    # two fp16 evaluation orders of the same graph: their distance is bounded by the fp16 floor of the graph (2.0-2.6e-3 at
+    # this width, see test_unet_gpu), measured 0.9-1.0e-3
+    assert torch.isfinite(fused).all() and e < 2e-3

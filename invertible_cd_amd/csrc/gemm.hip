@@ -538,7 +538,33 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_kernel(GemmK p) {
                 const int item = pass * NT + tid;
                 const int r = item >> 4, c8 = (item & 15) * 8;
                 const int m = m0 + h * 64 + r, n = n0 + c8;
-                if (m >= p.M || n >= p.N) continue;
+                const bool ok = m < p.M && n < p.N;
+                if (p.rowstat) {                 // row statistics of the output: every lane takes part (quad reductions)
+                    f16x8 o = {0, 0, 0, 0, 0, 0, 0, 0};
+                    if (ok) {
+                        const float* sp = stage + r * EPI_LD + c8;
+                        f32x4 v0 = *reinterpret_cast<const f32x4*>(sp), v1 = *reinterpret_cast<const f32x4*>(sp + 4);
+                        float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] *= p.alpha;
+                        if (p.ln_stats) ln_correct8(v, p.ln_stats, p.ln_s, m, n);
+                        if (p.bias)
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] += p.bias[n + e];
+                        if (p.rowbias)
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] += (float)p.rowbias[(long long)(m / p.rps) * p.ld_rowbias + n + e];
+                        if (p.resid)
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] += (float)p.resid[(long long)m * p.ldr + n + e];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o[e] = (half_t)v[e];
+                        *reinterpret_cast<f16x8*>(reinterpret_cast<half_t*>(p.out) + o_off + (long long)m * p.ldo + n) = o;
+                    }
+                    emit_rowstat(p.rowstat, p.M, o, m, n, ok, l);
+                    continue;
+                }
+                if (!ok) continue;
                 const float* sp = stage + r * EPI_LD + c8;
                 f32x4 v0 = *reinterpret_cast<const f32x4*>(sp), v1 = *reinterpret_cast<const f32x4*>(sp + 4);
                 float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
@@ -742,6 +768,10 @@ extern "C" int icd_gemm(const icd_gemm_desc* d, void* stream) {
     k.timeline = g_timeline;
     k.gm = g_group_m > 0 ? g_group_m : 1;        // the planner widens it below for launches with many n-tiles
     k.ln_stats = d->ln_stats; k.ln_s = d->ln_colsum;
+    k.rowstat = d->rowstat_out;
+    ICD_CHECK_ARG(!(d->rowstat_out && (d->mode != 0 || d->batch > 1 || d->N % 32 != 0 || d->xattn_k ||
+                                       (d->flags & (ICD_GEMM_GEGLU | ICD_GEMM_OUT_TRANS | ICD_GEMM_OUT_F32 | ICD_GEMM_RESID_F32)))),
+                  "icd_gemm: rowstat_out needs a dense, unbatched GEMM with plain fp16 output and N %% 32 == 0");
     ICD_CHECK_ARG((d->ln_stats == nullptr) == (d->ln_colsum == nullptr), "icd_gemm: ln_stats and ln_colsum go together");
     ICD_CHECK_ARG(!(d->ln_stats && (d->mode != 0 || (d->batch > 1) || (d->flags & ICD_GEMM_OUT_F32))),
                   "icd_gemm: the fused LayerNorm applies to dense, unbatched, fp16-output GEMMs");
@@ -770,7 +800,7 @@ extern "C" int icd_gemm(const icd_gemm_desc* d, void* stream) {
         return big ? launch<0, false, 4, 3, true>(k, 1, (hipStream_t)stream) : launch<0, false, 2, 2, true>(k, 1, (hipStream_t)stream);
     }
     int wm = 2, ks = 1;
-    const bool allow_split = !trans && !geglu && batch == 1 && d->splitk_ws != nullptr && d->splitk_ws_bytes > 0;
+    const bool allow_split = !trans && !geglu && batch == 1 && d->splitk_ws != nullptr && d->splitk_ws_bytes > 0 && !d->rowstat_out;
     const int nk_total = (d->K + BK - 1) / BK;
     hipStream_t st = (hipStream_t)stream;
     // ---- high-intensity tiles (gemm_big.hip), chosen from BIG_TILES by the cost model below ------------------------

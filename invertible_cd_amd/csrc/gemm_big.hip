@@ -21,7 +21,7 @@ namespace {
 constexpr int enc_vmcnt(int n) { return ((n >> 4) << 14) | 0x0F70 | (n & 15); }
 
 template <int MODE, int WM, int WN, int TM, int TN>
-__global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 1 : 2) void gemm_big_kernel(GemmK p) {
+__global__ __launch_bounds__(WM * WN * 64, 2) void gemm_big_kernel(GemmK p) {
     constexpr int NT = WM * WN * 64;
     constexpr int BM = WM * TM * 32, BNt = WN * TN * 32;
     constexpr int A_BYTES = BM * 128, W_BYTES = BNt * 128, STAGE_BYTES = A_BYTES + W_BYTES;
@@ -190,8 +190,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 1 : 2) void gemm_big_k
     load_frags(I0{}, I0{}, I0{});
 
     // register double-buffering of the fragments only where the accumulators leave room (128 x 64 wave tile)
-    // ... or where a 4-wave block has the whole 512-entry register file of its SIMD to itself (256 x 160 tile)
-    constexpr bool DBUF = TM * TN <= 8 || WM * WN == 4;
+    constexpr bool DBUF = TM * TN <= 8;
     auto k_tile = [&](auto st_tag, int t) {
         constexpr int ST = decltype(st_tag)::value;
         using STt = std::integral_constant<int, ST>;
@@ -270,8 +269,6 @@ int launch_big(const GemmK& k, int cfg, hipStream_t st) {
         return conv ? launch_one<1, 2, 4, 3, 2>(k, st) : launch_one<0, 2, 4, 3, 2>(k, st);
     case 3:   // 128 x 320: 4 x 2 waves of 32 x 160
         return conv ? launch_one<1, 4, 2, 1, 5>(k, st) : launch_one<0, 4, 2, 1, 5>(k, st);
-    case 4:   // 256 x 160: 4 x 1 waves of 64 x 160, one wave per SIMD - exactly 256 tiles for M = 8192, N = 1280
-        return conv ? launch_one<1, 4, 1, 2, 5>(k, st) : launch_one<0, 4, 1, 2, 5>(k, st);
     }
     icd_set_error("icd_gemm: unknown big-tile configuration %d", cfg);
     return ICD_ERR_INVALID_ARG;

@@ -21,6 +21,7 @@ struct GemmK {
     int gm;                                      // m-tiles per L2 group of the block -> tile map (tile_of_block)
     const float* ln_stats;                       // fused LayerNorm: fp32 [M][2] = (mean, rstd) of the A rows, or null
     const float* ln_s;                           //                  fp32 [N] = row sums of the gamma-scaled weights
+    float* rowstat;                              // icd_gemm_desc.rowstat_out: fp32 [N / 32][M][2] partial LayerNorm statistics, or null
     // cross-attention fused behind the query projection (icd_gemm_desc.xattn_*; gemm.hip xattn_epilogue)
     const half_t* xk; const half_t* xvt;
     int x_nk, x_ldk, x_ldvt; long long x_vt_bs; float x_scale_log2;
@@ -73,23 +74,44 @@ __device__ __forceinline__ void ln_correct8(float (&v)[8], const float* ln_stats
 }
 
 
+// icd_gemm_desc.rowstat_out: the 8 fp16-rounded outputs `o` of row m, columns n .. n+7 (n % 8 == 0) held by this lane; the four
+// lanes of an aligned quad hold the 32 columns of one group.  (sum, centred sum of squares) of the group go to
+// rowstat[(n / 32) * M + m].  Every lane of the wave must call it (cross-lane DPP); `ok` = this lane's outputs exist.
+__device__ __forceinline__ float quad_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
+    return v;
+}
+__device__ __forceinline__ void emit_rowstat(float* rowstat, int M, const f16x8& o, int m, int n, bool ok, int lane) {
+    float x[8], s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { x[e] = ok ? (float)o[e] : 0.f; s += x[e]; }
+    s = quad_sum(s);
+    const float mu = s * (1.f / 32.f);
+    float q = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const float dlt = x[e] - mu; q += dlt * dlt; }
+    q = quad_sum(q);
+    if (ok && (lane & 3) == 0) *reinterpret_cast<f32x2*>(rowstat + 2 * ((long long)(n >> 5) * M + m)) = (f32x2){s, q};
+}
+
 // gemm_big.hip tile configurations and their measured cost (tools/gemm_bench.py with forced configurations, one box):
 // one launch costs rounds x (k-tiles x tk + fixed) where a block owns its CU (1 block / CU), tk = one k-tile of one
 // block and fixed = prologue + exposed epilogue, both in units of one k-tile of a 256 x 256 block on a partly filled
 // chip (about 1.3 - 1.7 us depending on the box's clocks).  tk_full applies when >= 200 CUs are busy (chip-level
 // ceiling: the same block runs about 10 - 20 % slower), tk_part when <= 160.
 struct BigTile { int bm, bn; bool geglu_ok; double tk_part, tk_full, fixed; };
-constexpr int NUM_BIG_TILES = 5;
+constexpr int NUM_BIG_TILES = 4;
 constexpr BigTile BIG_TILES[NUM_BIG_TILES] = {
     {256, 256, true, 1.00, 1.08, 9.5},
     {256, 320, false, 1.07, 1.30, 15.3},
     {192, 256, true, 0.70, 0.76, 9.6},
     {128, 320, false, 0.72, 0.80, 7.2},
-    {256, 160, false, 9.70, 9.80, 9.0},       // forced-only until calibrated
 };
-// Two further configurations were built, measured and removed in round 2 (tools/gemm_timeline.py): a
-// generated hand-scheduled 4-wave 128 x 128 main loop and a 256 x 128 x 32 tile with two co-resident blocks per CU.  Neither
-// is faster: under a full-chip launch every tile family delivers the same ~4 TFLOP/s per CU because the chip is at its
+// Further configurations were built, measured and removed in round 2 (tools/gemm_timeline.py): a
+// generated hand-scheduled 4-wave 128 x 128 main loop, a 256 x 128 x 32 tile with two co-resident blocks per CU, and a 256 x 160
+// tile (exactly 256 blocks for M = 8192, N = 1280) both as 4 waves of 64 x 160 and as 8 waves sharing each wave tile between
+// two k-halves.  None is faster: under a full-chip launch every tile family delivers the same ~4 TFLOP/s per CU because the chip is at its
 // power limit (shader clock 1.3 - 1.7 GHz measured inside the main loop, 2.3 GHz when few CUs are busy).
 int launch_big(const GemmK& k, int cfg, hipStream_t st);     // cfg = index into BIG_TILES
 

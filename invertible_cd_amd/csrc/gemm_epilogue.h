@@ -79,6 +79,7 @@ __device__ __forceinline__ void fast_patch(const GemmK& p, const f32x16& acc0, c
             o[e] = (half_t)a0; o[4 + e] = (half_t)a1;
         }
         if (okl) *reinterpret_cast<f16x8*>(outp + (long long)m * p.ldo + n) = o;
+        if (p.rowstat) emit_rowstat(p.rowstat, p.M, o, m, n, okl, l);       // wave-uniform branch
     }
 }
 

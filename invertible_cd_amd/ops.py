@@ -60,7 +60,7 @@ FORBID_BIG_TILE = 0x200000
 
 
 def gemm(a, w, bias=None, resid=None, rowbias=None, rows_per_sample=0, geglu=False, out=None, alpha=1.0,
-         out_f32=False, debug_flags=0, ln_stats=None, ln_colsum=None):
+         out_f32=False, debug_flags=0, ln_stats=None, ln_colsum=None, rowstat_out=None):
     """out[M, N] = alpha * a[M, K] @ w[N, K]^T (+bias[N] fp32) (+rowbias[m // rps]) (+resid) ; GEGLU halves N.
     ln_stats [M, 2] fp32 + ln_colsum [N] fp32: LayerNorm of `a` fused into the epilogue (w carries gamma, bias carries W beta)."""
     _chk16(a, "a"); _chk16(w, "w")
@@ -87,6 +87,9 @@ def gemm(a, w, bias=None, resid=None, rowbias=None, rows_per_sample=0, geglu=Fal
         assert ln_stats.dtype == torch.float32 and ln_stats.is_contiguous() and tuple(ln_stats.shape) == (M, 2)
         assert ln_colsum.dtype == torch.float32 and ln_colsum.is_contiguous() and ln_colsum.numel() == N
         d.ln_stats, d.ln_colsum = ln_stats.data_ptr(), ln_colsum.data_ptr()
+    if rowstat_out is not None:               # fp32 [N / 32, M, 2]: per-32-column (sum, centred sum of squares) of the output rows
+        assert rowstat_out.dtype == torch.float32 and rowstat_out.is_contiguous() and tuple(rowstat_out.shape) == (n_out // 32, M, 2)
+        d.rowstat_out = rowstat_out.data_ptr()
     ws = _splitk_ws(d, a.device)
     _lib.check(_lib.load().icd_gemm(C.byref(d), _stream()), "icd_gemm")
     return out
@@ -201,6 +204,15 @@ def layernorm_stats(x, eps=1e-5):
     return out
 
 
+def layernorm_stats_finish(partials, C_, eps=1e-5):
+    """(mean, rstd) per row from the partials a producing gemm(..., rowstat_out=) left: fp32 [C/32, rows, 2] -> [rows, 2]."""
+    assert partials.is_cuda and partials.dtype == torch.float32 and partials.is_contiguous() and partials.shape[0] == C_ // 32
+    rows = partials.shape[1]
+    out = torch.empty((rows, 2), device=partials.device, dtype=torch.float32)
+    _lib.check(_lib.load().icd_layernorm_stats_finish(_p(partials), rows, C_, eps, _p(out), _stream()), "icd_layernorm_stats_finish")
+    return out
+
+
 def fold_layernorm(w, gamma, beta, bias=None):
     """Weights of a Linear that consumes LayerNorm(x; gamma, beta): (fp16 W * gamma, fp32 row sums of it, fp32 W beta + bias)."""
     w32 = w.float()
@@ -217,7 +229,7 @@ def softmax_rows(s, cols, ld_p, scale=1.0):
     return p
 
 
-def project_vt(x, w, B, n_tokens, ld_keys, ln_stats=None, ln_colsum=None):
+def project_vt(x, w, B, n_tokens, ld_keys, ln_stats=None, ln_colsum=None, debug_flags=0):
     """V^T[b, c, key] = (x[b*n_tokens + key] @ w^T)[c]  -> [B, N, ld_keys] (pad columns zero)."""
     _chk16(x, "x"); _chk16(w, "w")
     M, K = x.shape
@@ -228,7 +240,7 @@ def project_vt(x, w, B, n_tokens, ld_keys, ln_stats=None, ln_colsum=None):
     d.M, d.N, d.K, d.Nw = M, N, K, N
     d.lda, d.ldw, d.ldo = x.stride(0), w.stride(0), ld_keys
     d.rows_per_sample = n_tokens
-    d.mode, d.batch, d.zdiv, d.alpha, d.flags = 0, 1, 1, 1.0, ICD_GEMM_OUT_TRANS
+    d.mode, d.batch, d.zdiv, d.alpha, d.flags = 0, 1, 1, 1.0, ICD_GEMM_OUT_TRANS | debug_flags
     if ln_stats is not None:
         d.ln_stats, d.ln_colsum = ln_stats.data_ptr(), ln_colsum.data_ptr()
     _lib.check(_lib.load().icd_gemm(C.byref(d), _stream()), "icd_gemm(V^T)")

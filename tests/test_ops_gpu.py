@@ -93,6 +93,61 @@ def test_gemm_big_tile_dense(M, N, K):
     assert rel_l2(outg, val * F.gelu(gate)) < TOL
 
 
+@pytest.mark.parametrize("cfg_i", [0, 1, 2, 3])
+def test_gemm_every_big_tile_configuration(cfg_i):
+    """Each gemm_big.hip configuration forced in turn (ICD_GEMM_TUNE_BIG_CFG): dense with bias + residual on a ragged M, the
+    transposed (V^T) epilogue and a 3x3 conv with time bias."""
+    ops = _ops()
+    flag = (cfg_i + 1) << 24
+    M, N, K = 1000, 1280, 1344                        # N divisible by 256 and 320; 21 k-tiles (odd)
+    a, w = r16(M, K, seed=361), r16(N, K, seed=362, scale=K ** -0.5)
+    bias = torch.randn(N, generator=torch.Generator().manual_seed(363))
+    res = r16(M, N, seed=364)
+    out = ops.gemm(a.cuda(), w.cuda(), bias=bias.cuda(), resid=res.cuda(), debug_flags=flag)
+    assert rel_l2(out, a.float() @ w.float().t() + bias + res.float()) < TOL
+    plain = ops.gemm(a.cuda(), w.cuda(), debug_flags=flag)
+    assert rel_l2(plain, a.float() @ w.float().t()) < TOL
+    # V^T: 4 samples of 256 keys
+    a2 = r16(1024, 320, seed=365)
+    w2 = r16(1280, 320, seed=366, scale=320 ** -0.5)
+    vt = ops.project_vt(a2.cuda(), w2.cuda(), 4, 256, 256, debug_flags=flag)
+    assert rel_l2(vt, (a2.float() @ w2.float().t()).view(4, 256, 1280).transpose(1, 2)) < TOL
+    # conv 3x3, B=2, 16x16, 128 -> 1280 channels
+    x = r16(2, 128, 16, 16, seed=367)
+    wc = r16(1280, 128, 3, 3, seed=368, scale=(9 * 128) ** -0.5)
+    rb = r16(2, 1280, seed=369)
+    oc = ops.conv3x3(to_nhwc(x).cuda(), 2, 16, 16, ops.pack_conv_weight(wc).cuda(), bias.cuda(), rowbias=rb.cuda(), debug_flags=flag)
+    refc = to_nhwc(F.conv2d(x.float(), wc.float(), bias, padding=1) + rb.float()[:, :, None, None])
+    assert rel_l2(oc, refc) < TOL
+
+
+@pytest.mark.parametrize("M,N,K,flags", [(300, 320, 192, 0), (1000, 1280, 1344, 1 << 24), (1000, 1280, 1344, 2 << 24),
+                                         (1000, 1280, 1344, 4 << 24), (512, 640, 640, 0x100000), (200, 96, 64, 0)])
+def test_gemm_leaves_layernorm_statistics_of_its_output(M, N, K, flags):
+    """icd_gemm_desc.rowstat_out: the GEMM that writes the residual stream also leaves (sum, centred sum of squares) per
+    32-column group of every output row; icd_layernorm_stats_finish combines them into the (mean, rstd) that
+    icd_layernorm_stats would compute from a pass over the output.  Rows get a large common offset (mean >> std) to show the
+    centred form does not cancel."""
+    ops = _ops()
+    a, w = r16(M, K, seed=371), r16(N, K, seed=372, scale=K ** -0.5)
+    bias = torch.randn(N, generator=torch.Generator().manual_seed(373)) + 40.0
+    res = r16(M, N, seed=374)
+    part = torch.full((N // 32, M, 2), float("nan"), device="cuda")
+    out = ops.gemm(a.cuda(), w.cuda(), bias=bias.cuda(), resid=res.cuda(), rowstat_out=part, debug_flags=flags)
+    ref_out = ops.gemm(a.cuda(), w.cuda(), bias=bias.cuda(), resid=res.cuda(), debug_flags=flags)
+    assert rel_l2(out, ref_out) < 1e-4            # the by-product does not change the product (it only rules out split-K)
+    o = out.float().view(M, N // 32, 32)
+    assert torch.allclose(part[:, :, 0].t(), o.sum(-1), rtol=1e-5, atol=1e-3)
+    assert torch.allclose(part[:, :, 1].t(), ((o - o.mean(-1, keepdim=True)) ** 2).sum(-1), rtol=1e-4, atol=1e-3)
+    st = ops.layernorm_stats_finish(part, N)
+    st_ref = ops.layernorm_stats(out)
+    o64 = out.double()
+    assert torch.allclose(st[:, 0].double(), o64.mean(-1), rtol=1e-6, atol=1e-5)
+    rstd = (o64.var(-1, unbiased=False) + 1e-5).rsqrt()
+    assert ((st[:, 1].double() - rstd).abs() / rstd).max() < 1e-5
+    assert ((st_ref[:, 1].double() - rstd).abs() / rstd).max() < 1e-5
+
+
 @pytest.mark.parametrize("cfg", [
     dict(B=1, H=16, W=16, C0=128, C1=0, Co=256, stride=1, up=False),
     dict(B=2, H=16, W=16, C0=64, C1=64, Co=256, stride=1, up=False),

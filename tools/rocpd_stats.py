@@ -60,5 +60,22 @@ def main(path):
         print(f"{f:110s} {x[0]:7d} {x[1] / 1e6:10.3f} {x[1] / x[0] / 1e3:10.2f} {100 * x[1] / total:6.2f}")
 
 
+    # idle time between consecutive kernels of the product library (start[i+1] - end[i], overlaps count as 0), restricted to the
+    # steady region: pairs whose gap is < 50 us (longer gaps are host-side pauses between steps / phases of the script)
+    ours = sorted((s_, e_, short(n)) for n, s_, e_ in rows if re.search(r"gemm|attn|gn_|layernorm|conv_out|x0_step|sinusoid|silu|geglu|softmax|upsample|embed", n))
+    gaps, busy = [], 0
+    for (s0, e0, _), (s1, e1, _) in zip(ours, ours[1:]):
+        g = s1 - e0
+        if g < 50_000:
+            gaps.append(max(g, 0)); busy += e1 - s1
+    if gaps:
+        gaps.sort()
+        tot = sum(gaps)
+        print()
+        print(f"# inter-kernel gaps (consecutive product kernels, gaps < 50 us): {len(gaps)} pairs, mean {tot / len(gaps) / 1e3:.2f} us, "
+              f"median {gaps[len(gaps) // 2] / 1e3:.2f} us, p90 {gaps[int(len(gaps) * 0.9)] / 1e3:.2f} us; idle {tot / 1e6:.2f} ms beside "
+              f"{busy / 1e6:.2f} ms of kernels = {100 * tot / (tot + busy):.1f} % of the stream")
+
+
 if __name__ == "__main__":
     main(sys.argv[1])

@@ -51,6 +51,9 @@ int icd_version(void);
 #define ICD_GEMM_OUT_F32    2   /* out is float (attention scores before softmax)                                   */
 #define ICD_GEMM_OUT_TRANS  4   /* out[(b*N + n)*ldo + (m % rows_per_sample)], b = m / rows_per_sample  (V^T)      */
 #define ICD_GEMM_RESID_F32 16   /* resid is float [M, ldr] (fp32 residual stream of the fp32-fidelity VAE path)             */
+#define ICD_GEMM_LN_COMPUTE 32  /* ln_stats is an OUTPUT: this launch also computes the (mean, rstd) of A's rows (eps = ln_eps) - */
+                                /* from the MFMA operand fragments of its own main loop where the tile kernel allows (no pass  */
+                                /* over A, no extra launch), else with an icd_layernorm_stats launch first (needs lda == K)     */
 #define ICD_GEMM_PAD_HI     8   /* conv: zero padding on the bottom / right edge only (AutoencoderKL Downsample2D:  */
                                 /* F.pad(x, (0,1,0,1)) + conv3x3 stride 2 pad 0), instead of ksize/2 on every side   */
 
@@ -60,6 +63,7 @@ int icd_version(void);
 #define ICD_GEMM_TUNE_WM4        0x00080000   /* 256x128 tile, no split-K                                            */
 #define ICD_GEMM_TUNE_FORCE_BIG  0x00100000   /* take a 256-wide tile (gemm_big.hip) whatever the chip fill           */
 #define ICD_GEMM_TUNE_NO_BIG     0x00200000   /* never take one                                                      */
+#define ICD_GEMM_TUNE_NO_LN_INLINE 0x00800000 /* ICD_GEMM_LN_COMPUTE: always take the separate statistics launch (A/B)        */
 #define ICD_GEMM_TUNE_BN256      0x00400000   /* big tiles: only the BN = 256 shapes                                 */
 #define ICD_GEMM_TUNE_BIG_CFG(i) (((i) + 1) << 24)   /* force big-tile configuration i (0..3, see gemm_common.h)      */
 
@@ -96,7 +100,7 @@ typedef struct {
      * the gamma-scaled W; the epilogue computes  rstd_m * (alpha * (A W^T)[m][n] - mean_m * ln_colsum[n]) + bias[n] ...
      * with (W beta + original bias) passed as `bias`.  Exactly LN(A) W^T + bias in real arithmetic; the normalised
      * activation is never written.  Both NULL: plain GEMM.  Dense (mode 0), batch 1, fp16 output only. */
-    const float* ln_stats;
+    const float* ln_stats;    /* written, not read, under ICD_GEMM_LN_COMPUTE (valid for later launches on the same stream) */
     const float* ln_colsum;
     /* Cross-attention fused behind the query projection (the north-star kernel; replaces to_q -> baddbmm -> softmax -> bmm
      * of utils/p2p.py:321-342 on layers whose controller does not need the probabilities).  When xattn_k is set, A W^T
@@ -110,13 +114,7 @@ typedef struct {
     int32_t xattn_nk, xattn_ldk, xattn_ldvt;
     int64_t xattn_vt_bs;
     float xattn_scale;
-    /* LayerNorm statistics of the OUTPUT rows as a by-product of the epilogue that writes them (the residual stream of a
-     * BasicTransformerBlock is written by proj_in / to_out / ff.net.2 and read next by a LayerNorm): when set, the launch also
-     * stores, for every output row m and every 32-column group g, the pair (sum, centred sum of squares) of the fp16-rounded
-     * outputs of that group into rowstat_out[(g * M + m) * 2 ..] (fp32, [N / 32][M][2]); icd_layernorm_stats_finish combines the
-     * groups into (mean, rstd) - no pass over the activation.  Needs N %% 32 == 0, dense mode, batch 1, plain fp16 output
-     * (no GEGLU / transposed / fp32 output); such a launch never uses split-K. */
-    float* rowstat_out;
+    float ln_eps;             /* ICD_GEMM_LN_COMPUTE: epsilon of the LayerNorm (0 -> 1e-5) */
 } icd_gemm_desc;
 
 int icd_gemm(const icd_gemm_desc* d, void* stream);
@@ -150,10 +148,6 @@ int icd_layernorm(const void* x, int64_t rows, int32_t C, const float* gamma, co
 /* Statistics half of LayerNorm: stats[r] = (mean, 1/sqrt(var + eps)) of row r (fp32 [rows][2], exact two-pass variance);
  * the normalisation itself is applied by the consuming GEMM (icd_gemm_desc.ln_stats). */
 int icd_layernorm_stats(const void* x, int64_t rows, int32_t C, float eps, float* stats, void* stream);
-/* Same statistics from the per-32-column partials a producing GEMM left behind (icd_gemm_desc.rowstat_out, fp32
- * [C / 32][rows][2] = (sum, centred sum of squares) per group): groups are combined with the pairwise (Chan) update, so the
- * variance is as stable as the two-pass form.  C %% 32 == 0. */
-int icd_layernorm_stats_finish(const float* partials, int64_t rows, int32_t C, float eps, float* stats, void* stream);
 
 /* Row softmax: P[r, 0:cols] = softmax(scale * S[r, 0:cols]) (fp32 in, fp16 out, pad columns [cols, ld) zeroed).
  * Replaces Attention.get_attention_scores' softmax (utils/p2p.py:335). */
@@ -354,11 +348,10 @@ int icd_debug_gemm_group_m(int32_t gm);
  * controller asking for the probabilities) as ONE launch (icd_gemm_desc.xattn_*) instead of projection + attention.  Off by
  * default (measured slower at the SDXL sizes); results differ only by the fp16 rounding of q. */
 int icd_set_xattn_fusion(int32_t on);
-/* 1 (default): the executor takes every LayerNorm's statistics from the producing GEMM's epilogue (icd_gemm_desc.rowstat_out +
- * icd_layernorm_stats_finish).  0: a pass over the residual stream instead (icd_layernorm_stats; the producers may then use
- * split-K, so results move by fp16 re-rounding).  2: the producers still emit (same GEMM plans as 1) but the pass is used -
- * isolates the statistics themselves for tests. */
-int icd_set_ln_producer_stats(int32_t on);
+/* 1 (default): the first GEMM behind every LayerNorm of the executor computes the statistics itself (ICD_GEMM_LN_COMPUTE).
+ * 0: a separate icd_layernorm_stats pass over the residual stream before it.  A/B and tests; results agree to ~1e-6 in the
+ * statistics. */
+int icd_set_ln_inline_stats(int32_t on);
 
 #ifdef __cplusplus
 }

@@ -14,6 +14,7 @@ ICD_GEMM_OUT_F32 = 2
 ICD_GEMM_OUT_TRANS = 4
 ICD_GEMM_PAD_HI = 8
 ICD_GEMM_RESID_F32 = 16
+ICD_GEMM_LN_COMPUTE = 32
 ICD_HOOK_QUERY = 0
 ICD_HOOK_PROBS = 1
 
@@ -33,7 +34,7 @@ class GemmDesc(C.Structure):
         ("ln_stats", C.c_void_p), ("ln_colsum", C.c_void_p),
         ("xattn_k", C.c_void_p), ("xattn_vt", C.c_void_p), ("xattn_nk", C.c_int32), ("xattn_ldk", C.c_int32),
         ("xattn_ldvt", C.c_int32), ("xattn_vt_bs", C.c_int64), ("xattn_scale", C.c_float),
-        ("rowstat_out", C.c_void_p),
+        ("ln_eps", C.c_float),
     ]
 
 
@@ -88,7 +89,6 @@ SIGNATURES = {
     "icd_absmax": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "icd_split_cast": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]),
     "icd_layernorm_stats": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]),
-    "icd_layernorm_stats_finish": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]),
     "icd_softmax_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_int32,
                                    C.c_void_p]),
     "icd_attention_fused": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
@@ -125,7 +125,7 @@ SIGNATURES = {
     "icd_debug_gemm_timeline": (C.c_int, [C.c_void_p]),
     "icd_debug_gemm_group_m": (C.c_int, [C.c_int32]),
     "icd_set_xattn_fusion": (C.c_int, [C.c_int32]),
-    "icd_set_ln_producer_stats": (C.c_int, [C.c_int32]),
+    "icd_set_ln_inline_stats": (C.c_int, [C.c_int32]),
     "icd_profile_enable": (C.c_int, [C.c_int32]),
     "icd_profile_read": (C.c_int, [C.POINTER(ProfileRow), C.c_int32]),
     "icd_profile_dump": (C.c_int, [C.POINTER(ProfileRecord), C.c_int32]),

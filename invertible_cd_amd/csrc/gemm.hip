@@ -538,33 +538,7 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_kernel(GemmK p) {
                 const int item = pass * NT + tid;
                 const int r = item >> 4, c8 = (item & 15) * 8;
                 const int m = m0 + h * 64 + r, n = n0 + c8;
-                const bool ok = m < p.M && n < p.N;
-                if (p.rowstat) {                 // row statistics of the output: every lane takes part (quad reductions)
-                    f16x8 o = {0, 0, 0, 0, 0, 0, 0, 0};
-                    if (ok) {
-                        const float* sp = stage + r * EPI_LD + c8;
-                        f32x4 v0 = *reinterpret_cast<const f32x4*>(sp), v1 = *reinterpret_cast<const f32x4*>(sp + 4);
-                        float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] *= p.alpha;
-                        if (p.ln_stats) ln_correct8(v, p.ln_stats, p.ln_s, m, n);
-                        if (p.bias)
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) v[e] += p.bias[n + e];
-                        if (p.rowbias)
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) v[e] += (float)p.rowbias[(long long)(m / p.rps) * p.ld_rowbias + n + e];
-                        if (p.resid)
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) v[e] += (float)p.resid[(long long)m * p.ldr + n + e];
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) o[e] = (half_t)v[e];
-                        *reinterpret_cast<f16x8*>(reinterpret_cast<half_t*>(p.out) + o_off + (long long)m * p.ldo + n) = o;
-                    }
-                    emit_rowstat(p.rowstat, p.M, o, m, n, ok, l);
-                    continue;
-                }
-                if (!ok) continue;
+                if (m >= p.M || n >= p.N) continue;
                 const float* sp = stage + r * EPI_LD + c8;
                 f32x4 v0 = *reinterpret_cast<const f32x4*>(sp), v1 = *reinterpret_cast<const f32x4*>(sp + 4);
                 float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
@@ -768,10 +742,15 @@ extern "C" int icd_gemm(const icd_gemm_desc* d, void* stream) {
     k.timeline = g_timeline;
     k.gm = g_group_m > 0 ? g_group_m : 1;        // the planner widens it below for launches with many n-tiles
     k.ln_stats = d->ln_stats; k.ln_s = d->ln_colsum;
-    k.rowstat = d->rowstat_out;
-    ICD_CHECK_ARG(!(d->rowstat_out && (d->mode != 0 || d->batch > 1 || d->N % 32 != 0 || d->xattn_k ||
-                                       (d->flags & (ICD_GEMM_GEGLU | ICD_GEMM_OUT_TRANS | ICD_GEMM_OUT_F32 | ICD_GEMM_RESID_F32)))),
-                  "icd_gemm: rowstat_out needs a dense, unbatched GEMM with plain fp16 output and N %% 32 == 0");
+    k.ln_stats_w = nullptr; k.ln_eps = d->ln_eps > 0.f ? d->ln_eps : 1e-5f;
+    // ICD_GEMM_LN_COMPUTE: the big tiles compute the statistics in their main loop; every other path runs the statistics launch
+    const bool ln_compute = (d->flags & ICD_GEMM_LN_COMPUTE) != 0;
+    ICD_CHECK_ARG(!ln_compute || d->ln_stats, "icd_gemm: ICD_GEMM_LN_COMPUTE needs the ln_stats buffer (and ln_colsum)");
+    auto ln_stats_launch = [&]() -> int {
+        if (!ln_compute) return ICD_OK;
+        ICD_CHECK_ARG(d->lda == d->K, "icd_gemm: ICD_GEMM_LN_COMPUTE on this path needs contiguous rows (lda == K)");
+        return icd_layernorm_stats(d->a0, d->M, d->K, k.ln_eps, const_cast<float*>(d->ln_stats), stream);
+    };
     ICD_CHECK_ARG((d->ln_stats == nullptr) == (d->ln_colsum == nullptr), "icd_gemm: ln_stats and ln_colsum go together");
     ICD_CHECK_ARG(!(d->ln_stats && (d->mode != 0 || (d->batch > 1) || (d->flags & ICD_GEMM_OUT_F32))),
                   "icd_gemm: the fused LayerNorm applies to dense, unbatched, fp16-output GEMMs");
@@ -797,10 +776,11 @@ extern "C" int icd_gemm(const icd_gemm_desc* d, void* stream) {
         const bool big = g_xattn_tile == 4;
         k.nbm = d->M / (big ? 256 : 128); k.nbn = d->N / 128;
         if (g_group_m <= 0 && k.nbn >= 16) k.gm = 8;
+        { const int rc = ln_stats_launch(); if (rc != ICD_OK) return rc; }
         return big ? launch<0, false, 4, 3, true>(k, 1, (hipStream_t)stream) : launch<0, false, 2, 2, true>(k, 1, (hipStream_t)stream);
     }
     int wm = 2, ks = 1;
-    const bool allow_split = !trans && !geglu && batch == 1 && d->splitk_ws != nullptr && d->splitk_ws_bytes > 0 && !d->rowstat_out;
+    const bool allow_split = !trans && !geglu && batch == 1 && d->splitk_ws != nullptr && d->splitk_ws_bytes > 0;
     const int nk_total = (d->K + BK - 1) / BK;
     hipStream_t st = (hipStream_t)stream;
     // ---- high-intensity tiles (gemm_big.hip), chosen from BIG_TILES by the cost model below ------------------------
@@ -855,12 +835,22 @@ extern "C" int icd_gemm(const icd_gemm_desc* d, void* stream) {
                 k.ksize = 0; k.Hout = 0;
                 ICD_CHECK_ARG(d->lda % 8 == 0, "icd_gemm: lda must be a multiple of 8");
             }
+            if (ln_compute) {
+                // every n-tile recomputes the statistics of its rows (a few % of its main loop): free up to ~10 n-tiles (to_q / to_qk:
+                // 65.1 vs 65.7 us at 8192 x 2560 x 1280), dearer than the 8 us statistics launch on the 40 n-tiles of a GEGLU
+                // projection (243.9 vs 229.5 + 8)
+                const bool inline_ok = d->mode == 0 && k.ksplit == 1 && !trans && !(d->flags & (ICD_GEMM_OUT_F32 | ICD_GEMM_RESID_F32)) &&
+                                       !(d->flags & ICD_GEMM_TUNE_NO_LN_INLINE) && k.nbn <= 12;
+                if (inline_ok) k.ln_stats_w = const_cast<float*>(d->ln_stats);
+                else { const int rc0 = ln_stats_launch(); if (rc0 != ICD_OK) return rc0; }
+            }
             const int rc = launch_big(k, cfg, st);
             if (rc != ICD_OK) return rc;
             if (k.ksplit > 1) return launch_reduce(k, st);
             return ICD_OK;
         }
     }
+    { const int rc = ln_stats_launch(); if (rc != ICD_OK) return rc; }
     plan_gemm(d->M, d->N, d->K, batch, allow_split, d->splitk_ws_bytes, &wm, &ks);
     if (d->flags & ICD_GEMM_TUNE_WM2) { wm = 2; ks = 1; }          // tuning overrides (tools/gemm_bench.py)
     if (d->flags & ICD_GEMM_TUNE_WM4) { wm = 4; ks = 1; }

@@ -27,6 +27,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_big_kernel(GemmK p) {
     constexpr int A_BYTES = BM * 128, W_BYTES = BNt * 128, STAGE_BYTES = A_BYTES + W_BYTES;
     constexpr int NAJ = BM * 8 / NT, NWJ = BNt * 8 / NT;        // 16-B chunks per thread per stage
     constexpr int LOADS = NAJ + NWJ;
+    constexpr int LN_TABLE_OFF = 96 * 1024;                     // past the epilogue's staging patches (8 x 9 KiB), inside the stage buffers
+    static_assert(LN_TABLE_OFF + (1 + WN) * BM * 8 <= 2 * STAGE_BYTES, "LayerNorm table does not fit");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, wv = tid >> 6, l = tid & 63;
     const int wm = wv / WN, wn = wv - wm * WN;
@@ -161,6 +163,14 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_big_kernel(GemmK p) {
             }
     }
     f16x8 af[2][TM], wf[2][TN];               // set 1 is unused (and dead-code eliminated) without DBUF
+    // LayerNorm statistics of the A rows, in-kernel (p.ln_stats_w): the WN waves of a tile row see every element of their rows go
+    // by as MFMA operands (K = the LayerNorm width) and share the work - wave wn sums the k sub-steps s4 with s4 % WN == wn;
+    // lane (lr, lh) covers the k-columns it holds, v_dot2_f32_f16 with fp32 accumulate.  (All of it on the waves of column 0 made
+    // them the block's critical path: +10 % on a 40-n-tile GEGLU launch.)
+    const bool stat_on = MODE == 0 && p.ln_stats_w != nullptr;
+    float st_s[TM], st_q[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) { st_s[i] = 0.f; st_q[i] = 0.f; }
     auto load_frags = [&](auto st_tag, auto s_tag, auto set_tag) {
         constexpr int ST = decltype(st_tag)::value, S4 = decltype(s_tag)::value, SET = decltype(set_tag)::value;
 #pragma unroll
@@ -168,8 +178,20 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_big_kernel(GemmK p) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) wf[SET][j] = *reinterpret_cast<const f16x8*>(smem + rd_w[ST][S4] + j * 4096);
     };
-    auto mfmas = [&](auto set_tag) {
-        constexpr int SET = decltype(set_tag)::value;
+    auto mfmas = [&](auto set_tag, auto sub_tag) {
+        constexpr int SET = decltype(set_tag)::value, S4 = decltype(sub_tag)::value;
+        if (stat_on && (S4 % WN) == wn) {        // (slipping the dots in between the MFMAs makes hipcc spill hundreds of registers)
+            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+            const h2 one = {(_Float16)1.f, (_Float16)1.f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const h2 v = {af[SET][i][2 * e], af[SET][i][2 * e + 1]};
+                    st_s[i] = __builtin_amdgcn_fdot2(v, one, st_s[i], false);
+                    st_q[i] = __builtin_amdgcn_fdot2(v, v, st_q[i], false);
+                }
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -198,23 +220,23 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_big_kernel(GemmK p) {
         if (DBUF) {
             load_frags(STt{}, I1{}, I1{});
             __builtin_amdgcn_sched_barrier(0);
-            mfmas(I0{});
+            mfmas(I0{}, I0{});
             load_frags(STt{}, I2{}, I0{});
             __builtin_amdgcn_sched_barrier(0);
-            mfmas(I1{});
+            mfmas(I1{}, I1{});
             load_frags(STt{}, I3{}, I1{});
             __builtin_amdgcn_sched_barrier(0);
-            mfmas(I0{});
+            mfmas(I0{}, I2{});
             __builtin_amdgcn_sched_barrier(0);
-            mfmas(I1{});                         // last sub-step: its MFMAs are queued on the matrix pipe ...
+            mfmas(I1{}, I3{});                   // last sub-step: its MFMAs are queued on the matrix pipe ...
         } else {
-            mfmas(I0{});
+            mfmas(I0{}, I0{});
             load_frags(STt{}, I1{}, I0{});
-            mfmas(I0{});
+            mfmas(I0{}, I1{});
             load_frags(STt{}, I2{}, I0{});
-            mfmas(I0{});
+            mfmas(I0{}, I2{});
             load_frags(STt{}, I3{}, I0{});
-            mfmas(I0{});
+            mfmas(I0{}, I3{});
         }
         __builtin_amdgcn_sched_barrier(0);
         if (t + 1 < nk) {                        // ... and in their shadow: hand over to the next k-tile
@@ -230,9 +252,42 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_big_kernel(GemmK p) {
     }
 
     if (tl && tid == 0) tl[5] = __builtin_amdgcn_s_memtime();        // shader-clock ticks of the main loop (clock = ticks / time)
+    const float* ln_lds = nullptr;
+    if (stat_on) {
+        // per-wave partial sums -> LDS (behind the epilogue's staging patches), summed over the WN waves of the tile row in a fixed
+        // order; (mean, rstd) of the block's rows -> an LDS table for the epilogue, and to memory by n-tile 0 (a later GEMM
+        // normalised by the same LayerNorm reads them there)
+        float* table = reinterpret_cast<float*>(smem + LN_TABLE_OFF);
+        float* parts = table + 2 * BM;                                     // [WN][BM][2]
+        __syncthreads();                         // every wave is done with the stage buffers
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const float s_ = st_s[i] + __shfl_xor(st_s[i], 32), q_ = st_q[i] + __shfl_xor(st_q[i], 32);
+            if (lh == 0) *reinterpret_cast<f32x2*>(parts + 2 * (wn * BM + (wm * TM + i) * 32 + lr)) = (f32x2){s_, q_};
+        }
+        __syncthreads();
+        if (wn == 0 && lh == 0) {
+            const float inv_k = 1.f / (float)p.K;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int row = (wm * TM + i) * 32 + lr;
+                float s_ = 0.f, q_ = 0.f;
+#pragma unroll
+                for (int w = 0; w < WN; ++w) {
+                    const f32x2 v = *reinterpret_cast<const f32x2*>(parts + 2 * (w * BM + row));
+                    s_ += v[0]; q_ += v[1];
+                }
+                const float mean = s_ * inv_k, var = fmaxf(q_ * inv_k - mean * mean, 0.f);
+                const float rstd = rsqrtf(var + p.ln_eps);
+                *reinterpret_cast<f32x2*>(table + 2 * row) = (f32x2){mean, rstd};
+                if (nt == 0 && m0 + row < p.M) *reinterpret_cast<f32x2*>(p.ln_stats_w + 2 * (long long)(m0 + row)) = (f32x2){mean, rstd};
+            }
+        }
+        ln_lds = table - 2 * (long long)m0;      // indexed by the global row like p.ln_stats (the epilogue's own barrier publishes it)
+    }
     // ---- epilogue (gemm_epilogue.h): per-wave LDS patches, no block-wide slabs -----------------------------------------
     // (the 256 x 320 conv tile has no registers left for the early-load fast path: 160 accumulators + the im2col loader state)
-    wave_epilogue<TM, TN, !(MODE == 1 && TM * TN > 8)>(p, acc, smem, wv, wm, wn, l, m0, n0, split, tl);
+    wave_epilogue<TM, TN, !(MODE == 1 && TM * TN > 8)>(p, acc, smem, wv, wm, wn, l, m0, n0, split, tl, ln_lds);
     if (tl) {                                    // last wave out writes the end stamp (stores of this wave are issued, not drained)
         __syncthreads();
         if (tid == 0) tl[3] = __builtin_amdgcn_s_memrealtime();

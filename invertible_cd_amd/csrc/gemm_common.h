@@ -21,7 +21,8 @@ struct GemmK {
     int gm;                                      // m-tiles per L2 group of the block -> tile map (tile_of_block)
     const float* ln_stats;                       // fused LayerNorm: fp32 [M][2] = (mean, rstd) of the A rows, or null
     const float* ln_s;                           //                  fp32 [N] = row sums of the gamma-scaled weights
-    float* rowstat;                              // icd_gemm_desc.rowstat_out: fp32 [N / 32][M][2] partial LayerNorm statistics, or null
+    float* ln_stats_w;                           // ICD_GEMM_LN_COMPUTE taken in-kernel: (mean, rstd) of the A rows are computed from the
+    float ln_eps;                                //   fragments in the main loop (gemm_big.hip), used from LDS and stored here by n-tile 0
     // cross-attention fused behind the query projection (icd_gemm_desc.xattn_*; gemm.hip xattn_epilogue)
     const half_t* xk; const half_t* xvt;
     int x_nk, x_ldk, x_ldvt; long long x_vt_bs; float x_scale_log2;
@@ -73,27 +74,6 @@ __device__ __forceinline__ void ln_correct8(float (&v)[8], const float* ln_stats
     }
 }
 
-
-// icd_gemm_desc.rowstat_out: the 8 fp16-rounded outputs `o` of row m, columns n .. n+7 (n % 8 == 0) held by this lane; the four
-// lanes of an aligned quad hold the 32 columns of one group.  (sum, centred sum of squares) of the group go to
-// rowstat[(n / 32) * M + m].  Every lane of the wave must call it (cross-lane DPP); `ok` = this lane's outputs exist.
-__device__ __forceinline__ float quad_sum(float v) {
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
-    return v;
-}
-__device__ __forceinline__ void emit_rowstat(float* rowstat, int M, const f16x8& o, int m, int n, bool ok, int lane) {
-    float x[8], s = 0.f;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { x[e] = ok ? (float)o[e] : 0.f; s += x[e]; }
-    s = quad_sum(s);
-    const float mu = s * (1.f / 32.f);
-    float q = 0.f;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { const float dlt = x[e] - mu; q += dlt * dlt; }
-    q = quad_sum(q);
-    if (ok && (lane & 3) == 0) *reinterpret_cast<f32x2*>(rowstat + 2 * ((long long)(n >> 5) * M + m)) = (f32x2){s, q};
-}
 
 // gemm_big.hip tile configurations and their measured cost (tools/gemm_bench.py with forced configurations, one box):
 // one launch costs rounds x (k-tiles x tk + fixed) where a block owns its CU (1 block / CU), tk = one k-tile of one

@@ -22,7 +22,7 @@ static __device__ __attribute__((aligned(16))) const float icd_epi_ln_id[2] = {0
 // as the output store).  Out-of-range lanes read the neutral page instead of branching around their loads.
 template <int JN, bool R, bool T, bool L, bool PF_ROWBIAS, int PF_PASSES>
 __device__ __forceinline__ void fast_patch(const GemmK& p, const f32x16& acc0, const f32x16& acc1, float* wst, int l, int mrow0,
-                                           int ncol0) {
+                                           int ncol0, const float* ln_lds) {
     constexpr int LDW = 68;
     constexpr int CHS = JN == 2 ? 3 : 2, NPASS = JN == 2 ? 4 : 2;
     const int lr = l & 31, lh = l >> 5;
@@ -47,7 +47,10 @@ __device__ __forceinline__ void fast_patch(const GemmK& p, const f32x16& acc0, c
         const bool okp = m < p.M && ncol_ok;
         if (R) rs[pass] = *reinterpret_cast<const f16x8*>((p.resid && okp) ? p.resid + (long long)m * p.ldr + n : zp);
         if (T && PF_ROWBIAS) rb[pass] = *reinterpret_cast<const f16x8*>((p.rowbias && okp) ? p.rowbias + (long long)(m / p.rps) * p.ld_rowbias + n : zp);
-        if (L) st[pass] = *reinterpret_cast<const f32x2*>((p.ln_stats && okp) ? p.ln_stats + 2 * (long long)m : icd_epi_ln_id);
+        if (L) {                                 // row statistics: from the kernel's own LDS table when it computed them (ln_lds)
+            if (ln_lds) st[pass] = *reinterpret_cast<const f32x2*>(ln_lds + 2 * (long long)m);
+            else st[pass] = *reinterpret_cast<const f32x2*>((p.ln_stats && okp) ? p.ln_stats + 2 * (long long)m : icd_epi_ln_id);
+        }
     }
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -66,7 +69,10 @@ __device__ __forceinline__ void fast_patch(const GemmK& p, const f32x16& acc0, c
         if (T && !PF_ROWBIAS) rb[pass] = *reinterpret_cast<const f16x8*>((p.rowbias && okl) ? p.rowbias + (long long)(m / p.rps) * p.ld_rowbias + n : zp);
         if (pass >= PF_PASSES) {
             if (R) rs[pass] = *reinterpret_cast<const f16x8*>((p.resid && okl) ? p.resid + (long long)m * p.ldr + n : zp);
-            if (L) st[pass] = *reinterpret_cast<const f32x2*>((p.ln_stats && okl) ? p.ln_stats + 2 * (long long)m : icd_epi_ln_id);
+            if (L) {
+                if (ln_lds) st[pass] = *reinterpret_cast<const f32x2*>(ln_lds + 2 * (long long)m);
+                else st[pass] = *reinterpret_cast<const f32x2*>((p.ln_stats && okl) ? p.ln_stats + 2 * (long long)m : icd_epi_ln_id);
+            }
         }
         f16x8 o;
 #pragma unroll
@@ -79,14 +85,13 @@ __device__ __forceinline__ void fast_patch(const GemmK& p, const f32x16& acc0, c
             o[e] = (half_t)a0; o[4 + e] = (half_t)a1;
         }
         if (okl) *reinterpret_cast<f16x8*>(outp + (long long)m * p.ldo + n) = o;
-        if (p.rowstat) emit_rowstat(p.rowstat, p.M, o, m, n, okl, l);       // wave-uniform branch
     }
 }
 
 // All patches of one wave through fast_patch (one operand mix per instantiation).
 template <int TM, int TN, bool R, bool T, bool L>
 __device__ __forceinline__ void wave_epilogue_fast(const GemmK& p, f32x16 (&acc)[TM][TN], float* wst, int wm, int wn, int l, int m0,
-                                                   int n0) {
+                                                   int n0, const float* ln_lds) {
     constexpr bool PF_ROWBIAS = TM * TN <= 8;                    // the 160-accumulator tiles have no registers left for it,
     constexpr int PF_PASSES = TM * TN <= 8 ? 4 : 2;              // and request only the first two passes early
 #pragma unroll
@@ -95,8 +100,8 @@ __device__ __forceinline__ void wave_epilogue_fast(const GemmK& p, f32x16 (&acc)
 #pragma unroll
         for (int j0 = 0; j0 < TN; j0 += 2) {
             const int ncol0 = n0 + (wn * TN + j0) * 32;
-            if (TN - j0 >= 2) fast_patch<2, R, T, L, PF_ROWBIAS, PF_PASSES>(p, acc[i][j0], acc[i][j0 + 1 < TN ? j0 + 1 : j0], wst, l, mrow0, ncol0);
-            else fast_patch<1, R, T, L, PF_ROWBIAS, PF_PASSES>(p, acc[i][j0], acc[i][j0], wst, l, mrow0, ncol0);
+            if (TN - j0 >= 2) fast_patch<2, R, T, L, PF_ROWBIAS, PF_PASSES>(p, acc[i][j0], acc[i][j0 + 1 < TN ? j0 + 1 : j0], wst, l, mrow0, ncol0, ln_lds);
+            else fast_patch<1, R, T, L, PF_ROWBIAS, PF_PASSES>(p, acc[i][j0], acc[i][j0], wst, l, mrow0, ncol0, ln_lds);
         }
     }
 }
@@ -105,7 +110,7 @@ __device__ __forceinline__ void wave_epilogue_fast(const GemmK& p, f32x16 (&acc)
 // whose wave tile is (TM*32) x (TN*32); m0 / n0: origin of the block tile.  All waves of the block must call it.
 template <int TM, int TN, bool FAST_OK = true>
 __device__ __forceinline__ void wave_epilogue(const GemmK& p, f32x16 (&acc)[TM][TN], unsigned char* smem, int wv, int wm, int wn,
-                                              int l, int m0, int n0, int split, unsigned long long* tl) {
+                                              int l, int m0, int n0, int split, unsigned long long* tl, const float* ln_lds = nullptr) {
     const int lr = l & 31, lh = l >> 5;
     const int tid = threadIdx.x;
     const bool geglu = p.flags & ICD_GEMM_GEGLU;
@@ -120,11 +125,11 @@ __device__ __forceinline__ void wave_epilogue(const GemmK& p, f32x16 (&acc)[TM][
     if (FAST_OK && !trans && !geglu && !part && !out_f32 && !(p.flags & ICD_GEMM_RESID_F32)) {
         // fast path of the common epilogue, specialised by which operands exist (wave-uniform switch around the whole wave tile)
         switch ((p.resid ? 1 : 0) | (p.rowbias ? 2 : 0) | (p.ln_stats ? 4 : 0)) {
-            case 0: wave_epilogue_fast<TM, TN, false, false, false>(p, acc, wst, wm, wn, l, m0, n0); break;   // plain / bias only
-            case 1: wave_epilogue_fast<TM, TN, true, false, false>(p, acc, wst, wm, wn, l, m0, n0); break;    // + residual
-            case 2: wave_epilogue_fast<TM, TN, false, true, false>(p, acc, wst, wm, wn, l, m0, n0); break;    // + time bias
-            case 4: wave_epilogue_fast<TM, TN, false, false, true>(p, acc, wst, wm, wn, l, m0, n0); break;    // LayerNorm-folded
-            default: wave_epilogue_fast<TM, TN, true, true, true>(p, acc, wst, wm, wn, l, m0, n0); break;     // other mixes
+            case 0: wave_epilogue_fast<TM, TN, false, false, false>(p, acc, wst, wm, wn, l, m0, n0, ln_lds); break;   // plain / bias only
+            case 1: wave_epilogue_fast<TM, TN, true, false, false>(p, acc, wst, wm, wn, l, m0, n0, ln_lds); break;    // + residual
+            case 2: wave_epilogue_fast<TM, TN, false, true, false>(p, acc, wst, wm, wn, l, m0, n0, ln_lds); break;    // + time bias
+            case 4: wave_epilogue_fast<TM, TN, false, false, true>(p, acc, wst, wm, wn, l, m0, n0, ln_lds); break;    // LayerNorm-folded
+            default: wave_epilogue_fast<TM, TN, true, true, true>(p, acc, wst, wm, wn, l, m0, n0, ln_lds); break;     // other mixes
         }
         return;
     }
@@ -188,7 +193,8 @@ __device__ __forceinline__ void wave_epilogue(const GemmK& p, f32x16 (&acc)[TM][
                 for (int pass = 0; pass < 2; ++pass) {
                     const int m = mrow0 + ((pass * 64 + l) >> 2);
                     const float* lp = (p.ln_stats && m < p.M && ncol_ok) ? p.ln_stats + 2 * (long long)m : icd_epi_ln_id;
-                    g_st[pass] = *reinterpret_cast<const f32x2*>(lp);
+                    if (ln_lds) g_st[pass] = *reinterpret_cast<const f32x2*>(ln_lds + 2 * (long long)m);
+                    else g_st[pass] = *reinterpret_cast<const f32x2*>(lp);
                 }
             }
 #pragma unroll

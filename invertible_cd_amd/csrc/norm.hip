@@ -719,45 +719,6 @@ extern "C" int icd_split_cast(const float* x, int64_t rows, int32_t C, float sca
     return ICD_OK;
 }
 
-// (sum, centred sum of squares) per 32-column group -> (mean, rstd) per row.  8 lanes per row: lane j folds groups j, j+8, ...
-// (independent loads), then the 8 partial aggregates (count, mean, M2) merge pairwise (Chan) in a fixed order - a thread per
-// row with a serial loop over 40 groups is latency-bound at ~15 us for 8192 rows.
-__global__ __launch_bounds__(256) void layernorm_finish_kernel(const float* __restrict__ part, long long rows, int groups, float eps,
-                                                               float* __restrict__ stats) {
-    const long long r = (long long)blockIdx.x * 32 + (threadIdx.x >> 3);
-    const int j = threadIdx.x & 7;
-    const bool live = r < rows;
-    float n = 0.f, mean = 0.f, m2 = 0.f;
-    for (int g = j; g < groups; g += 8) {
-        f32x2 pq = {0.f, 0.f};
-        if (live) pq = *reinterpret_cast<const f32x2*>(part + 2 * ((long long)g * rows + r));
-        const float gm = pq[0] * (1.f / 32.f), dlt = gm - mean, nn = n + 32.f;
-        mean += dlt * (32.f / nn);
-        m2 += pq[1] + dlt * dlt * (n * 32.f / nn);
-        n = nn;
-    }
-#pragma unroll
-    for (int off = 1; off < 8; off <<= 1) {
-        const float nb = __shfl_xor(n, off), mb = __shfl_xor(mean, off), qb = __shfl_xor(m2, off);
-        if (nb > 0.f) {                          // (an empty partner - fewer than 8 groups - merges as a no-op)
-            const float nn = n + nb, dlt = mb - mean, w = nb / nn;
-            mean += dlt * w;
-            m2 += qb + dlt * dlt * n * w;
-            n = nn;
-        }
-    }
-    if (live && j == 0) *reinterpret_cast<f32x2*>(stats + 2 * r) = (f32x2){mean, rsqrtf(m2 / n + eps)};
-}
-
-extern "C" int icd_layernorm_stats_finish(const float* partials, int64_t rows, int32_t C, float eps, float* stats, void* stream) {
-    ICD_CHECK_ARG(partials && stats, "icd_layernorm_stats_finish: null pointer");
-    ICD_CHECK_ARG(C > 0 && C % 32 == 0 && rows > 0, "icd_layernorm_stats_finish: C must be a positive multiple of 32 (got %d)", C);
-    hipLaunchKernelGGL(layernorm_finish_kernel, dim3((unsigned)((rows + 31) / 32)), dim3(256), 0, (hipStream_t)stream, partials,
-                       (long long)rows, C / 32, eps, stats);
-    ICD_CHECK_LAUNCH("icd_layernorm_stats_finish");
-    return ICD_OK;
-}
-
 extern "C" int icd_layernorm_stats(const void* x, int64_t rows, int32_t C, float eps, float* stats, void* stream) {
     ICD_CHECK_ARG(x && stats, "icd_layernorm_stats: null pointer");
     ICD_CHECK_ARG(C > 0 && C % 8 == 0 && C <= 2048, "icd_layernorm_stats: C must be a multiple of 8 and <= 2048 (got %d)", C);

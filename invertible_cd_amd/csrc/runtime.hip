@@ -49,7 +49,7 @@ struct ProfScope {
 // is hosted on the 128-wide tile family, whose main loop is 30 - 40 % slower than the 256-wide tiles the plain projection
 // gets, so at SDXL B = 8 the fused launch (63.8 us) loses to projection (35.4 us) + attention (23.3 us); DESIGN.md section 4.
 bool g_no_xattn_fusion = true;
-int g_rowstat_mode = 1;                     // icd_set_ln_producer_stats: 0 pass over the stream, 1 from the producer, 2 both (pass wins)
+bool g_ln_inline = true;                    // icd_set_ln_inline_stats: the GEMM behind a LayerNorm computes its statistics (ICD_GEMM_LN_COMPUTE)
 
 struct Arena {
     char* base = nullptr;
@@ -167,7 +167,7 @@ struct Exec {
     void gemm_desc(icd_gemm_desc& d) {
         // split-K scratch for small-M / deep-K shapes comes from the arena (accounted for in the dry run too)
         void* ws = nullptr;
-        const bool splittable = (d.batch <= 1) && !(d.flags & (ICD_GEMM_OUT_TRANS | ICD_GEMM_GEGLU)) && !d.rowstat_out;
+        const bool splittable = (d.batch <= 1) && !(d.flags & (ICD_GEMM_OUT_TRANS | ICD_GEMM_GEGLU));
         const long long need = splittable ? icd_gemm_workspace_bytes(d.M, d.N, d.K) : 0;
         if (need > 0) { ws = alloc<char>(need); d.splitk_ws = ws; d.splitk_ws_bytes = need; }
         struct Rel { Exec* e; void* p; ~Rel() { if (p) e->release(p); } } rel{this, ws};
@@ -180,10 +180,10 @@ struct Exec {
     // dense: out[M,N] (ldo) = a[M,K](lda) @ w[N,K]^T + bias + resid
     void linear(const half_t* a, int lda, int M, int K, const half_t* w, int N, const float* bias, const half_t* resid,
                 int ldr, half_t* out, int ldo, int flags = 0, int rps = 0, const float* ln_stats = nullptr,
-                const float* ln_colsum = nullptr, float* rowstat = nullptr) {
+                const float* ln_colsum = nullptr) {
         icd_gemm_desc d; memset(&d, 0, sizeof(d));
         d.a0 = a; d.w = w; d.bias = bias; d.resid = resid; d.out = out;
-        d.ln_stats = ln_stats; d.ln_colsum = ln_colsum; d.rowstat_out = rowstat;
+        d.ln_stats = ln_stats; d.ln_colsum = ln_colsum;
         d.M = M; d.N = N; d.K = K; d.Nw = N; d.lda = lda; d.ldw = K; d.ldo = ldo; d.ldr = ldr;
         d.rows_per_sample = rps; d.mode = 0; d.batch = 1; d.zdiv = 1; d.alpha = 1.f; d.flags = flags;
         gemm_desc(d);
@@ -207,13 +207,11 @@ struct Exec {
         run(icd_groupnorm(x0.p, x0.C, x1 ? x1->p : nullptr, x1 ? x1->C : 0, B, HW, u->cfg.norm_groups, g, b, eps, silu, out, gn_ws, st));
     }
     // LayerNorm statistics only (2 B / element read): the normalisation is applied by the consuming GEMMs' epilogues
-    // `part` != null: the GEMM that wrote x left per-32-column partial statistics behind (icd_gemm_desc.rowstat_out) - combine
-    // them (rows * C / 4 bytes read) instead of reading x again
-    void ln_stats(const half_t* x, long long rows, int C, float* stats, const float* part = nullptr) {
-        if (!ok() || dry) return;
-        ProfScope ps(true, st, ICD_PROF_LAYERNORM, 0.0, part && g_rowstat_mode == 1 ? 0.25 * (double)rows * C : 2.0 * (double)rows * C);
-        if (part && g_rowstat_mode == 1) run(icd_layernorm_stats_finish(part, rows, C, 1e-5f, stats, st));
-        else run(icd_layernorm_stats(x, rows, C, 1e-5f, stats, st));
+    // LayerNorm statistics by a pass over the stream (2 B / element read) - only when the consuming GEMM does not compute them
+    void ln_stats(const half_t* x, long long rows, int C, float* stats) {
+        if (!ok() || dry || g_ln_inline) return;
+        ProfScope ps(true, st, ICD_PROF_LAYERNORM, 0.0, 2.0 * (double)rows * C);
+        run(icd_layernorm_stats(x, rows, C, 1e-5f, stats, st));
     }
 
     // ---------------------------------------------------------------------------------------------- blocks
@@ -310,10 +308,10 @@ struct Exec {
         half_t* n = alloc<half_t>(M * C);
         groupnorm(x, nullptr, HW, Wf(p + ".norm.weight", C), Wf(p + ".norm.bias", C), 1e-6f, 0, n);
         half_t* h = alloc<half_t>(M * C);
-        // every GEMM that writes the residual stream h also leaves the next LayerNorm's partial statistics (32-column groups)
-        float* lnpart = (C % 32 == 0 && g_rowstat_mode != 0) ? alloc<float>(M * (C / 32) * 2) : nullptr;
-        linear(n, C, (int)M, C, Wh(p + ".proj_in.weight", (long long)C * C), C, Wf(p + ".proj_in.bias", C), nullptr, 0, h, C, 0, 0, nullptr,
-               nullptr, lnpart);
+        linear(n, C, (int)M, C, Wh(p + ".proj_in.weight", (long long)C * C), C, Wf(p + ".proj_in.bias", C), nullptr, 0, h, C);
+        // the first GEMM behind each LayerNorm computes the statistics of its input rows itself (from its MFMA operand fragments
+        // where the tile kernel can, see icd_gemm) and leaves them in lnst for a second consumer (to_v after to_qk)
+        const int lnc = g_ln_inline ? ICD_GEMM_LN_COMPUTE : 0;
         release(n);
         // LayerNorm is never materialised: per-row (mean, rstd) from a statistics pass over the residual stream, gamma
         // folded into the consuming projection's weights at load time (unet.py), the rank-1 correction in its epilogue.
@@ -321,10 +319,10 @@ struct Exec {
         for (int kb = 0; kb < depth && ok(); ++kb) {
             const std::string b = p + ".transformer_blocks." + std::to_string(kb);
             // ---- self attention ----
-            ln_stats(h, M, C, lnst, lnpart);
+            ln_stats(h, M, C, lnst);
             half_t* qk = alloc<half_t>(M * 2 * C);
             linear(h, C, (int)M, C, Wh(b + ".attn1.to_qk.weight", 2LL * C * C), 2 * C, Wf(b + ".attn1.to_qk.lnbias", 2 * C), nullptr, 0, qk,
-                   2 * C, 0, 0, lnst, Wf(b + ".attn1.to_qk.lnsum", 2 * C));
+                   2 * C, lnc, 0, lnst, Wf(b + ".attn1.to_qk.lnsum", 2 * C));
             half_t* vt = alloc<half_t>((long long)B * C * ldv_self);
             linear(h, C, (int)M, C, Wh(b + ".attn1.to_v.weight", (long long)C * C), C, nullptr, nullptr, 0, vt, ldv_self,
                    ICD_GEMM_OUT_TRANS, HW, lnst, Wf(b + ".attn1.to_v.lnsum", C));      // (W_v beta) rides in to_out's bias
@@ -332,10 +330,9 @@ struct Exec {
             const AttnPlan self_plan = attn_query(false, place, heads, HW, HW);
             attention(self_plan, false, place, qk, 2 * C, qk + C, 2 * C, vt, ldv_self, (long long)C * ldv_self, heads, HW, HW, d, ao, C);
             release(qk); release(vt);
-            linear(ao, C, (int)M, C, Wh(b + ".attn1.to_out.0.weight", (long long)C * C), C, Wf(b + ".attn1.to_out.0.bias", C), h, C, h, C, 0, 0,
-                   nullptr, nullptr, lnpart);
+            linear(ao, C, (int)M, C, Wh(b + ".attn1.to_out.0.weight", (long long)C * C), C, Wf(b + ".attn1.to_out.0.bias", C), h, C, h, C);
             // ---- cross attention ----
-            ln_stats(h, M, C, lnst, lnpart);
+            ln_stats(h, M, C, lnst);
             // K and V^T of this layer are column / row slices of the per-forward batched projections
             const half_t* kx = k_all + kv_off;
             const half_t* vx = vt_all + (long long)kv_off * ldv_cross;
@@ -351,7 +348,7 @@ struct Exec {
                     g.a0 = h; g.w = wq; g.bias = bq; g.out = ao;
                     g.M = (int)M; g.N = C; g.K = C; g.Nw = C; g.lda = C; g.ldw = C; g.ldo = C;
                     g.rows_per_sample = HW; g.mode = 0; g.batch = 1; g.zdiv = 1; g.alpha = 1.f;
-                    g.ln_stats = lnst; g.ln_colsum = sq;
+                    g.ln_stats = lnst; g.ln_colsum = sq; g.flags = lnc;
                     g.xattn_k = kx; g.xattn_vt = vx; g.xattn_nk = nctx; g.xattn_ldk = u->kv_total; g.xattn_ldvt = ldv_cross;
                     g.xattn_vt_bs = vx_bs; g.xattn_scale = 1.0f / sqrtf((float)d);
                     ProfScope ps(true, st, ICD_PROF_XATTN, 2.0 * M * (double)C * C + 4.0 * M * (double)nctx * C, 0.0, (int)M, C, C, heads);
@@ -359,24 +356,21 @@ struct Exec {
                 }
             } else {
                 half_t* q2 = alloc<half_t>(M * C);
-                linear(h, C, (int)M, C, wq, C, bq, nullptr, 0, q2, C, 0, 0, lnst, sq);
+                linear(h, C, (int)M, C, wq, C, bq, nullptr, 0, q2, C, lnc, 0, lnst, sq);
                 attention(cross_plan, true, place, q2, C, kx, u->kv_total, vx, ldv_cross, vx_bs, heads, HW, nctx, d, ao, C);
                 release(q2);
             }
             kv_off += C;
-            linear(ao, C, (int)M, C, Wh(b + ".attn2.to_out.0.weight", (long long)C * C), C, Wf(b + ".attn2.to_out.0.bias", C), h, C, h, C, 0, 0,
-                   nullptr, nullptr, lnpart);
+            linear(ao, C, (int)M, C, Wh(b + ".attn2.to_out.0.weight", (long long)C * C), C, Wf(b + ".attn2.to_out.0.bias", C), h, C, h, C);
             release(ao);
             // ---- GEGLU feed-forward ----
-            ln_stats(h, M, C, lnst, lnpart);
+            ln_stats(h, M, C, lnst);
             half_t* ff = alloc<half_t>(M * 4 * C);
             linear(h, C, (int)M, C, Wh(b + ".ff.net.0.proj.weight", 8LL * C * C), 8 * C, Wf(b + ".ff.net.0.proj.bias", 8 * C), nullptr, 0,
-                   ff, 4 * C, ICD_GEMM_GEGLU, 0, lnst, Wf(b + ".ff.net.0.proj.lnsum", 8 * C));
-            linear(ff, 4 * C, (int)M, 4 * C, Wh(b + ".ff.net.2.weight", 4LL * C * C), C, Wf(b + ".ff.net.2.bias", C), h, C, h, C, 0, 0, nullptr,
-                   nullptr, kb + 1 < depth ? lnpart : nullptr);
+                   ff, 4 * C, ICD_GEMM_GEGLU | lnc, 0, lnst, Wf(b + ".ff.net.0.proj.lnsum", 8 * C));
+            linear(ff, 4 * C, (int)M, 4 * C, Wh(b + ".ff.net.2.weight", 4LL * C * C), C, Wf(b + ".ff.net.2.bias", C), h, C, h, C);
             release(ff);
         }
-        if (lnpart) release(lnpart);
         release(lnst);
         half_t* out = alloc<half_t>(M * C);
         linear(h, C, (int)M, C, Wh(p + ".proj_out.weight", (long long)C * C), C, Wf(p + ".proj_out.bias", C), x.p, C, out, C);
@@ -562,7 +556,7 @@ int temb_total(const icd_unet_config& c) {
 }  // namespace
 
 extern "C" int icd_set_xattn_fusion(int32_t on) { g_no_xattn_fusion = on == 0; return ICD_OK; }
-extern "C" int icd_set_ln_producer_stats(int32_t on) { g_rowstat_mode = on < 0 || on > 2 ? 1 : on; return ICD_OK; }
+extern "C" int icd_set_ln_inline_stats(int32_t on) { g_ln_inline = on != 0; return ICD_OK; }
 
 extern "C" int icd_profile_enable(int32_t enable) {
     for (auto& r : g_prof) { g_ev_pool.push_back(r.a); g_ev_pool.push_back(r.b); }

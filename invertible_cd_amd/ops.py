@@ -60,7 +60,7 @@ FORBID_BIG_TILE = 0x200000
 
 
 def gemm(a, w, bias=None, resid=None, rowbias=None, rows_per_sample=0, geglu=False, out=None, alpha=1.0,
-         out_f32=False, debug_flags=0, ln_stats=None, ln_colsum=None, rowstat_out=None):
+         out_f32=False, debug_flags=0, ln_stats=None, ln_colsum=None, ln_compute=False, ln_eps=1e-5):
     """out[M, N] = alpha * a[M, K] @ w[N, K]^T (+bias[N] fp32) (+rowbias[m // rps]) (+resid) ; GEGLU halves N.
     ln_stats [M, 2] fp32 + ln_colsum [N] fp32: LayerNorm of `a` fused into the epilogue (w carries gamma, bias carries W beta)."""
     _chk16(a, "a"); _chk16(w, "w")
@@ -87,9 +87,9 @@ def gemm(a, w, bias=None, resid=None, rowbias=None, rows_per_sample=0, geglu=Fal
         assert ln_stats.dtype == torch.float32 and ln_stats.is_contiguous() and tuple(ln_stats.shape) == (M, 2)
         assert ln_colsum.dtype == torch.float32 and ln_colsum.is_contiguous() and ln_colsum.numel() == N
         d.ln_stats, d.ln_colsum = ln_stats.data_ptr(), ln_colsum.data_ptr()
-    if rowstat_out is not None:               # fp32 [N / 32, M, 2]: per-32-column (sum, centred sum of squares) of the output rows
-        assert rowstat_out.dtype == torch.float32 and rowstat_out.is_contiguous() and tuple(rowstat_out.shape) == (n_out // 32, M, 2)
-        d.rowstat_out = rowstat_out.data_ptr()
+        if ln_compute:                        # ln_stats is filled by this launch (ICD_GEMM_LN_COMPUTE), not read
+            d.flags |= _lib.ICD_GEMM_LN_COMPUTE
+            d.ln_eps = ln_eps
     ws = _splitk_ws(d, a.device)
     _lib.check(_lib.load().icd_gemm(C.byref(d), _stream()), "icd_gemm")
     return out
@@ -201,15 +201,6 @@ def layernorm_stats(x, eps=1e-5):
     rows, Cc = x.shape
     out = torch.empty((rows, 2), device=x.device, dtype=torch.float32)
     _lib.check(_lib.load().icd_layernorm_stats(_p(x), rows, Cc, eps, _p(out), _stream()), "icd_layernorm_stats")
-    return out
-
-
-def layernorm_stats_finish(partials, C_, eps=1e-5):
-    """(mean, rstd) per row from the partials a producing gemm(..., rowstat_out=) left: fp32 [C/32, rows, 2] -> [rows, 2]."""
-    assert partials.is_cuda and partials.dtype == torch.float32 and partials.is_contiguous() and partials.shape[0] == C_ // 32
-    rows = partials.shape[1]
-    out = torch.empty((rows, 2), device=partials.device, dtype=torch.float32)
-    _lib.check(_lib.load().icd_layernorm_stats_finish(_p(partials), rows, C_, eps, _p(out), _stream()), "icd_layernorm_stats_finish")
     return out
 
 

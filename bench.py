@@ -50,6 +50,9 @@ def parse():
                          "path, SURVEY 8d) or uint8 images [N,512,512,3] after a per-rank VAE decode inside the timed region "
                          "(running/sd1.5/generate.py:372-383)")
     ap.add_argument("--no-sdxl", action="store_true", help="skip the additional SDXL B=8 measurement of the default run")
+    ap.add_argument("--xattn-fusion", type=int, default=2, choices=[0, 1, 2],
+                    help="A/B switch (icd_set_xattn_fusion): 2 = fused query-projection + cross-attention launch where it measured "
+                         "faster (default), 0 = never, 1 = wherever eligible")
     ap.add_argument("--ln-inline-stats", type=int, default=1, choices=[0, 1],
                     help="A/B switch (icd_set_ln_inline_stats): 1 = the GEMM behind a LayerNorm computes its statistics (default), "
                          "0 = a separate statistics pass over the residual stream")
@@ -368,6 +371,9 @@ def main():
     if a.ln_inline_stats != 1:
         from invertible_cd_amd import _lib
         _lib.load().icd_set_ln_inline_stats(a.ln_inline_stats)
+    if a.xattn_fusion != 2:
+        from invertible_cd_amd import _lib
+        _lib.load().icd_set_xattn_fusion(a.xattn_fusion)
     out, sd, cfg = run_arch(a, a.arch, batch, a.steps, a.warmup, device, world, rank, primary=True)
     # The default run also times BASELINE config 4's per-GPU half (SDXL, 8 images per GPU) and carries it as a sub-object of
     # the same JSON line, so the driver's clock covers it too; `value` stays config 2 (the single-GPU metric configuration).

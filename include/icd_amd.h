@@ -344,9 +344,10 @@ int icd_profile_dump(icd_profile_record* recs, int32_t max_recs);
 int icd_debug_gemm_timeline(void* buf);
 /* m-tiles per L2 group of the GEMM block -> tile map (0: default).  A/B tuning only; results are unchanged. */
 int icd_debug_gemm_group_m(int32_t gm);
-/* on != 0: the executor runs LayerNorm -> to_q -> cross-attention of every eligible layer (head dim 64, tokens %% 256 == 0, no
- * controller asking for the probabilities) as ONE launch (icd_gemm_desc.xattn_*) instead of projection + attention.  Off by
- * default (measured slower at the SDXL sizes); results differ only by the fp16 rounding of q. */
+/* The executor can run LayerNorm -> to_q -> cross-attention of a layer (head dim 64, tokens %% 256 == 0, <= 96 keys, no
+ * controller asking for the probabilities) as ONE launch (icd_gemm_desc.xattn_*) instead of projection + attention.
+ * 0: never; 1: every eligible layer; 2 (default): where it measured faster - the 256 x 256 host tile (C %% 256 == 0) in one round
+ * of 128..256 blocks (SDXL's 1024-token layers at 8 images per GPU).  Results differ only by the fp16 rounding order of q. */
 int icd_set_xattn_fusion(int32_t on);
 /* 1 (default): the first GEMM behind every LayerNorm of the executor computes the statistics itself (ICD_GEMM_LN_COMPUTE).
  * 0: a separate icd_layernorm_stats pass over the residual stream before it.  A/B and tests; results agree to ~1e-6 in the

@@ -773,6 +773,14 @@ extern "C" int icd_gemm(const icd_gemm_desc* d, void* stream) {
         // 128 x 128 tiles with two resident blocks per CU (measured, SDXL 32x32 level: 63.8 us at B = 8 / 98.9 us at B = 16 against
         // 73.8 / 113.1 us with 256 x 128 tiles, whose partial last round costs a whole tile; the two launches it replaces take
         // 67.3 / 109.9 us); the 256-row tile stays available for tuning
+        // ... and since the 256 x 256 tile of gemm_big.hip hosts it (a block = 256 queries x 4 heads, K / V^T staged once in the
+        // idle operand stages): the fast GEMM tile under the same epilogue, LayerNorm statistics from its own main loop
+        if (g_xattn_tile == 0 && d->N % 256 == 0 && (long long)(d->M / 256) * (d->N / 256) >= 32) {
+            k.nbm = d->M / 256; k.nbn = d->N / 256;
+            if (ln_compute && k.nbn <= 12 && !(d->flags & ICD_GEMM_TUNE_NO_LN_INLINE)) k.ln_stats_w = const_cast<float*>(d->ln_stats);
+            else { const int rc = ln_stats_launch(); if (rc != ICD_OK) return rc; }
+            return launch_big(k, 100, (hipStream_t)stream);
+        }
         const bool big = g_xattn_tile == 4;
         k.nbm = d->M / (big ? 256 : 128); k.nbn = d->N / 128;
         if (g_group_m <= 0 && k.nbn >= 16) k.gm = 8;

@@ -18,17 +18,180 @@ using namespace icd_gemm_detail;
 
 namespace {
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Cross-attention as the epilogue of the query projection on the 256 x 256 tile (the north-star kernel, see gemm.hip's
+// xattn_epilogue for the arithmetic: S^T = K q^T on the accumulators used in place as the MFMA B operand, exact softmax over
+// <= 96 key slots, O^T = V^T P^T).  A block = 256 queries of ONE sample x 4 heads of 64; wave (wm, wn) owns head wn for the
+// 128 queries of tile row wm (TM = 4 query tiles of 32).  Unlike the 128-wide host, K and V^T of the block's 4 heads are staged
+// ONCE in the (now idle) operand stages - 96 keys x 256 dims (row stride 520 B: conflict-free 8-B fragment reads) and 256 dims x
+// 96 keys (stride 208 B).  The four query tiles are first rounded to fp16 q (128 accumulator registers -> 64), then processed in
+// pairs on one register-resident set of K fragments and one of V^T fragments (reading each fragment from LDS right before
+// its MFMA left ~36 exposed LDS latencies per tile: 17 us of epilogue per block).  O leaves through a private LDS patch per
+// wave as 128-B row segments.
+constexpr int XA_K_OFF = 0, XA_K_LD = 520, XA_V_OFF = 96 * XA_K_LD, XA_V_LD = 208, XA_TABLE_OFF = XA_V_OFF + 256 * XA_V_LD;
+constexpr int XA_PATCH_OFF = XA_TABLE_OFF + 5 * 256 * 8, XA_SMEM = XA_PATCH_OFF + 8 * 32 * 72 * 2;     // 49920 + 53248 + 10240 + 36864
+static_assert(XA_SMEM <= 160 * 1024, "fused cross-attention: LDS budget");
+
+template <int TM>
+__device__ __forceinline__ void xattn_epilogue_big(const GemmK& p, f32x16 (&acc)[TM][2], unsigned char* smem, int wv, int wm, int wn,
+                                                   int l, int m0, int n0, const float* ln_lds) {
+    constexpr int KT = 3, KS = 4, ST = 6, DT = 2;
+    const int lr = l & 31, lh = l >> 5, tid = threadIdx.x;
+    const int b = m0 / p.rps;                              // the 256 rows of a block lie inside one sample
+    // ---- stage K [96 keys][256 dims] and V^T [256 dims][96 keys] of the block's 4 heads (the caller's barrier freed the stages)
+    {
+        const half_t* Kb = p.xk + (long long)b * p.x_nk * p.x_ldk + n0;
+        const half_t* Vb = p.xvt + (long long)b * p.x_vt_bs + (long long)n0 * p.x_ldvt;
+        const f16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {                      // 96 rows x 32 chunks of 16 B, 512 threads
+            const int item = j * 512 + tid, key = item >> 5, ch = item & 31;
+            const f16x8 v = key < p.x_nk ? *reinterpret_cast<const f16x8*>(Kb + (long long)key * p.x_ldk + ch * 8) : z8;
+            *reinterpret_cast<f16x8*>(smem + XA_K_OFF + key * XA_K_LD + ch * 16) = v;
+        }
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {                      // 256 rows x 12 chunks of 16 B (keys 0..95)
+            const int item = j * 512 + tid, row = item / 12, ch = item - row * 12;
+            const f16x8 v = ch * 8 < p.x_ldvt ? *reinterpret_cast<const f16x8*>(Vb + (long long)row * p.x_ldvt + ch * 8) : z8;
+            *reinterpret_cast<f16x8*>(smem + XA_V_OFF + row * XA_V_LD + ch * 16) = v;
+        }
+    }
+    __syncthreads();
+    const unsigned char* Kl = smem + XA_K_OFF + wn * 128;  // this wave's head: 64 dims = 128 B into every key row
+    const unsigned char* Vl = smem + XA_V_OFF + wn * 64 * XA_V_LD;
+    const int prow = (lr & 0x13) | ((lr & 4) << 1) | ((lr & 8) >> 1);
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    half_t* patch = reinterpret_cast<half_t*>(smem + XA_PATCH_OFF) + wv * (32 * 72);
+    const int ncol = n0 + wn * 64;
+    // ---- 1. every query tile -> fp16 q (LayerNorm correction, bias, softmax scale * log2 e folded in, one rounding): the 128
+    //         accumulator registers become 64, which is what lets the K and V^T fragments stay in registers across two tiles ----
+    f16x8 qf[TM][KS];
+    {
+        f32x2 lst[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int mrow = m0 + (wm * TM + i) * 32;
+            lst[i] = (f32x2){0.f, 1.f};
+            if (p.ln_stats) {
+                if (ln_lds) lst[i] = *reinterpret_cast<const f32x2*>(ln_lds + 2 * (mrow + lr - m0));
+                else lst[i] = *reinterpret_cast<const f32x2*>(p.ln_stats + 2 * (long long)(mrow + lr));
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {                  // column group outermost: its bias / column sums are loaded once for 4 tiles
+                const int n = ncol + j * 32 + 8 * g + 4 * lh;
+                f32x4 s4 = {0.f, 0.f, 0.f, 0.f}, t4 = {0.f, 0.f, 0.f, 0.f};
+                if (p.ln_stats) s4 = *reinterpret_cast<const f32x4*>(p.ln_s + n);
+                if (p.bias) t4 = *reinterpret_cast<const f32x4*>(p.bias + n);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float v = acc[i][j][4 * g + e] * p.alpha;
+                        v = lst[i][1] * (v - lst[i][0] * s4[e]) + t4[e];
+                        qf[i][2 * j + (g >> 1)][4 * (g & 1) + e] = (half_t)(v * p.x_scale_log2);
+                    }
+            }
+    }
+    static_assert(TM % 2 == 0, "query tiles are processed in pairs");
+#pragma unroll
+    for (int i0 = 0; i0 < TM; i0 += 2) {
+        // ---- 2. S^T = K q^T for two query tiles on ONE set of K fragments (24 reads in flight instead of 24 exposed latencies
+        //         per tile), exact softmax over the <= 96 key slots ----
+        f16x8 pf[2][ST];
+        float inv[2];
+        {
+            f16x8 kf[KT][KS];
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const unsigned char* src = Kl + (kt * 32 + prow) * XA_K_LD + (ks * 16 + lh * 4) * 2;
+                    const f16x4 lo = *reinterpret_cast<const f16x4*>(src), hi = *reinterpret_cast<const f16x4*>(src + 16);
+                    kf[kt][ks] = (f16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                }
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii) {
+                f32x16 sc[KT];
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                    for (int kt = 0; kt < KT; ++kt)
+                        sc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kt][ks], qf[i0 + ii][ks], ks == 0 ? zero16 : sc[kt], 0, 0, 0);
+                float mx = -INFINITY;
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int key = kt * 32 + 16 * (e >> 3) + 8 * lh + (e & 7);
+                        if (key >= p.x_nk) sc[kt][e] = -INFINITY;
+                        mx = fmaxf(mx, sc[kt][e]);
+                    }
+                {
+                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+                    mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+                }
+                float rs = 0.f;
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const float pv = __builtin_amdgcn_exp2f(sc[kt][e] - mx);
+                        rs += pv;
+                        pf[ii][kt * 2 + (e >> 3)][e & 7] = (half_t)pv;
+                    }
+                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(rs), __float_as_uint(rs), false, false);
+                inv[ii] = 1.0f / (__uint_as_float(sw[0]) + __uint_as_float(sw[1]));
+            }
+        }
+        // ---- 3. O^T = V^T P^T (V^T fragments from LDS as they are used: holding them too makes hipcc spill); O leaves through the
+        //         wave's LDS patch ----
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) {
+            const int mrow = m0 + (wm * TM + i0 + ii) * 32;
+            f32x16 o[DT];
+#pragma unroll
+            for (int st = 0; st < ST; ++st)
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+                {
+                    const f16x8 vf = *reinterpret_cast<const f16x8*>(Vl + (dt * 32 + lr) * XA_V_LD + (st * 16 + lh * 8) * 2);
+                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[ii][st], st == 0 ? zero16 : o[dt], 0, 0, 0);
+                }
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f16x4 v = {(half_t)(o[dt][4 * g] * inv[ii]), (half_t)(o[dt][4 * g + 1] * inv[ii]), (half_t)(o[dt][4 * g + 2] * inv[ii]),
+                               (half_t)(o[dt][4 * g + 3] * inv[ii])};
+                    *reinterpret_cast<f16x4*>(patch + lr * 72 + dt * 32 + 8 * g + 4 * lh) = v;
+                }
+            half_t* out = reinterpret_cast<half_t*>(p.out);
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) {
+                const int r = pass * 8 + (l >> 3), c8 = (l & 7) * 8;
+                const f16x8 v = *reinterpret_cast<const f16x8*>(patch + r * 72 + c8);
+                *reinterpret_cast<f16x8*>(out + (long long)(mrow + r) * p.ldo + ncol + c8) = v;
+            }
+        }
+    }
+}
+
 constexpr int enc_vmcnt(int n) { return ((n >> 4) << 14) | 0x0F70 | (n & 15); }
 
-template <int MODE, int WM, int WN, int TM, int TN>
+template <int MODE, int WM, int WN, int TM, int TN, bool XATTN = false>
 __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_big_kernel(GemmK p) {
     constexpr int NT = WM * WN * 64;
     constexpr int BM = WM * TM * 32, BNt = WN * TN * 32;
     constexpr int A_BYTES = BM * 128, W_BYTES = BNt * 128, STAGE_BYTES = A_BYTES + W_BYTES;
     constexpr int NAJ = BM * 8 / NT, NWJ = BNt * 8 / NT;        // 16-B chunks per thread per stage
     constexpr int LOADS = NAJ + NWJ;
-    constexpr int LN_TABLE_OFF = 96 * 1024;                     // past the epilogue's staging patches (8 x 9 KiB), inside the stage buffers
-    static_assert(LN_TABLE_OFF + (1 + WN) * BM * 8 <= 2 * STAGE_BYTES, "LayerNorm table does not fit");
+    // past the epilogue's staging patches (8 x 9 KiB), inside the stage buffers; the fused cross-attention epilogue has its own map
+    constexpr int LN_TABLE_OFF = XATTN ? XA_TABLE_OFF : 96 * 1024;
+    static_assert(XATTN || LN_TABLE_OFF + (1 + WN) * BM * 8 <= 2 * STAGE_BYTES, "LayerNorm table does not fit");
+    static_assert(!XATTN || (MODE == 0 && WM == 2 && WN == 4 && TN == 2), "fused cross-attention: 256 x 256 tile, a wave per head");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, wv = tid >> 6, l = tid & 63;
     const int wm = wv / WN, wn = wv - wm * WN;
@@ -283,27 +446,34 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_big_kernel(GemmK p) {
                 if (nt == 0 && m0 + row < p.M) *reinterpret_cast<f32x2*>(p.ln_stats_w + 2 * (long long)(m0 + row)) = (f32x2){mean, rstd};
             }
         }
-        ln_lds = table - 2 * (long long)m0;      // indexed by the global row like p.ln_stats (the epilogue's own barrier publishes it)
+        ln_lds = table;                          // indexed by row - m0 (the epilogue's own barrier publishes it)
     }
     // ---- epilogue (gemm_epilogue.h): per-wave LDS patches, no block-wide slabs -----------------------------------------
     // (the 256 x 320 conv tile has no registers left for the early-load fast path: 160 accumulators + the im2col loader state)
-    wave_epilogue<TM, TN, !(MODE == 1 && TM * TN > 8)>(p, acc, smem, wv, wm, wn, l, m0, n0, split, tl, ln_lds);
+    if constexpr (XATTN) {
+        if (!stat_on) __syncthreads();           // (the statistics block above already synchronised) every wave is done with the stages
+        if (tl && tid == 0) tl[2] = __builtin_amdgcn_s_memrealtime();
+        xattn_epilogue_big<TM>(p, acc, smem, wv, wm, wn, l, m0, n0, ln_lds);
+    } else {
+        wave_epilogue<TM, TN, !(MODE == 1 && TM * TN > 8)>(p, acc, smem, wv, wm, wn, l, m0, n0, split, tl, ln_lds);
+    }
     if (tl) {                                    // last wave out writes the end stamp (stores of this wave are issued, not drained)
         __syncthreads();
         if (tid == 0) tl[3] = __builtin_amdgcn_s_memrealtime();
     }
 }
 
-template <int MODE, int WM, int WN, int TM, int TN>
+template <int MODE, int WM, int WN, int TM, int TN, bool XATTN = false>
 int launch_one(const GemmK& k, hipStream_t st) {
-    constexpr int smem = 2 * (WM * TM * 32 + WN * TN * 32) * 128;
+    constexpr int smem0 = 2 * (WM * TM * 32 + WN * TN * 32) * 128;
+    constexpr int smem = XATTN && XA_SMEM > smem0 ? XA_SMEM : smem0;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_big_kernel<MODE, WM, WN, TM, TN>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_big_kernel<MODE, WM, WN, TM, TN, XATTN>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_big_kernel<MODE, WM, WN, TM, TN>), dim3(k.nbm * k.nbn, k.ksplit, 1), dim3(WM * WN * 64), smem, st, k);
+    hipLaunchKernelGGL((gemm_big_kernel<MODE, WM, WN, TM, TN, XATTN>), dim3(k.nbm * k.nbn, k.ksplit, 1), dim3(WM * WN * 64), smem, st, k);
     ICD_CHECK_LAUNCH("icd_gemm(big tile)");
     return ICD_OK;
 }
@@ -325,6 +495,8 @@ int launch_big(const GemmK& k, int cfg, hipStream_t st) {
     case 3:   // 128 x 320: 4 x 2 waves of 32 x 160
         return conv ? launch_one<1, 4, 2, 1, 5>(k, st) : launch_one<0, 4, 2, 1, 5>(k, st);
     }
+    if (cfg == 100)   // query projection + cross-attention in one launch (icd_gemm_desc.xattn_*): 256 x 256 = 256 queries x 4 heads
+        return launch_one<0, 2, 4, 4, 2, true>(k, st);
     icd_set_error("icd_gemm: unknown big-tile configuration %d", cfg);
     return ICD_ERR_INVALID_ARG;
 }

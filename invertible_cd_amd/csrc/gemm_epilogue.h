@@ -22,7 +22,7 @@ static __device__ __attribute__((aligned(16))) const float icd_epi_ln_id[2] = {0
 // as the output store).  Out-of-range lanes read the neutral page instead of branching around their loads.
 template <int JN, bool R, bool T, bool L, bool PF_ROWBIAS, int PF_PASSES>
 __device__ __forceinline__ void fast_patch(const GemmK& p, const f32x16& acc0, const f32x16& acc1, float* wst, int l, int mrow0,
-                                           int ncol0, const float* ln_lds) {
+                                           int ncol0, const float* ln_lds, int ln_m0) {
     constexpr int LDW = 68;
     constexpr int CHS = JN == 2 ? 3 : 2, NPASS = JN == 2 ? 4 : 2;
     const int lr = l & 31, lh = l >> 5;
@@ -48,7 +48,7 @@ __device__ __forceinline__ void fast_patch(const GemmK& p, const f32x16& acc0, c
         if (R) rs[pass] = *reinterpret_cast<const f16x8*>((p.resid && okp) ? p.resid + (long long)m * p.ldr + n : zp);
         if (T && PF_ROWBIAS) rb[pass] = *reinterpret_cast<const f16x8*>((p.rowbias && okp) ? p.rowbias + (long long)(m / p.rps) * p.ld_rowbias + n : zp);
         if (L) {                                 // row statistics: from the kernel's own LDS table when it computed them (ln_lds)
-            if (ln_lds) st[pass] = *reinterpret_cast<const f32x2*>(ln_lds + 2 * (long long)m);
+            if (ln_lds) st[pass] = *reinterpret_cast<const f32x2*>(ln_lds + 2 * (m - ln_m0));
             else st[pass] = *reinterpret_cast<const f32x2*>((p.ln_stats && okp) ? p.ln_stats + 2 * (long long)m : icd_epi_ln_id);
         }
     }
@@ -70,7 +70,7 @@ __device__ __forceinline__ void fast_patch(const GemmK& p, const f32x16& acc0, c
         if (pass >= PF_PASSES) {
             if (R) rs[pass] = *reinterpret_cast<const f16x8*>((p.resid && okl) ? p.resid + (long long)m * p.ldr + n : zp);
             if (L) {
-                if (ln_lds) st[pass] = *reinterpret_cast<const f32x2*>(ln_lds + 2 * (long long)m);
+                if (ln_lds) st[pass] = *reinterpret_cast<const f32x2*>(ln_lds + 2 * (m - ln_m0));
                 else st[pass] = *reinterpret_cast<const f32x2*>((p.ln_stats && okl) ? p.ln_stats + 2 * (long long)m : icd_epi_ln_id);
             }
         }
@@ -100,8 +100,8 @@ __device__ __forceinline__ void wave_epilogue_fast(const GemmK& p, f32x16 (&acc)
 #pragma unroll
         for (int j0 = 0; j0 < TN; j0 += 2) {
             const int ncol0 = n0 + (wn * TN + j0) * 32;
-            if (TN - j0 >= 2) fast_patch<2, R, T, L, PF_ROWBIAS, PF_PASSES>(p, acc[i][j0], acc[i][j0 + 1 < TN ? j0 + 1 : j0], wst, l, mrow0, ncol0, ln_lds);
-            else fast_patch<1, R, T, L, PF_ROWBIAS, PF_PASSES>(p, acc[i][j0], acc[i][j0], wst, l, mrow0, ncol0, ln_lds);
+            if (TN - j0 >= 2) fast_patch<2, R, T, L, PF_ROWBIAS, PF_PASSES>(p, acc[i][j0], acc[i][j0 + 1 < TN ? j0 + 1 : j0], wst, l, mrow0, ncol0, ln_lds, m0);
+            else fast_patch<1, R, T, L, PF_ROWBIAS, PF_PASSES>(p, acc[i][j0], acc[i][j0], wst, l, mrow0, ncol0, ln_lds, m0);
         }
     }
 }
@@ -193,7 +193,7 @@ __device__ __forceinline__ void wave_epilogue(const GemmK& p, f32x16 (&acc)[TM][
                 for (int pass = 0; pass < 2; ++pass) {
                     const int m = mrow0 + ((pass * 64 + l) >> 2);
                     const float* lp = (p.ln_stats && m < p.M && ncol_ok) ? p.ln_stats + 2 * (long long)m : icd_epi_ln_id;
-                    if (ln_lds) g_st[pass] = *reinterpret_cast<const f32x2*>(ln_lds + 2 * (long long)m);
+                    if (ln_lds) g_st[pass] = *reinterpret_cast<const f32x2*>(ln_lds + 2 * (m - m0));
                     else g_st[pass] = *reinterpret_cast<const f32x2*>(lp);
                 }
             }

@@ -45,10 +45,12 @@ struct ProfScope {
     ~ProfScope() { if (on) (void)hipEventRecord(g_prof[idx].b, st); }
 };
 
-// icd_set_xattn_fusion: run LN2 -> to_q -> cross-attention as ONE launch (icd_gemm xattn_*).  Off by default: the fused kernel
-// is hosted on the 128-wide tile family, whose main loop is 30 - 40 % slower than the 256-wide tiles the plain projection
-// gets, so at SDXL B = 8 the fused launch (63.8 us) loses to projection (35.4 us) + attention (23.3 us); DESIGN.md section 4.
-bool g_no_xattn_fusion = true;
+// icd_set_xattn_fusion: run LN2 -> to_q -> cross-attention as ONE launch (icd_gemm xattn_*).  0 never, 1 wherever the kernel is
+// eligible, 2 (default) where it measured faster than projection + attention: hosted on the 256 x 256 tile (C % 256 == 0) with
+// one round of 128..256 blocks - SDXL's 1024-token layers at 8 images per GPU: 59.4 us against 62.7 us.  With more than one
+// round, or on the 128-wide host (C = 640), its softmax epilogue (17 us per block, VALU bound, serial behind the main loop)
+// costs more than the q round trip it saves; DESIGN.md section 4.
+int g_xattn_mode = 2;
 bool g_ln_inline = true;                    // icd_set_ln_inline_stats: the GEMM behind a LayerNorm computes its statistics (ICD_GEMM_LN_COMPUTE)
 
 struct Arena {
@@ -341,7 +343,9 @@ struct Exec {
             const half_t* wq = Wh(b + ".attn2.to_q.weight", (long long)C * C);
             const float* bq = Wf(b + ".attn2.to_q.lnbias", C);
             const float* sq = Wf(b + ".attn2.to_q.lnsum", C);
-            if (!cross_plan.mat && d == 64 && C % 128 == 0 && HW % 256 == 0 && nctx <= 96 && !g_no_xattn_fusion) {
+            const long long xa_blocks = (M / 256) * (C / 256);
+            const bool xa_auto = C % 256 == 0 && xa_blocks >= 128 && xa_blocks <= 256;
+            if (!cross_plan.mat && d == 64 && C % 128 == 0 && HW % 256 == 0 && nctx <= 96 && (g_xattn_mode == 1 || (g_xattn_mode == 2 && xa_auto))) {
                 // the north-star kernel: LN2 -> to_q -> softmax(q K^T / 8) V in ONE launch, q stays in the accumulators
                 if (ok() && !dry) {
                     icd_gemm_desc g; memset(&g, 0, sizeof(g));
@@ -555,7 +559,7 @@ int temb_total(const icd_unet_config& c) {
 
 }  // namespace
 
-extern "C" int icd_set_xattn_fusion(int32_t on) { g_no_xattn_fusion = on == 0; return ICD_OK; }
+extern "C" int icd_set_xattn_fusion(int32_t on) { g_xattn_mode = on < 0 || on > 2 ? 2 : on; return ICD_OK; }
 extern "C" int icd_set_ln_inline_stats(int32_t on) { g_ln_inline = on != 0; return ICD_OK; }
 
 extern "C" int icd_profile_enable(int32_t enable) {

@@ -238,7 +238,8 @@ def project_vt(x, w, B, n_tokens, ld_keys, ln_stats=None, ln_colsum=None, debug_
     return out
 
 
-def query_cross_attention(a, w, k, vt, B, n_tokens, nk, scale, bias=None, ln_stats=None, ln_colsum=None):
+def query_cross_attention(a, w, k, vt, B, n_tokens, nk, scale, bias=None, ln_stats=None, ln_colsum=None, ln_compute=False,
+                          debug_flags=0):
     """Query projection + cross-attention in ONE launch (icd_gemm_desc.xattn_*): q = a[M, K] @ w[C, K]^T (+ fused LayerNorm,
     + bias), heads of 64 columns; out[m, h*64:(h+1)*64] = softmax(scale * q_h[m] . K_h^T) V_h.  k: [B*nk, ldk] rows (a column
     slice of a wider matrix is fine), vt: [B, C, ldvt] (V transposed, pad keys zero).  Needs C % 128 == 0, n_tokens % 256 == 0,
@@ -254,9 +255,11 @@ def query_cross_attention(a, w, k, vt, B, n_tokens, nk, scale, bias=None, ln_sta
     d.M, d.N, d.K, d.Nw = M, N, K, N
     d.lda, d.ldw, d.ldo = a.stride(0), w.stride(0), out.stride(0)
     d.rows_per_sample = n_tokens
-    d.mode, d.batch, d.zdiv, d.alpha, d.flags = 0, 1, 1, 1.0, 0
+    d.mode, d.batch, d.zdiv, d.alpha, d.flags = 0, 1, 1, 1.0, debug_flags
     if ln_stats is not None:
         d.ln_stats, d.ln_colsum = ln_stats.data_ptr(), ln_colsum.data_ptr()
+        if ln_compute:
+            d.flags |= _lib.ICD_GEMM_LN_COMPUTE
     d.xattn_k, d.xattn_vt = k.data_ptr(), vt.data_ptr()
     d.xattn_nk, d.xattn_ldk, d.xattn_ldvt, d.xattn_vt_bs, d.xattn_scale = nk, k.stride(0), vt.stride(1), vt.stride(0), scale
     _lib.check(_lib.load().icd_gemm(C.byref(d), _stream()), "icd_gemm(xattn)")

@@ -307,6 +307,7 @@ class UNet2DConditionModel:
             io.text_embeds, io.time_ids = te.data_ptr(), ti.data_ptr()
         eps = torch.empty_like(x)
         errors = []
+        self._live.clear()
         hook, probs_mode = self._make_hook(errors)
         ws = self._workspace(B, H, W, n_ctx, probs_mode)
         io.sample, io.timesteps, io.context, io.eps = x.data_ptr(), t.data_ptr(), ctx.data_ptr(), eps.data_ptr()
@@ -315,7 +316,8 @@ class UNet2DConditionModel:
         io.sample_is_f32 = int(io_dtype == torch.float32)
         io.hook = hook
         rc = self._lib.icd_unet_forward(self._h, C.byref(io), C.c_void_p(torch.cuda.current_stream().cuda_stream))
-        self._live.clear()
+        # the probability buffers handed in by the hook stay referenced until the NEXT call (cleared at its start): the launch is
+        # asynchronous, and freeing them here would rely on every later consumer of the allocator running on this same stream
         if errors:
             raise errors[0]
         _lib.check(rc, "icd_unet_forward")

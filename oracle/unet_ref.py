@@ -11,7 +11,7 @@ statement of the attention arithmetic is the p2p hook utils/p2p.py:299-352, whic
 Everything else restates the published diffusers 0.25.1 architecture (SURVEY.md section 8a rows a12/a13 and
 Appendix B) with stock torch.nn.functional ops; architecture fidelity is pinned by the exact parameter counts
 (859 520 964 / 2 567 463 684 + 163 840 for cond_proj) and the diffusers state-dict key/shape layout
-(tests/test_oracle_unet.py).
+(tests/test_oracle_golden.py).
 
 Functional style: weights are a flat dict {diffusers key: fp32 tensor}; layout NCHW / [B,N,C] as in the reference.
 """

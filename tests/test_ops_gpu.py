@@ -492,7 +492,8 @@ def test_layernorm_fused_into_gemm(M, C, N, flags):
 
 # ------------------------------------------------------------------------------ query projection + cross-attention, one launch
 @pytest.mark.parametrize("B,n_tok,C,X,nk,ln", [(2, 256, 128, 64, 77, False), (1, 1024, 1280, 128, 77, True), (3, 256, 256, 64, 13, True),
-                                               (2, 512, 640, 96, 96, False)])
+                                               (2, 512, 640, 96, 96, False), (2, 1024, 1280, 128, 77, True), (3, 768, 1280, 64, 77, False),
+                                               (2, 2048, 768, 64, 96, True)])
 def test_query_projection_with_fused_cross_attention(B, n_tok, C, X, nk, ln):
     """The north-star kernel: q = LN(h) W_q^T never leaves the accumulators; S^T = K q^T, softmax over <= 96 keys and
     O^T = V^T P^T run in the GEMM's epilogue (heads of 64).  Reference: torch fp32, the op sequence of utils/p2p.py:321-342."""
@@ -523,6 +524,11 @@ def test_query_projection_with_fused_cross_attention(B, n_tok, C, X, nk, ln):
     e = rel_l2(out, ref)
     print(f"[xattn fused B={B} n={n_tok} C={C} nk={nk} ln={ln}] rel-L2 = {e:.3e}")
     assert e < 2e-3                                                    # P is rounded to fp16 before P.V, like attention_fused
+    if ln:                                                             # the launch computes the LayerNorm statistics itself
+        st2 = torch.full_like(st, float("nan"))
+        out2 = ops.query_cross_attention(h.cuda(), w16.cuda(), k_dev, vt_dev, B, n_tok, nk, scale, bias=t.cuda(), ln_stats=st2,
+                                         ln_colsum=s.cuda(), ln_compute=True)
+        assert rel_l2(out2, ref) < 2e-3 and torch.allclose(st2, st, rtol=1e-4, atol=1e-4)
     # and against the unfused kernels of this library on the same operands (q rounded to fp16 in between)
     qd = ops.gemm(h.cuda(), w16.cuda(), bias=t.cuda(), ln_stats=st, ln_colsum=s.cuda()) if ln else ops.gemm(h.cuda(), wq.cuda())
     un = ops.attention_fused(qd, k_dev, vt_dev, B, H, n_tok, nk, 64, scale)

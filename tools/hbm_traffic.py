@@ -28,6 +28,8 @@ def family(k):
     m = re.search(r"gemm_kernel<(\d), (?:false|true), \d, \d, (false|true)", k)
     if m and m.group(2) == "true":
         return "xattn_fused"
+    if re.search(r"gemm_big_kernel<\d, \d, \d, \d, \d, true", k):        # 256 x 256 host of the fused query-projection + attention
+        return "xattn_fused"
     m = re.search(r"gemm(?:_big)?_kernel<(\d)", k)
     if m:
         return "gemm_dense" if m.group(1) == "0" else "gemm_conv"

@@ -35,7 +35,7 @@ def main(path):
     fam = {}
     for n, a in agg.items():
         m = re.search(r"gemm(?:_big)?_kernel<(\d)", n)
-        mx = re.search(r"gemm_kernel<\d, (?:false|true), \d, \d, true", n)
+        mx = re.search(r"gemm_kernel<\d, (?:false|true), \d, \d, true", n) or re.search(r"gemm_big_kernel<\d, \d, \d, \d, \d, true", n)
         if mx:
             f = "xattn_fused"
         elif m:

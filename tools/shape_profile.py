@@ -12,10 +12,10 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--arch", default="sd15")
 ap.add_argument("--batch", type=int, default=32)
 ap.add_argument("--reps", type=int, default=3)
-ap.add_argument("--xattn", action="store_true", help="query projection + cross-attention as ONE launch (A/B; default: two launches)")
+ap.add_argument("--xattn", type=int, default=2, help="icd_set_xattn_fusion: 0 two launches, 1 fused wherever eligible, 2 (default) where faster")
 ap.add_argument("--xattn-tile", type=int, default=0, help="2: force the 128x128 tile of the fused kernel, 4: the 256x128 tile")
 a = ap.parse_args()
-_lib.load().icd_set_xattn_fusion(int(a.xattn or bool(a.xattn_tile)))
+_lib.load().icd_set_xattn_fusion(1 if a.xattn_tile else a.xattn)
 if a.xattn_tile:
     _lib.load().icd_debug_gemm_group_m(-a.xattn_tile)
 cfg = SD15 if a.arch == "sd15" else SDXL

@@ -28,6 +28,7 @@ sys.path.insert(0, ROOT)
 
 import torch  # noqa: E402
 
+_REAL_STDOUT = sys.stdout            # main() prints the JSON line here; __main__ points sys.stdout at stderr for the rest
 PEAK_MFMA_F16 = 2516.6e12          # 256 CU x 2.4 GHz x 4096 flop/clk/CU, dense (MI355X_MICROARCH.md: ~2.5 PF)
 PEAK_HBM = 8.0e12
 ALGO_TFLOP_PER_SAMPLE_FWD = {"sd15": 0.8033, "sdxl": 6.7612}
@@ -395,8 +396,12 @@ def main():
         out["sdxl"] = {k: sdxl[k] for k in keep if k in sdxl}
     if world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(a.arch, sd, cfg)
-    print(json.dumps(out))
+    print(json.dumps(out), file=_REAL_STDOUT, flush=True)
 
 
 if __name__ == "__main__":
+    # the contract is ONE JSON line on stdout: everything else the stack prints (the reference-shaped Generator announces its
+    # endpoint tables like utils/generation.py does) goes to stderr
+    _REAL_STDOUT = sys.stdout
+    sys.stdout = sys.stderr
     main()

@@ -133,8 +133,8 @@ __device__ __forceinline__ void xattn_epilogue_big(const GemmK& p, f32x16 (&acc)
                     const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
                     mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
                 }
-                float rs = 0.f;
-#pragma unroll
+                float rs = 0.f;                          // (skipping the mask / the exponentials of key slots past the last key with
+#pragma unroll                                           //  wave-uniform branches made hipcc spill 54 registers: slower)
                 for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
@@ -449,13 +449,14 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_big_kernel(GemmK p) {
         ln_lds = table;                          // indexed by row - m0 (the epilogue's own barrier publishes it)
     }
     // ---- epilogue (gemm_epilogue.h): per-wave LDS patches, no block-wide slabs -----------------------------------------
-    // (the 256 x 320 conv tile has no registers left for the early-load fast path: 160 accumulators + the im2col loader state)
+    // (since the fast path is specialised by operand mix, the 256 x 320 conv tile - 160 accumulators + the im2col loader state -
+    //  fits it too: FAST_OK stays a template switch for experiments)
     if constexpr (XATTN) {
         if (!stat_on) __syncthreads();           // (the statistics block above already synchronised) every wave is done with the stages
         if (tl && tid == 0) tl[2] = __builtin_amdgcn_s_memrealtime();
         xattn_epilogue_big<TM>(p, acc, smem, wv, wm, wn, l, m0, n0, ln_lds);
     } else {
-        wave_epilogue<TM, TN, !(MODE == 1 && TM * TN > 8)>(p, acc, smem, wv, wm, wn, l, m0, n0, split, tl, ln_lds);
+        wave_epilogue<TM, TN, true>(p, acc, smem, wv, wm, wn, l, m0, n0, split, tl, ln_lds);
     }
     if (tl) {                                    // last wave out writes the end stamp (stores of this wave are issued, not drained)
         __syncthreads();

@@ -84,9 +84,9 @@ struct BigTile { int bm, bn; bool geglu_ok; double tk_part, tk_full, fixed; };
 constexpr int NUM_BIG_TILES = 4;
 constexpr BigTile BIG_TILES[NUM_BIG_TILES] = {
     {256, 256, true, 1.00, 1.08, 9.5},
-    {256, 320, false, 1.07, 1.30, 15.3},
+    {256, 320, false, 1.07, 1.30, 13.5},
     {192, 256, true, 0.70, 0.76, 9.6},
-    {128, 320, false, 0.72, 0.80, 7.2},
+    {128, 320, false, 0.72, 0.80, 9.0},
 };
 // Further configurations were built, measured and removed in round 2 (tools/gemm_timeline.py): a
 // generated hand-scheduled 4-wave 128 x 128 main loop, a 256 x 128 x 32 tile with two co-resident blocks per CU, and a 256 x 160

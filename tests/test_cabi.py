@@ -78,3 +78,31 @@ def test_unet_plan_on_cpu_dry_run():
     ws2 = lib.icd_unet_workspace_bytes(h, 4, 16, 16, 77)
     assert 0 < ws < ws2
     lib.icd_unet_destroy(h)
+
+
+def test_header_is_plain_c_and_the_ctypes_mirrors_have_its_layout(tmp_path):
+    """include/icd_amd.h compiles as C99 with nothing but <stdint.h> (the boundary a cgo / JNI / ctypes binding sees), and the
+    structs the Python host passes have exactly the size and field offsets the C compiler gives them."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no C compiler on this box")
+    pairs = {"icd_gemm_desc": _lib.GemmDesc, "icd_unet_config": _lib.UNetConfig, "icd_unet_io": _lib.UNetIO}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "icd_amd.h"', "int main(void) {"]
+    for cname, cls in pairs.items():
+        lines.append(f'  printf("{cname} size %zu\\n", sizeof({cname}));')
+        for fname, *_ in cls._fields_:
+            lines.append(f'  printf("{cname} {fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ["  return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)],
+                   check=True, capture_output=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
+    got = {(a, b): int(c) for a, b, c in (ln.split() for ln in out.splitlines())}
+    for cname, cls in pairs.items():
+        assert got[(cname, "size")] == ctypes.sizeof(cls), cname
+        for fname, *_ in cls._fields_:
+            assert got[(cname, fname)] == getattr(cls, fname).offset, f"{cname}.{fname}"

@@ -227,6 +227,20 @@ int icd_conv_out_n(const void* x, int32_t B, int32_t H, int32_t W, int32_t Cin, 
 int icd_p2p_cross_edit(void* probs, int32_t n_prompts, int32_t heads, int64_t nq, int32_t nk, int32_t ld, const void* At,
                        const float* D, void* stream);
 
+/* LocalBlend (utils/p2p.py:18-44) in one launch: word-weighted mean over layers x heads of the res x res cross-attention maps
+ * of each prompt -> 3x3 max pool -> (nearest resize to the latent) -> normalise by the maximum -> threshold th_pool, OR-ed with
+ * the base prompt's mask; optional substruct words (alpha_sub: no pooling, threshold th_sub) are cleared from it;
+ * out[p] = x[0] + float(mask_p) * (x[p] - x[0]).  maps[l]: fp16 [n_prompts * heads[l], res*res, ld] (the accumulated
+ * AttentionStore tensors, row stride ld >= n_words), alpha / alpha_sub: fp32 [n_prompts][n_words] word masks, x: [n_prompts, C,
+ * H, W] fp16 or fp32, out: fp32 (torch's promotion of `base + mask.float() * (x_t - base)`).  maps / heads are HOST arrays of
+ * n_layers <= 8 entries. */
+int icd_local_blend(const void* const* maps, const int32_t* heads, int32_t n_layers, int32_t n_prompts, int32_t res,
+                    int32_t n_words, int32_t ld, const float* alpha, const float* alpha_sub, float th_pool, float th_sub,
+                    const void* x, int32_t x_is_f32, int32_t C, int32_t H, int32_t W, float* out, void* stream);
+/* dst[t][i] += src[t][i] (fp16, rounded like torch's in-place add) for up to 32 tensors in one launch: the per-step accumulation
+ * of AttentionStore.between_steps (utils/p2p.py:164-170).  dst / src / counts are HOST arrays; tensors 16-byte aligned. */
+int icd_accumulate_multi(void* const* dst, const void* const* src, const int64_t* counts, int32_t n_tensors, void* stream);
+
 /* Consistency boundary step, eps-prediction (utils/generation.py:136-155 == utils/generation_sdxl.py:112-132):
  *   x0 = (x - sigma_t*eps)/alpha_t ; out = alpha_s*x0 + sigma_s*eps, (alpha_s, sigma_s) := (1, 0) where s == 0.
  * coef: fp32 [B,4] = (alpha_t, sigma_t, alpha_s, sigma_s) per sample (host gathers them from the 1000-entry

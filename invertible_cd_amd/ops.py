@@ -423,3 +423,37 @@ def x0_step(x, eps, coef, out_dtype=None):
     coef = coef.to(device=x.device, dtype=torch.float32).contiguous()
     _lib.check(_lib.load().icd_x0_step(_p(x), _p(eps), _p(coef), B, x.numel() // B, flags, _p(out), _stream()), "icd_x0_step")
     return out
+
+
+def local_blend(maps, alpha, alpha_sub, th_pool, th_sub, x_t, res=16):
+    """LocalBlend in one launch (icd_local_blend).  maps: list of <= 8 fp16 cuda tensors [P*heads_l, res*res, n_words] (last dim
+    contiguous, rows evenly strided), alpha / alpha_sub: fp32 [P, n_words] word masks, x_t: [P, C, H, W] fp16 / fp32 -> fp32."""
+    P = alpha.shape[0]
+    n_words = alpha.shape[1]
+    assert x_t.is_cuda and x_t.is_contiguous() and x_t.dtype in (torch.float16, torch.float32) and x_t.shape[0] == P
+    ld = maps[0].stride(1)
+    ptrs, heads = (C.c_void_p * len(maps))(), (C.c_int32 * len(maps))()
+    for i, m in enumerate(maps):
+        assert m.is_cuda and m.dtype == torch.float16 and m.dim() == 3 and m.shape[1] == res * res and m.shape[2] == n_words
+        assert m.stride(2) == 1 and m.stride(1) == ld and m.stride(0) == res * res * ld and m.shape[0] % P == 0
+        ptrs[i], heads[i] = m.data_ptr(), m.shape[0] // P
+    al = alpha.to(device=x_t.device, dtype=torch.float32).contiguous()
+    als = None if alpha_sub is None else alpha_sub.to(device=x_t.device, dtype=torch.float32).contiguous()
+    out = torch.empty(x_t.shape, device=x_t.device, dtype=torch.float32)
+    _lib.check(_lib.load().icd_local_blend(ptrs, heads, len(maps), P, res, n_words, ld, _p(al), None if als is None else _p(als),
+                                           float(th_pool), float(th_sub), _p(x_t), int(x_t.dtype == torch.float32), x_t.shape[1],
+                                           x_t.shape[2], x_t.shape[3], _p(out), _stream()), "icd_local_blend")
+    return out
+
+
+def accumulate_multi(dst, src):
+    """dst[t] += src[t] for lists of fp16 cuda tensors (<= 32 per launch), rounded like torch's in-place add."""
+    lib = _lib.load()
+    for i in range(0, len(dst), 32):
+        d, s = dst[i:i + 32], src[i:i + 32]
+        n = len(d)
+        dp, sp, cn = (C.c_void_p * n)(), (C.c_void_p * n)(), (C.c_int64 * n)()
+        for t, (a, b) in enumerate(zip(d, s)):
+            assert a.is_cuda and b.is_cuda and a.dtype == b.dtype == torch.float16 and a.is_contiguous() and b.is_contiguous() and a.shape == b.shape
+            dp[t], sp[t], cn[t] = a.data_ptr(), b.data_ptr(), a.numel()
+        _lib.check(lib.icd_accumulate_multi(dp, sp, cn, n, _stream()), "icd_accumulate_multi")

@@ -51,6 +51,18 @@ class LocalBlend:
                 mask[i, :, :, :, :, get_word_inds(prompt, w, tokenizer)] = 1
         return mask
 
+    @staticmethod
+    def _on_device(x_t, layers):
+        """The HIP kernel takes the accumulated store tensors as they are: fp16 on the GPU, [P*heads, 256, 77] with evenly
+        strided rows.  Anything else (CPU goldens, foreign dtypes) takes the torch expression below."""
+        if not (x_t.is_cuda and x_t.dim() == 4 and x_t.dtype in (torch.float16, torch.float32)):
+            return False
+        for m in layers:
+            if not (m.is_cuda and m.dtype == torch.float16 and m.dim() == 3 and m.shape[1] == 256 and m.shape[2] == MAX_NUM_WORDS
+                    and m.stride(2) == 1 and m.stride(1) == layers[0].stride(1) and m.stride(0) == 256 * m.stride(1)):
+                return False
+        return len(layers) <= 8
+
     def get_mask(self, maps, alpha, use_pool, x_t):
         """Word-weighted mean over layers x heads of the 16x16 maps -> (3x3 max-pool) -> nearest resize to the latent ->
         per-prompt max normalisation -> threshold; every prompt's mask is OR-ed with the base prompt's (utils/p2p.py:20-31)."""
@@ -70,6 +82,13 @@ class LocalBlend:
             return x_t
         n_prompts = self.alpha_layers.shape[0]
         layers = attention_store["down_cross"][2:4] + attention_store["up_cross"][:3]
+        if self._on_device(x_t, layers):
+            # one HIP launch (icd_local_blend): word-weighted mean of the maps, pool, normalise, threshold, OR with the base
+            # prompt's mask, substruct words, nearest resize and the blend itself
+            from . import ops
+            sub = None if self.substruct_layers is None else self.substruct_layers.reshape(n_prompts, MAX_NUM_WORDS)
+            return ops.local_blend(layers, self.alpha_layers.reshape(n_prompts, MAX_NUM_WORDS), sub, self.th[0], self.th[1],
+                                   x_t.contiguous())
         maps = torch.cat([m.reshape(n_prompts, -1, 1, 16, 16, MAX_NUM_WORDS) for m in layers], dim=1)
         mask = self.get_mask(maps, self.alpha_layers, True, x_t)
         if self.substruct_layers is not None:
@@ -193,9 +212,15 @@ class AttentionStore(AttentionControl):
         if not self.attention_store:
             self.attention_store = self.step_store
         else:
-            for key, acc in self.attention_store.items():
-                for i, t in enumerate(acc):
-                    t += self.step_store[key][i]
+            pairs = [(t, self.step_store[key][i]) for key, acc in self.attention_store.items() for i, t in enumerate(acc)]
+            if pairs and all(t.is_cuda and t.dtype == torch.float16 and t.is_contiguous() and s.is_cuda and s.dtype == torch.float16
+                             and s.is_contiguous() and t.shape == s.shape and t.data_ptr() % 16 == 0 and s.data_ptr() % 16 == 0
+                             for t, s in pairs):
+                from . import ops                  # one launch for all stored maps (icd_accumulate_multi), same rounding as `t += s`
+                ops.accumulate_multi([t for t, _ in pairs], [s for _, s in pairs])
+            else:
+                for t, s in pairs:
+                    t += s
         self.step_store = self.get_empty_store()
 
     def get_average_attention(self):

@@ -6,6 +6,7 @@ import os
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 from invertible_cd_amd import p2p
 from stubs import StubTokenizer
@@ -128,3 +129,60 @@ def test_local_blend_values_on_device(g):
     assert bad.mean() < 5e-3
     assert not bad[:, 0].any()                                   # base prompt row is never blended
     assert np.abs(got - g["refine_lat_in"][None]).max() > 0      # and the blend did change the edited row
+
+
+def test_local_blend_kernel_matches_the_torch_expression():
+    """icd_local_blend (one launch) against the torch expression of utils/p2p.py:18-44 evaluated on the same device tensors:
+    with and without substruct words, fp16 and fp32 latents, 3 prompts.  The two sum the word-weighted maps in different orders,
+    so a border pixel of the thresholded mask may flip: <= 0.2 % of the elements may differ, none in the base row; wherever the
+    masks agree the blend is bit-identical."""
+    from invertible_cd_amd import ops
+    gen = torch.Generator().manual_seed(7)
+    P, H_, res = 3, 8, 16
+    yy, xx = torch.meshgrid(torch.arange(res).float(), torch.arange(res).float(), indexing="ij")
+    layers = []
+    for li in range(5):                                  # word columns carry a spatial blob (else the normalised heat is flat)
+        m = torch.softmax(torch.randn(P * H_, res * res, 77, generator=gen) * 3.0, dim=-1)
+        for w, (cy, cx) in ((2, (4.0, 5.0)), (5, (11.0, 9.0)), (7, (8.0, 3.0))):
+            blob = torch.exp(-((yy - cy - 0.3 * li) ** 2 + (xx - cx) ** 2) / 8.0).reshape(1, res * res)
+            m[:, :, w] = m[:, :, w] * (0.05 + blob) * (1 + 0.1 * torch.rand(P * H_, 1, generator=gen))
+        layers.append(m.half().cuda())
+    alpha = torch.zeros(P, 77); alpha[:, [2, 5]] = 1
+    sub = torch.zeros(P, 77); sub[:, [7]] = 1
+    for x_dtype in (torch.float16, torch.float32):
+        x = torch.randn(P, 4, 64, 64, generator=gen).to(x_dtype).cuda()
+        for a_sub in (None, sub):
+            got = ops.local_blend(layers, alpha, a_sub, 0.3, 0.3, x)
+            maps = torch.cat([m.reshape(P, -1, 1, res, res, 77) for m in layers], dim=1)
+
+            def get_mask(al, use_pool, th):
+                heat = (maps * al.cuda().reshape(P, 1, 1, 1, 1, 77)).sum(-1).mean(1)
+                if use_pool:
+                    heat = F.max_pool2d(heat, kernel_size=3, stride=1, padding=1)
+                heat = F.interpolate(heat, size=x.shape[2:])
+                heat = heat / heat.amax(dim=(2, 3), keepdim=True)
+                on = heat.gt(th)
+                return on[:1] + on
+            mask = get_mask(alpha, True, 0.3)
+            if a_sub is not None:
+                mask = mask * ~get_mask(a_sub, False, 0.3)
+            want = x[:1] + mask.float() * (x - x[:1])
+            assert got.dtype == want.dtype == torch.float32 and got.shape == want.shape
+            bad = (got != want)
+            assert bad.float().mean() < 2e-3 and not bad[0].any()
+            assert 0.02 < mask.float().mean() < 0.98                              # the test exercises both branches of the mask
+
+
+def test_accumulate_multi_is_torch_inplace_add():
+    """icd_accumulate_multi: one launch adds 32 + 5 step maps into the store with torch's fp16 rounding (ragged sizes, tails)."""
+    from invertible_cd_amd import ops
+    gen = torch.Generator().manual_seed(8)
+    shapes = [(16, 256, 77), (16, 1024, 77), (16, 256, 256), (3, 5, 7)] * 9 + [(1, 1, 1)]
+    dst = [torch.rand(s, generator=gen).half().cuda() for s in shapes]
+    src = [torch.rand(s, generator=gen).half().cuda() for s in shapes]
+    want = [d.clone() for d in dst]
+    for w, s_ in zip(want, src):
+        w += s_
+    ops.accumulate_multi(dst, src)
+    for d, w in zip(dst, want):
+        assert torch.equal(d, w)

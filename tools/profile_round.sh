@@ -19,7 +19,9 @@ for arch in sd15 sdxl; do
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmcF_$arch -o p -- python bench.py --arch $arch --steps 1 --warmup 1 --no-cpu-baseline --no-vae --no-ref-batching --no-profile --no-sdxl > /dev/null 2> $OUT/pmcF_$arch.err
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmcW_$arch -o p -- python bench.py --arch $arch --steps 1 --warmup 1 --no-cpu-baseline --no-vae --no-ref-batching --no-profile --no-sdxl > /dev/null 2> $OUT/pmcW_$arch.err
   python tools/hbm_traffic.py $OUT/pmcF_$arch $OUT/pmcW_$arch --arch $arch --batch $b > $OUT/${TAG}_hbm_traffic_${arch}_b${b}.json 2>> $OUT/pmcF_$arch.err
-  rm -rf $OUT/pmcF_$arch $OUT/pmcW_$arch
+  timeout -k 5 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmcM_$arch -o p -- python bench.py --arch $arch --steps 1 --warmup 1 --no-cpu-baseline --no-vae --no-ref-batching --no-profile --no-sdxl > /dev/null 2> $OUT/pmcM_$arch.err
+  python tools/mfma_util.py $OUT/pmcM_$arch --arch $arch --batch $b > $OUT/${TAG}_mfma_util_${arch}_b${b}.json 2>> $OUT/pmcM_$arch.err
+  rm -rf $OUT/pmcF_$arch $OUT/pmcW_$arch $OUT/pmcM_$arch
   find $OUT/prof_$arch -name "*.db" -delete
 done
 tail -c 1500 $OUT/${TAG}_bench_default.json

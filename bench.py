@@ -52,10 +52,10 @@ def parse():
                          "(running/sd1.5/generate.py:372-383)")
     ap.add_argument("--no-sdxl", action="store_true", help="skip the additional SDXL B=8 measurement of the default run")
     ap.add_argument("--xattn-fusion", type=int, default=2, choices=[0, 1, 2],
-                    help="A/B switch (icd_set_xattn_fusion): 2 = fused query-projection + cross-attention launch where it measured "
+                    help="A/B switch (UNet option xattn_fusion): 2 = fused query-projection + cross-attention launch where it measured "
                          "faster (default), 0 = never, 1 = wherever eligible")
     ap.add_argument("--ln-inline-stats", type=int, default=1, choices=[0, 1],
-                    help="A/B switch (icd_set_ln_inline_stats): 1 = the GEMM behind a LayerNorm computes its statistics (default), "
+                    help="A/B switch (UNet option ln_inline_stats): 1 = the GEMM behind a LayerNorm computes its statistics (default), "
                          "0 = a separate statistics pass over the residual stream")
     return ap.parse_args()
 
@@ -95,7 +95,7 @@ def build_sd15(batch, device):
     def step():
         return solver.cons_generation(latents, guidance_scale=7.0, w_embed_dim=512, dynamic_guidance=False, tau1=1.0, tau2=1.0)[-1]
     del sd
-    return step, solver, None, SD15
+    return step, solver, None, SD15, model.unet
 
 
 def build_sdxl(batch, device):
@@ -118,7 +118,7 @@ def build_sdxl(batch, device):
                                                     compute_embeddings_fn=lambda p, o, c: dict(emb), return_latent=True)[1]
     pipe.vae = None
     del sd
-    return step, None, None, SDXL
+    return step, None, None, SDXL, pipe.unet
 
 
 def hbm_traffic(arch, batch, family):
@@ -193,7 +193,8 @@ def run_arch(a, arch, batch, steps, warmup, device, world, rank, primary):
     """Warm up, time `steps` passes of the hot path + the ONE end-of-run all-gather, return the JSON fields."""
     import torch.distributed as dist
     from invertible_cd_amd import _lib, dist_utils
-    step, solver, sd, cfg = (build_sd15 if arch == "sd15" else build_sdxl)(batch, device)
+    step, solver, sd, cfg, net = (build_sd15 if arch == "sd15" else build_sdxl)(batch, device)
+    net.set_option("ln_inline_stats", a.ln_inline_stats).set_option("xattn_fusion", a.xattn_fusion)     # per-handle A/B switches
 
     def sync_all():
         torch.cuda.synchronize()
@@ -369,12 +370,6 @@ def main():
         dist_utils.init("nccl")                     # RCCL
         assert dist.get_world_size() == a.gpus and dist.get_backend() == "nccl"
     batch = a.batch or (32 if a.arch == "sd15" else 8)
-    if a.ln_inline_stats != 1:
-        from invertible_cd_amd import _lib
-        _lib.load().icd_set_ln_inline_stats(a.ln_inline_stats)
-    if a.xattn_fusion != 2:
-        from invertible_cd_amd import _lib
-        _lib.load().icd_set_xattn_fusion(a.xattn_fusion)
     out, sd, cfg = run_arch(a, a.arch, batch, a.steps, a.warmup, device, world, rank, primary=True)
     # The default run also times BASELINE config 4's per-GPU half (SDXL, 8 images per GPU) and carries it as a sub-object of
     # the same JSON line, so the driver's clock covers it too; `value` stays config 2 (the single-GPU metric configuration).

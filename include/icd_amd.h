@@ -115,9 +115,24 @@ typedef struct {
     int64_t xattn_vt_bs;
     float xattn_scale;
     float ln_eps;             /* ICD_GEMM_LN_COMPUTE: epsilon of the LayerNorm (0 -> 1e-5) */
+    /* Tuning and diagnostics travel with the call - the library keeps no process-wide GEMM state.  Zero / NULL: defaults.
+     * None of them changes a result beyond fp32 summation order. */
+    int32_t tune_group_m;     /* m-tiles per L2 group of the block -> tile map (0: the planner's choice) */
+    int32_t tune_xattn_tile;  /* host tile of the fused query-projection + cross-attention launch: 0 planner, 2 = 128 x 128, 4 = 256 x 128 */
+    void* debug_timeline;     /* device buffer of 8 x uint64 per block: every block of this launch stamps s_memrealtime (100 MHz) at */
+                              /* start, first k-tile landed, main loop done, epilogue done (+ s_memtime ticks of the main loop)     */
 } icd_gemm_desc;
 
 int icd_gemm(const icd_gemm_desc* d, void* stream);
+/* What icd_gemm would run for this descriptor (pure function of the descriptor; nothing is enqueued): kernel 0 = the 128-wide
+ * tiles of gemm.hip, 1 = the 256-wide tiles of gemm_big.hip; tile_m x tile_n the block tile; ksplit > 1: split-K + reduce launch;
+ * ln_inline: ICD_GEMM_LN_COMPUTE statistics come from the main loop's operand fragments (no statistics launch); xattn: the
+ * cross-attention epilogue runs in this launch.  The executor records it per launch (icd_profile_dump) so that tests can assert
+ * which code path a UNet forward took. */
+typedef struct {
+    int32_t kernel, tile_m, tile_n, ksplit, ln_inline, xattn;
+} icd_gemm_plan_info;
+int icd_gemm_plan(const icd_gemm_desc* d, icd_gemm_plan_info* out);
 /* Bytes of split-K scratch icd_gemm would like for this shape (0: the shape is not split). */
 int64_t icd_gemm_workspace_bytes(int32_t M, int32_t N, int32_t K);
 
@@ -291,11 +306,26 @@ int icd_unet_set_tensor(icd_unet* u, const char* name, const void* ptr, int32_t 
 /* Validate that every tensor the plan needs is bound. */
 int icd_unet_finalize(icd_unet* u);
 int32_t icd_unet_num_attention_layers(const icd_unet* u);
+/* Per-handle execution options (two handles on two streams may hold different settings; nothing is process-wide).
+ *   ICD_UNET_OPT_XATTN_FUSION   LayerNorm -> to_q -> cross-attention of a layer (head dim 64, tokens %% 256 == 0, <= 96 keys, no
+ *       controller asking for its probabilities) as ONE launch (icd_gemm_desc.xattn_*): 0 never, 1 every eligible layer,
+ *       2 (default) where it measured faster - the 256 x 256 host tile (C %% 256 == 0) in one round of 128..256 blocks (SDXL's
+ *       1024-token layers at 8 images per GPU).  Results differ only by the fp16 rounding order of q.
+ *   ICD_UNET_OPT_LN_INLINE_STATS  1 (default): the first GEMM behind every LayerNorm computes the statistics itself
+ *       (ICD_GEMM_LN_COMPUTE); 0: a separate icd_layernorm_stats pass over the residual stream.  Statistics agree to ~1e-6.
+ *   ICD_UNET_OPT_XATTN_TILE     A/B tuning of the fused launch's host tile (icd_gemm_desc.tune_xattn_tile): 0 (default) planner,
+ *       2 = 128 x 128, 4 = 256 x 128.
+ * Returns ICD_ERR_INVALID_ARG for an unknown option or value. */
+#define ICD_UNET_OPT_XATTN_FUSION    1
+#define ICD_UNET_OPT_LN_INLINE_STATS 2
+#define ICD_UNET_OPT_XATTN_TILE      3
+int icd_unet_set_option(icd_unet* u, int32_t option, int32_t value);
 int64_t icd_unet_workspace_bytes(const icd_unet* u, int32_t batch, int32_t H, int32_t W, int32_t n_ctx);
-/* Same, sized for a known materialisation rule of the attention hook: probs_mode 0 = no layer is ever materialised (no
- * hook), 1 = the rule of the reference's shipped controllers (every cross-attention layer and every layer with <= 32^2
- * queries, utils/p2p.py:147,184-188), 2 = any layer (what icd_unet_workspace_bytes assumes).  A forward whose hook asks
- * for more than the arena was sized for fails with ICD_ERR_WORKSPACE. */
+/* Same for a known materialisation rule of the attention hook: probs_mode 0 = no layer is ever materialised (no hook), 1 =
+ * the rule of the reference's shipped controllers (every cross-attention layer and every layer with <= 32^2 queries,
+ * utils/p2p.py:147,184-188), 2 = any layer (what icd_unet_workspace_bytes assumes).  Since the one-pass probability kernel
+ * (icd_attention_probs) removed the fp32 score tensor the rule no longer moves the arena's peak - all three modes return the
+ * same size today; the entry point stays for ABI stability.  Probabilities are the hook's allocations, never arena memory. */
 int64_t icd_unet_workspace_bytes_ex(const icd_unet* u, int32_t batch, int32_t H, int32_t W, int32_t n_ctx,
                                     int32_t probs_mode);
 
@@ -350,24 +380,11 @@ typedef struct {
     int32_t kind, M, N, K, aux;
     float ms;
     double flops;
+    int32_t tile_m, tile_n;   /* GEMM launches: the planner's block tile (icd_gemm_plan) */
+    int32_t plan_flags;       /* bit 0: gemm_big.hip tile, bit 1: LayerNorm statistics in the main loop, bit 2: fused cross-attention */
+    int32_t ksplit;
 } icd_profile_record;
 int icd_profile_dump(icd_profile_record* recs, int32_t max_recs);
-/* Diagnostics for kernel tuning (tools/gemm_timeline.py): while `buf` (device, 8 x uint64 per block of the next launches)
- * is registered, every block of the 256-wide GEMM tiles stamps s_memrealtime (100 MHz) at: start, first k-tile landed,
- * main loop done, epilogue done.  NULL switches it off.  No reference counterpart. */
-int icd_debug_gemm_timeline(void* buf);
-/* m-tiles per L2 group of the GEMM block -> tile map (0: default).  A/B tuning only; results are unchanged. */
-int icd_debug_gemm_group_m(int32_t gm);
-/* The executor can run LayerNorm -> to_q -> cross-attention of a layer (head dim 64, tokens %% 256 == 0, <= 96 keys, no
- * controller asking for the probabilities) as ONE launch (icd_gemm_desc.xattn_*) instead of projection + attention.
- * 0: never; 1: every eligible layer; 2 (default): where it measured faster - the 256 x 256 host tile (C %% 256 == 0) in one round
- * of 128..256 blocks (SDXL's 1024-token layers at 8 images per GPU).  Results differ only by the fp16 rounding order of q. */
-int icd_set_xattn_fusion(int32_t on);
-/* 1 (default): the first GEMM behind every LayerNorm of the executor computes the statistics itself (ICD_GEMM_LN_COMPUTE).
- * 0: a separate icd_layernorm_stats pass over the residual stream before it.  A/B and tests; results agree to ~1e-6 in the
- * statistics. */
-int icd_set_ln_inline_stats(int32_t on);
-
 #ifdef __cplusplus
 }
 #endif

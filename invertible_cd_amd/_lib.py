@@ -15,6 +15,9 @@ ICD_GEMM_OUT_TRANS = 4
 ICD_GEMM_PAD_HI = 8
 ICD_GEMM_RESID_F32 = 16
 ICD_GEMM_LN_COMPUTE = 32
+ICD_UNET_OPT_XATTN_FUSION = 1
+ICD_UNET_OPT_LN_INLINE_STATS = 2
+ICD_UNET_OPT_XATTN_TILE = 3
 ICD_HOOK_QUERY = 0
 ICD_HOOK_PROBS = 1
 
@@ -35,7 +38,13 @@ class GemmDesc(C.Structure):
         ("xattn_k", C.c_void_p), ("xattn_vt", C.c_void_p), ("xattn_nk", C.c_int32), ("xattn_ldk", C.c_int32),
         ("xattn_ldvt", C.c_int32), ("xattn_vt_bs", C.c_int64), ("xattn_scale", C.c_float),
         ("ln_eps", C.c_float),
+        ("tune_group_m", C.c_int32), ("tune_xattn_tile", C.c_int32), ("debug_timeline", C.c_void_p),
     ]
+
+
+class GemmPlanInfo(C.Structure):
+    _fields_ = [("kernel", C.c_int32), ("tile_m", C.c_int32), ("tile_n", C.c_int32), ("ksplit", C.c_int32),
+                ("ln_inline", C.c_int32), ("xattn", C.c_int32)]
 
 
 class UNetConfig(C.Structure):
@@ -58,7 +67,7 @@ class ProfileRow(C.Structure):
 
 class ProfileRecord(C.Structure):
     _fields_ = [("kind", C.c_int32), ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("aux", C.c_int32), ("ms", C.c_float),
-                ("flops", C.c_double)]
+                ("flops", C.c_double), ("tile_m", C.c_int32), ("tile_n", C.c_int32), ("plan_flags", C.c_int32), ("ksplit", C.c_int32)]
 
 
 PROF_KINDS = ("gemm_conv", "gemm_dense", "gemm_batched", "attn_fused", "groupnorm", "layernorm", "softmax", "misc", "xattn_fused")
@@ -125,10 +134,8 @@ SIGNATURES = {
     "icd_pack_nchw": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "icd_conv_out_n": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
                                  C.c_void_p, C.c_int32, C.c_void_p]),
-    "icd_debug_gemm_timeline": (C.c_int, [C.c_void_p]),
-    "icd_debug_gemm_group_m": (C.c_int, [C.c_int32]),
-    "icd_set_xattn_fusion": (C.c_int, [C.c_int32]),
-    "icd_set_ln_inline_stats": (C.c_int, [C.c_int32]),
+    "icd_gemm_plan": (C.c_int, [C.POINTER(GemmDesc), C.POINTER(GemmPlanInfo)]),
+    "icd_unet_set_option": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "icd_profile_enable": (C.c_int, [C.c_int32]),
     "icd_profile_read": (C.c_int, [C.POINTER(ProfileRow), C.c_int32]),
     "icd_profile_dump": (C.c_int, [C.POINTER(ProfileRecord), C.c_int32]),
@@ -187,3 +194,18 @@ def profile_dump():
     if n < 0:
         check(n, "icd_profile_dump")
     return [(PROF_KINDS[r.kind], r.M, r.N, r.K, r.aux, r.ms, r.flops) for r in recs[:n]]
+
+
+def profile_plans():
+    """Per-launch planner records of the GEMM families: dicts with family, M, N, K, aux, tile (m, n), big (gemm_big.hip tile),
+    ln_inline (LayerNorm statistics in the main loop), xattn (fused cross-attention epilogue), ksplit - what a test asserts when
+    it claims a forward took a given code path.  Call after synchronising the stream."""
+    lib = load()
+    n = lib.icd_profile_dump(None, 0)
+    recs = (ProfileRecord * max(n, 1))()
+    n = lib.icd_profile_dump(recs, n)
+    if n < 0:
+        check(n, "icd_profile_dump")
+    return [dict(family=PROF_KINDS[r.kind], M=r.M, N=r.N, K=r.K, aux=r.aux, ms=r.ms, tile=(r.tile_m, r.tile_n),
+                 big=bool(r.plan_flags & 1), ln_inline=bool(r.plan_flags & 2), xattn=bool(r.plan_flags & 4), ksplit=r.ksplit)
+            for r in recs[:n] if r.tile_m > 0]

@@ -25,6 +25,7 @@
 //   * blockIdx -> tile mapping is XCD-aware (block b runs on XCD b%8): every XCD gets a contiguous range of tiles
 //     so the n-tiles that share an activation tile hit the same private L2.
 #include <algorithm>
+#include <string.h>
 #include <type_traits>
 #include "gemm_common.h"
 
@@ -698,22 +699,10 @@ extern "C" int64_t icd_gemm_workspace_bytes(int32_t M, int32_t N, int32_t K) {
     return need;
 }
 
-static int g_xattn_tile = 0;                    // 0: planner, 2: force 128 x 128, 4: force 256 x 128 (icd_debug_gemm_group_m(-2 / -4))
-static int g_group_m = 0;
-// Tuning override of the L2 grouping of the block -> tile map (0: the planner's default); results never change.
-extern "C" int icd_debug_gemm_group_m(int32_t gm) {
-    if (gm == -2 || gm == -4) { g_xattn_tile = -gm; return ICD_OK; }      // tuning: tile of the fused query-projection + attention kernel
-    if (gm == -1) { g_xattn_tile = 0; return ICD_OK; }
-    g_group_m = gm;
-    return ICD_OK;
-}
+// One planner for icd_gemm (launch = true) and icd_gemm_plan (launch = false: reports the tile the same call would run on, nothing
+// is enqueued).  All tuning / diagnostics inputs travel in the descriptor: the library keeps no process-wide GEMM state.
+static int gemm_run(const icd_gemm_desc* d, void* stream, icd_gemm_plan_info* info, bool do_launch) {
 
-static unsigned long long* g_timeline = nullptr;
-// Diagnostics: while a buffer is registered, every big-tile GEMM block writes four s_memrealtime stamps (100 MHz:
-// block start, first k-tile landed, main loop done, epilogue done) to buf[4 * linear block id].  buf == NULL: off.
-extern "C" int icd_debug_gemm_timeline(void* buf) { g_timeline = (unsigned long long*)buf; return ICD_OK; }
-
-extern "C" int icd_gemm(const icd_gemm_desc* d, void* stream) {
     ICD_CHECK_ARG(d != nullptr, "icd_gemm: null descriptor");
     ICD_CHECK_ARG(d->a0 && d->w && d->out, "icd_gemm: a0/w/out must be non-null");
     ICD_CHECK_ARG(d->M > 0 && d->N > 0 && d->K > 0, "icd_gemm: M,N,K must be positive (got %d,%d,%d)", d->M, d->N, d->K);
@@ -739,15 +728,23 @@ extern "C" int icd_gemm(const icd_gemm_desc* d, void* stream) {
     k.zdiv = d->zdiv > 0 ? d->zdiv : 1;
     k.a_bs0 = d->a_bs0; k.a_bs1 = d->a_bs1; k.w_bs0 = d->w_bs0; k.w_bs1 = d->w_bs1; k.o_bs0 = d->o_bs0; k.o_bs1 = d->o_bs1;
     k.alpha = d->alpha; k.flags = d->flags;
-    k.timeline = g_timeline;
+    k.timeline = (unsigned long long*)d->debug_timeline;
+    const int g_group_m = d->tune_group_m, g_xattn_tile = d->tune_xattn_tile;
     k.gm = g_group_m > 0 ? g_group_m : 1;        // the planner widens it below for launches with many n-tiles
     k.ln_stats = d->ln_stats; k.ln_s = d->ln_colsum;
     k.ln_stats_w = nullptr; k.ln_eps = d->ln_eps > 0.f ? d->ln_eps : 1e-5f;
     // ICD_GEMM_LN_COMPUTE: the big tiles compute the statistics in their main loop; every other path runs the statistics launch
     const bool ln_compute = (d->flags & ICD_GEMM_LN_COMPUTE) != 0;
     ICD_CHECK_ARG(!ln_compute || d->ln_stats, "icd_gemm: ICD_GEMM_LN_COMPUTE needs the ln_stats buffer (and ln_colsum)");
+    auto plan_is = [&](int kernel, int tm, int tn, int xattn) {      // report the choice; true: planning only, do not launch
+        if (info) {
+            info->kernel = kernel; info->tile_m = tm; info->tile_n = tn; info->ksplit = k.ksplit;
+            info->ln_inline = k.ln_stats_w != nullptr; info->xattn = xattn;
+        }
+        return !do_launch;
+    };
     auto ln_stats_launch = [&]() -> int {
-        if (!ln_compute) return ICD_OK;
+        if (!ln_compute || !do_launch) return ICD_OK;
         ICD_CHECK_ARG(d->lda == d->K, "icd_gemm: ICD_GEMM_LN_COMPUTE on this path needs contiguous rows (lda == K)");
         return icd_layernorm_stats(d->a0, d->M, d->K, k.ln_eps, const_cast<float*>(d->ln_stats), stream);
     };
@@ -779,12 +776,14 @@ extern "C" int icd_gemm(const icd_gemm_desc* d, void* stream) {
             k.nbm = d->M / 256; k.nbn = d->N / 256;
             if (ln_compute && k.nbn <= 12 && !(d->flags & ICD_GEMM_TUNE_NO_LN_INLINE)) k.ln_stats_w = const_cast<float*>(d->ln_stats);
             else { const int rc = ln_stats_launch(); if (rc != ICD_OK) return rc; }
+            if (plan_is(1, 256, 256, 1)) return ICD_OK;
             return launch_big(k, 100, (hipStream_t)stream);
         }
         const bool big = g_xattn_tile == 4;
         k.nbm = d->M / (big ? 256 : 128); k.nbn = d->N / 128;
         if (g_group_m <= 0 && k.nbn >= 16) k.gm = 8;
         { const int rc = ln_stats_launch(); if (rc != ICD_OK) return rc; }
+        if (plan_is(0, big ? 256 : 128, 128, 1)) return ICD_OK;
         return big ? launch<0, false, 4, 3, true>(k, 1, (hipStream_t)stream) : launch<0, false, 2, 2, true>(k, 1, (hipStream_t)stream);
     }
     int wm = 2, ks = 1;
@@ -852,6 +851,7 @@ extern "C" int icd_gemm(const icd_gemm_desc* d, void* stream) {
                 if (inline_ok) k.ln_stats_w = const_cast<float*>(d->ln_stats);
                 else { const int rc0 = ln_stats_launch(); if (rc0 != ICD_OK) return rc0; }
             }
+            if (plan_is(1, c.bm, c.bn, 0)) return ICD_OK;
             const int rc = launch_big(k, cfg, st);
             if (rc != ICD_OK) return rc;
             if (k.ksplit > 1) return launch_reduce(k, st);
@@ -878,10 +878,21 @@ extern "C" int icd_gemm(const icd_gemm_desc* d, void* stream) {
                       "icd_gemm: bad conv geometry");
         ICD_CHECK_ARG(batch == 1 && !trans, "icd_gemm: conv mode is not batched / transposed");
         const bool fast = ((d->C0 + d->C1) % 64 == 0) && (d->C0 % 64 == 0);
-        if (!fast) { k.nbm = (d->M + 127) / 128; return launch<2, false, 2, 2>(k, 1, st); }
+        if (!fast) k.nbm = (d->M + 127) / 128;
+        if (plan_is(0, fast && wm == 4 ? 256 : 128, 128, 0)) return ICD_OK;
+        if (!fast) return launch<2, false, 2, 2>(k, 1, st);
         return wm == 4 ? launch<1, false, 4, 3>(k, 1, st) : launch<1, false, 2, 2>(k, 1, st);
     }
     ICD_CHECK_ARG(d->lda % 8 == 0, "icd_gemm: lda must be a multiple of 8");
+    if (plan_is(0, wm * 64, 128, 0)) return ICD_OK;
     if (trans) return wm == 4 ? launch<0, true, 4, 3>(k, batch, st) : launch<0, true, 2, 2>(k, batch, st);
     return wm == 4 ? launch<0, false, 4, 3>(k, batch, st) : launch<0, false, 2, 2>(k, batch, st);
+}
+
+extern "C" int icd_gemm(const icd_gemm_desc* d, void* stream) { return gemm_run(d, stream, nullptr, true); }
+
+extern "C" int icd_gemm_plan(const icd_gemm_desc* d, icd_gemm_plan_info* out) {
+    ICD_CHECK_ARG(out != nullptr, "icd_gemm_plan: null output");
+    memset(out, 0, sizeof(*out));
+    return gemm_run(d, nullptr, out, false);
 }

@@ -47,7 +47,10 @@ __device__ __forceinline__ void xattn_epilogue_big(const GemmK& p, f32x16 (&acc)
         for (int j = 0; j < 6; ++j) {                      // 96 rows x 32 chunks of 16 B, 512 threads
             const int item = j * 512 + tid, key = item >> 5, ch = item & 31;
             const f16x8 v = key < p.x_nk ? *reinterpret_cast<const f16x8*>(Kb + (long long)key * p.x_ldk + ch * 8) : z8;
-            *reinterpret_cast<f16x8*>(smem + XA_K_OFF + key * XA_K_LD + ch * 16) = v;
+            // the 520-B row pitch (conflict-free 8-B fragment reads) is only 8-byte aligned: two 8-byte stores
+            half_t* dst = reinterpret_cast<half_t*>(smem + XA_K_OFF + key * XA_K_LD + ch * 16);
+            *reinterpret_cast<f16x4*>(dst) = (f16x4){v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<f16x4*>(dst + 4) = (f16x4){v[4], v[5], v[6], v[7]};
         }
 #pragma unroll
         for (int j = 0; j < 6; ++j) {                      // 256 rows x 12 chunks of 16 B (keys 0..95)

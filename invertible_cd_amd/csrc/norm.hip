@@ -272,12 +272,18 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_f32_kernel(const float* _
     const int b = blockIdx.y, sp = blockIdx.x, nsplit = gridDim.x;
     const int p_begin = sp * pix_per_split, p_end = min(HW, p_begin + pix_per_split);
     if (rsub < rpi) {
-        float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
+        // Sums of (x - pivot), pivot = the group's first element of this sample: real SDXL-VAE activations have |mean| >> std in
+        // some groups (the reason this path exists), and E[x^2] - mean^2 on raw fp32 sums would cancel several digits there.
+        // With the pivot inside the group's range the sums stay O(std), the variance keeps ~7 digits (torch uses Welford).
+        float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f}, pv[4];
+        const int cpg0 = C / groups;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pv[e] = x[(long long)b * HW * C + ((chunk * 4 + e) / cpg0) * cpg0];
         const float* base = x + (long long)b * HW * C + chunk * 4;
         for (int p = p_begin + rsub; p < p_end; p += rpi) {
             const f32x4 v = *reinterpret_cast<const f32x4*>(base + (long long)p * C);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { s[e] += v[e]; q[e] += v[e] * v[e]; }
+            for (int e = 0; e < 4; ++e) { const float dv = v[e] - pv[e]; s[e] += dv; q[e] += dv * dv; }
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) { part[((rsub * C) + chunk * 4 + e) * 2] = s[e]; part[((rsub * C) + chunk * 4 + e) * 2 + 1] = q[e]; }
@@ -320,9 +326,9 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_split_kernel(const float*
         ss = group_sum<16>(ss); qq = group_sum<16>(qq);
         if (g < groups && j == 0) {
             const float n = (float)HW * (float)(C / groups);
-            const float mean = ss / n;
-            s_mean[g] = mean;
-            s_rstd[g] = rsqrtf(fmaxf(qq / n - mean * mean, 0.f) + eps);
+            const float dm = ss / n;                             // mean of (x - pivot), see gn_stats_f32_kernel
+            s_mean[g] = x[(long long)b * HW * C + g * (C / groups)] + dm;
+            s_rstd[g] = rsqrtf(fmaxf(qq / n - dm * dm, 0.f) + eps);
         }
     }
     __syncthreads();
@@ -691,11 +697,15 @@ extern "C" int icd_groupnorm_f32_split(const float* x, int32_t C, int32_t B, int
     return ICD_OK;
 }
 
-// max |x| over n fp32 values -> *out (device, fp32; the caller zeroes it): non-negative floats order like their bit patterns,
-// so a device-wide atomicMax on the bits is exact and order independent
+// max |x| over n fp32 values -> *out (device, fp32; icd_absmax zeroes it first): non-negative floats order like their bit
+// patterns, so a device-wide atomicMax on the bits is exact and order independent.  A NaN input counts as +inf (fmaxf alone
+// would drop it), so the host's finiteness guard (ops.split_cast_guarded) fires for NaN activations as well.
 __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long long n, unsigned* __restrict__ out) {
     float m = 0.f;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float v = x[i];
+        m = (v != v) ? INFINITY : fmaxf(m, fabsf(v));
+    }
     m = wave_max(m);
     if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
 }

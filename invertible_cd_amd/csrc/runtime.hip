@@ -20,7 +20,7 @@ namespace {
 struct Tensor { const void* ptr; int dtype; long long numel; };
 
 // ---- per-family launch timing (HIP events on the launch stream) ------------------------------------------------
-struct ProfRec { hipEvent_t a, b; int kind; double flops, bytes; int M, N, K, aux; };
+struct ProfRec { hipEvent_t a, b; int kind; double flops, bytes; int M, N, K, aux; int tile_m, tile_n, plan_flags, ksplit; };
 bool g_prof_on = false;
 unsigned g_prof_mask = 0xffffffffu;     // bit k: record launches of family k
 std::vector<ProfRec> g_prof;
@@ -37,21 +37,21 @@ struct ProfScope {
     ProfScope(bool active, hipStream_t s, int kind, double flops, double bytes, int M = 0, int N = 0, int K = 0, int aux = 0)
         : on(active && g_prof_on && ((g_prof_mask >> kind) & 1u)), st(s), idx(0) {
         if (!on) return;
-        ProfRec r{prof_event(), prof_event(), kind, flops, bytes, M, N, K, aux};
+        ProfRec r{prof_event(), prof_event(), kind, flops, bytes, M, N, K, aux, 0, 0, 0, 0};
         (void)hipEventRecord(r.a, st);
         idx = g_prof.size();
         g_prof.push_back(r);
     }
     ~ProfScope() { if (on) (void)hipEventRecord(g_prof[idx].b, st); }
+    void plan(const icd_gemm_desc& d) {          // which tile the planner takes for this launch (tests assert the code path)
+        if (!on) return;
+        icd_gemm_plan_info pi;
+        if (icd_gemm_plan(&d, &pi) != ICD_OK) return;
+        ProfRec& r = g_prof[idx];
+        r.tile_m = pi.tile_m; r.tile_n = pi.tile_n; r.ksplit = pi.ksplit;
+        r.plan_flags = (pi.kernel ? 1 : 0) | (pi.ln_inline ? 2 : 0) | (pi.xattn ? 4 : 0);
+    }
 };
-
-// icd_set_xattn_fusion: run LN2 -> to_q -> cross-attention as ONE launch (icd_gemm xattn_*).  0 never, 1 wherever the kernel is
-// eligible, 2 (default) where it measured faster than projection + attention: hosted on the 256 x 256 tile (C % 256 == 0) with
-// one round of 128..256 blocks - SDXL's 1024-token layers at 8 images per GPU: 59.4 us against 62.7 us.  With more than one
-// round, or on the 128-wide host (C = 640), its softmax epilogue (17 us per block, VALU bound, serial behind the main loop)
-// costs more than the q round trip it saves; DESIGN.md section 4.
-int g_xattn_mode = 2;
-bool g_ln_inline = true;                    // icd_set_ln_inline_stats: the GEMM behind a LayerNorm computes its statistics (ICD_GEMM_LN_COMPUTE)
 
 struct Arena {
     char* base = nullptr;
@@ -110,6 +110,15 @@ struct icd_unet {
     int n_attn = 0;
     int temb_total = 0;
     int kv_total = 0;               // sum of C over every transformer block (cross-attention K / V columns)
+    // per-handle execution options (icd_unet_set_option)
+    // xattn_mode: run LN2 -> to_q -> cross-attention as ONE launch (icd_gemm xattn_*).  0 never, 1 wherever the kernel is eligible,
+    // 2 (default) where it measured faster than projection + attention: hosted on the 256 x 256 tile (C % 256 == 0) with one
+    // round of 128..256 blocks - SDXL's 1024-token layers at 8 images per GPU: 59.4 us against 62.7 us.  With more than one
+    // round, or on the 128-wide host (C = 640), its softmax epilogue (17 us per block, VALU bound, serial behind the main loop)
+    // costs more than the q round trip it saves; DESIGN.md section 4.
+    int xattn_mode = 2;
+    bool ln_inline = true;          // the GEMM behind a LayerNorm computes its statistics (ICD_GEMM_LN_COMPUTE)
+    int xattn_tile = 0;             // A/B: host tile of the fused launch (icd_gemm_desc.tune_xattn_tile)
 };
 
 namespace {
@@ -177,6 +186,7 @@ struct Exec {
         const int nb = d.batch > 0 ? d.batch : 1;
         ProfScope ps(true, st, d.mode == 1 ? ICD_PROF_GEMM_CONV : (nb > 1 ? ICD_PROF_GEMM_BATCHED : ICD_PROF_GEMM_DENSE),
                      2.0 * d.M * (double)d.N * d.K * nb, 0.0, d.M, d.N, d.K, d.mode == 1 ? d.ksize * 100 + d.stride * 10 + d.upsample : d.flags);
+        ps.plan(d);
         run(icd_gemm(&d, st));
     }
     // dense: out[M,N] (ldo) = a[M,K](lda) @ w[N,K]^T + bias + resid
@@ -208,10 +218,9 @@ struct Exec {
         ProfScope ps(true, st, ICD_PROF_GROUPNORM, 0.0, 6.0 * B * (double)HW * (x0.C + (x1 ? x1->C : 0)));
         run(icd_groupnorm(x0.p, x0.C, x1 ? x1->p : nullptr, x1 ? x1->C : 0, B, HW, u->cfg.norm_groups, g, b, eps, silu, out, gn_ws, st));
     }
-    // LayerNorm statistics only (2 B / element read): the normalisation is applied by the consuming GEMMs' epilogues
     // LayerNorm statistics by a pass over the stream (2 B / element read) - only when the consuming GEMM does not compute them
     void ln_stats(const half_t* x, long long rows, int C, float* stats) {
-        if (!ok() || dry || g_ln_inline) return;
+        if (!ok() || dry || u->ln_inline) return;
         ProfScope ps(true, st, ICD_PROF_LAYERNORM, 0.0, 2.0 * (double)rows * C);
         run(icd_layernorm_stats(x, rows, C, 1e-5f, stats, st));
     }
@@ -313,7 +322,7 @@ struct Exec {
         linear(n, C, (int)M, C, Wh(p + ".proj_in.weight", (long long)C * C), C, Wf(p + ".proj_in.bias", C), nullptr, 0, h, C);
         // the first GEMM behind each LayerNorm computes the statistics of its input rows itself (from its MFMA operand fragments
         // where the tile kernel can, see icd_gemm) and leaves them in lnst for a second consumer (to_v after to_qk)
-        const int lnc = g_ln_inline ? ICD_GEMM_LN_COMPUTE : 0;
+        const int lnc = u->ln_inline ? ICD_GEMM_LN_COMPUTE : 0;
         release(n);
         // LayerNorm is never materialised: per-row (mean, rstd) from a statistics pass over the residual stream, gamma
         // folded into the consuming projection's weights at load time (unet.py), the rank-1 correction in its epilogue.
@@ -345,7 +354,7 @@ struct Exec {
             const float* sq = Wf(b + ".attn2.to_q.lnsum", C);
             const long long xa_blocks = (M / 256) * (C / 256);
             const bool xa_auto = C % 256 == 0 && xa_blocks >= 128 && xa_blocks <= 256;
-            if (!cross_plan.mat && d == 64 && C % 128 == 0 && HW % 256 == 0 && nctx <= 96 && (g_xattn_mode == 1 || (g_xattn_mode == 2 && xa_auto))) {
+            if (!cross_plan.mat && d == 64 && C % 128 == 0 && HW % 256 == 0 && nctx <= 96 && (u->xattn_mode == 1 || (u->xattn_mode == 2 && xa_auto))) {
                 // the north-star kernel: LN2 -> to_q -> softmax(q K^T / 8) V in ONE launch, q stays in the accumulators
                 if (ok() && !dry) {
                     icd_gemm_desc g; memset(&g, 0, sizeof(g));
@@ -354,8 +363,9 @@ struct Exec {
                     g.rows_per_sample = HW; g.mode = 0; g.batch = 1; g.zdiv = 1; g.alpha = 1.f;
                     g.ln_stats = lnst; g.ln_colsum = sq; g.flags = lnc;
                     g.xattn_k = kx; g.xattn_vt = vx; g.xattn_nk = nctx; g.xattn_ldk = u->kv_total; g.xattn_ldvt = ldv_cross;
-                    g.xattn_vt_bs = vx_bs; g.xattn_scale = 1.0f / sqrtf((float)d);
+                    g.xattn_vt_bs = vx_bs; g.xattn_scale = 1.0f / sqrtf((float)d); g.tune_xattn_tile = u->xattn_tile;
                     ProfScope ps(true, st, ICD_PROF_XATTN, 2.0 * M * (double)C * C + 4.0 * M * (double)nctx * C, 0.0, (int)M, C, C, heads);
+                    ps.plan(g);
                     run(icd_gemm(&g, st));
                 }
             } else {
@@ -559,8 +569,22 @@ int temb_total(const icd_unet_config& c) {
 
 }  // namespace
 
-extern "C" int icd_set_xattn_fusion(int32_t on) { g_xattn_mode = on < 0 || on > 2 ? 2 : on; return ICD_OK; }
-extern "C" int icd_set_ln_inline_stats(int32_t on) { g_ln_inline = on != 0; return ICD_OK; }
+extern "C" int icd_unet_set_option(icd_unet* u, int32_t option, int32_t value) {
+    ICD_CHECK_ARG(u != nullptr, "icd_unet_set_option: null handle");
+    switch (option) {
+    case ICD_UNET_OPT_XATTN_FUSION:
+        ICD_CHECK_ARG(value >= 0 && value <= 2, "icd_unet_set_option: ICD_UNET_OPT_XATTN_FUSION takes 0, 1 or 2 (got %d)", value);
+        u->xattn_mode = value; return ICD_OK;
+    case ICD_UNET_OPT_XATTN_TILE:
+        ICD_CHECK_ARG(value == 0 || value == 2 || value == 4, "icd_unet_set_option: ICD_UNET_OPT_XATTN_TILE takes 0, 2 or 4 (got %d)", value);
+        u->xattn_tile = value; return ICD_OK;
+    case ICD_UNET_OPT_LN_INLINE_STATS:
+        ICD_CHECK_ARG(value == 0 || value == 1, "icd_unet_set_option: ICD_UNET_OPT_LN_INLINE_STATS takes 0 or 1 (got %d)", value);
+        u->ln_inline = value != 0; return ICD_OK;
+    }
+    icd_set_error("icd_unet_set_option: unknown option %d", option);
+    return ICD_ERR_INVALID_ARG;
+}
 
 extern "C" int icd_profile_enable(int32_t enable) {
     for (auto& r : g_prof) { g_ev_pool.push_back(r.a); g_ev_pool.push_back(r.b); }
@@ -588,6 +612,7 @@ extern "C" int icd_profile_dump(icd_profile_record* recs, int32_t max_recs) {
         if (hipEventElapsedTime(&ms, g_prof[i].a, g_prof[i].b) != hipSuccess) { icd_set_error("icd_profile_dump: events not complete"); return ICD_ERR_HIP; }
         recs[i].kind = g_prof[i].kind; recs[i].M = g_prof[i].M; recs[i].N = g_prof[i].N; recs[i].K = g_prof[i].K; recs[i].aux = g_prof[i].aux;
         recs[i].ms = ms; recs[i].flops = g_prof[i].flops;
+        recs[i].tile_m = g_prof[i].tile_m; recs[i].tile_n = g_prof[i].tile_n; recs[i].plan_flags = g_prof[i].plan_flags; recs[i].ksplit = g_prof[i].ksplit;
     }
     return recs ? n : (int)g_prof.size();
 }
@@ -669,9 +694,10 @@ extern "C" int64_t icd_unet_workspace_bytes_ex(const icd_unet* u, int32_t batch,
     return peak + 4096;
 }
 
-// Worst case (any hook may ask for the probabilities of any layer); callers that know their controller's rule use the
-// _ex form: mode 0 (no hook) and mode 1 (shipped controllers, utils/p2p.py:147) need far less - the fp32 score chunk of
-// a materialised 64x64 self-attention layer alone is 1 GiB.
+// Worst case (any hook may ask for the probabilities of any layer).  Since the one-pass probability kernel removed the fp32
+// score tensor, the materialisation rule only moves the cross-attention query buffer q2, which never sets the arena's peak:
+// the _ex form returns the same number for every probs_mode today and is kept for ABI stability (probabilities themselves
+// are the hook's allocations, not arena memory).
 extern "C" int64_t icd_unet_workspace_bytes(const icd_unet* u, int32_t batch, int32_t H, int32_t W, int32_t n_ctx) {
     return icd_unet_workspace_bytes_ex(u, batch, H, W, n_ctx, 2);
 }

@@ -60,7 +60,7 @@ FORBID_BIG_TILE = 0x200000
 
 
 def gemm(a, w, bias=None, resid=None, rowbias=None, rows_per_sample=0, geglu=False, out=None, alpha=1.0,
-         out_f32=False, debug_flags=0, ln_stats=None, ln_colsum=None, ln_compute=False, ln_eps=1e-5):
+         out_f32=False, debug_flags=0, ln_stats=None, ln_colsum=None, ln_compute=False, ln_eps=1e-5, group_m=0, timeline=None):
     """out[M, N] = alpha * a[M, K] @ w[N, K]^T (+bias[N] fp32) (+rowbias[m // rps]) (+resid) ; GEGLU halves N.
     ln_stats [M, 2] fp32 + ln_colsum [N] fp32: LayerNorm of `a` fused into the epilogue (w carries gamma, bias carries W beta)."""
     _chk16(a, "a"); _chk16(w, "w")
@@ -90,6 +90,8 @@ def gemm(a, w, bias=None, resid=None, rowbias=None, rows_per_sample=0, geglu=Fal
         if ln_compute:                        # ln_stats is filled by this launch (ICD_GEMM_LN_COMPUTE), not read
             d.flags |= _lib.ICD_GEMM_LN_COMPUTE
             d.ln_eps = ln_eps
+    d.tune_group_m = group_m                  # tuning / diagnostics travel in the descriptor (no process-wide state)
+    d.debug_timeline = timeline.data_ptr() if timeline is not None else None
     ws = _splitk_ws(d, a.device)
     _lib.check(_lib.load().icd_gemm(C.byref(d), _stream()), "icd_gemm")
     return out
@@ -239,7 +241,7 @@ def project_vt(x, w, B, n_tokens, ld_keys, ln_stats=None, ln_colsum=None, debug_
 
 
 def query_cross_attention(a, w, k, vt, B, n_tokens, nk, scale, bias=None, ln_stats=None, ln_colsum=None, ln_compute=False,
-                          debug_flags=0):
+                          debug_flags=0, xattn_tile=0, timeline=None):
     """Query projection + cross-attention in ONE launch (icd_gemm_desc.xattn_*): q = a[M, K] @ w[C, K]^T (+ fused LayerNorm,
     + bias), heads of 64 columns; out[m, h*64:(h+1)*64] = softmax(scale * q_h[m] . K_h^T) V_h.  k: [B*nk, ldk] rows (a column
     slice of a wider matrix is fine), vt: [B, C, ldvt] (V transposed, pad keys zero).  Needs C % 128 == 0, n_tokens % 256 == 0,
@@ -262,6 +264,8 @@ def query_cross_attention(a, w, k, vt, B, n_tokens, nk, scale, bias=None, ln_sta
             d.flags |= _lib.ICD_GEMM_LN_COMPUTE
     d.xattn_k, d.xattn_vt = k.data_ptr(), vt.data_ptr()
     d.xattn_nk, d.xattn_ldk, d.xattn_ldvt, d.xattn_vt_bs, d.xattn_scale = nk, k.stride(0), vt.stride(1), vt.stride(0), scale
+    d.tune_xattn_tile = xattn_tile            # 0 planner, 2 / 4: force the 128 x 128 / 256 x 128 host tile (A/B)
+    d.debug_timeline = timeline.data_ptr() if timeline is not None else None
     _lib.check(_lib.load().icd_gemm(C.byref(d), _stream()), "icd_gemm(xattn)")
     return out
 

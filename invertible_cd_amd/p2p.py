@@ -392,7 +392,14 @@ def register_attention_control(model, controller):
 
 
 class HookAdapter:
-    """Bridges the executor's C callback (query / probs-ready per Attention module) to a controller object."""
+    """Bridges the executor's C callback (query / probs-ready per Attention module) to a controller object.
+
+    Constraint on what a controller may return for SELF-attention layers: every row of P must still sum to one.  The
+    executor folds norm1's beta through attn1.to_v into attn1.to_out's bias at load time (unet.pack_state_dict: P (V + 1 w^T)
+    = P V + 1 w^T only when P 1 = 1), so an edit that rescales or un-normalises self-attention rows would see the reference's
+    P (V + W_v beta) replaced by P V + W_o W_v beta.  Every shipped controller satisfies it (self-attention edits copy whole
+    softmax rows, utils/p2p.py:183-188; Reweight only touches cross-attention, whose V carries no LayerNorm).  Cross-attention
+    probabilities are unconstrained."""
 
     def __init__(self, controller, cond_only: bool, dev):
         self.c = controller

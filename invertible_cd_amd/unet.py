@@ -127,6 +127,7 @@ def pack_state_dict(cfg: UNetConfig, sd, device):
 
             fold(f"{b}.attn1.to_qk", torch.cat([take(f"{b}.attn1.to_q.weight").to(device), take(f"{b}.attn1.to_k.weight").to(device)], 0), "norm1")
             tv = fold(f"{b}.attn1.to_v", take(f"{b}.attn1.to_v.weight"), "norm1")           # W_v beta: a constant over the keys,
+            del packed[f"{b}.attn1.to_v.lnbias"]                                                # (not applied by the to_v GEMM itself)
             wo = take(f"{b}.attn1.to_out.0.weight").to(device).float()                          # softmax rows sum to one ->
             packed[f"{b}.attn1.to_out.0.weight"] = w16(wo)                                      # it moves into to_out's bias
             packed[f"{b}.attn1.to_out.0.bias"] = f32(take(f"{b}.attn1.to_out.0.bias").to(device).float() + wo @ tv)
@@ -199,6 +200,15 @@ class UNet2DConditionModel:
         self.attn_cond_only = False
         self._t_cache = {}
         self._live = []
+
+    OPTIONS = {"xattn_fusion": _lib.ICD_UNET_OPT_XATTN_FUSION, "ln_inline_stats": _lib.ICD_UNET_OPT_LN_INLINE_STATS,
+               "xattn_tile": _lib.ICD_UNET_OPT_XATTN_TILE}
+
+    def set_option(self, name, value):
+        """Per-handle execution option (icd_unet_set_option): 'xattn_fusion' 0 / 1 / 2, 'ln_inline_stats' 0 / 1, 'xattn_tile' 0 / 2 / 4.  A/B tuning and
+        tests; the defaults are the measured-faster settings and nothing is process-wide."""
+        _lib.check(self._lib.icd_unet_set_option(self._h, self.OPTIONS[name], int(value)), f"icd_unet_set_option({name})")
+        return self
 
     # ------------------------------------------------------------------ duck-typed nn.Module surface
     def named_children(self):

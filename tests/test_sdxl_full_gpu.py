@@ -149,30 +149,68 @@ def test_sdxl_inversion_from_image_tensor_and_pil(sdxl):
 
 
 def test_fused_query_projection_cross_attention_inside_the_unet(sdxl):
-    """The north-star kernel forced on for every eligible layer of the executor (icd_set_xattn_fusion(1)): full-width SDXL, 64x64
-    latent - the 1024-token layers take the 256 x 256 host tile, the 4096-token layers (C = 640) the 128-wide host.  Same
-    result as projection + attention (mode 0) up to the fp16 rounding order of q."""
+    """The north-star kernel forced on for every eligible layer of the executor (option xattn_fusion = 1), full-width SDXL at a
+    64x64 latent, B = 2: the 1024-token layers have C = 640 (not a multiple of 256) and the 256-token C = 1280 layers only make 10
+    blocks of 256 x 256, so ALL 70 launches are hosted on the 128-wide tile of gemm.hip here (asserted from the planner records).
+    The 256 x 256 host (xattn_epilogue_big) is pinned against the oracle at 128x128 latents by
+    test_full_sdxl_forward_128x128_b2_on_the_benchmarked_tiles.  Same result as projection + attention (mode 0) up to the fp16
+    rounding order of q."""
     from invertible_cd_amd import _lib, synthetic
     cfg, pipe, _ = sdxl
     inp = synthetic.synthetic_inputs(cfg, 2, 64, 64, seed=21, device="cpu")
     kw = dict(encoder_hidden_states=inp["context"].cuda().half(), timestep_cond=torch.randn(2, 512, generator=torch.Generator().manual_seed(1)).cuda().half(),
               added_cond_kwargs={"text_embeds": inp["text_embeds"].cuda().half(), "time_ids": inp["time_ids"].cuda()})
     x = inp["latents"].cuda().half()
-    lib = _lib.load()
-    lib.icd_set_xattn_fusion(0)
+    pipe.unet.set_option("xattn_fusion", 0)
     _lib.profile_enable(True)
     try:
         base = pipe.unet(x, 499, **kw).sample
-        lib.icd_set_xattn_fusion(1)
+        pipe.unet.set_option("xattn_fusion", 1)
         fused = pipe.unet(x, 499, **kw).sample
         torch.cuda.synchronize()
         fam = _lib.profile_read()
+        plans = [p for p in _lib.profile_plans() if p["family"] == "xattn_fused"]
     finally:
-        lib.icd_set_xattn_fusion(2)              # default: only where it measured faster
+        pipe.unet.set_option("xattn_fusion", 2)  # default: only where it measured faster
         _lib.profile_enable(False)
     assert fam["xattn_fused"]["launches"] == 70                  # every cross-attention layer of SDXL took the fused kernel
+    assert len(plans) == 70 and all(p["xattn"] and not p["big"] and p["tile"] == (128, 128) for p in plans)
     e = rel_l2(fused, base)
-    print(f"[sdxl fused xattn in the executor] rel-L2 vs two launches = {e:.3e}")
+    print(f"[sdxl fused xattn in the executor, 128-wide host] rel-L2 vs two launches = {e:.3e}")
     # two fp16 evaluation orders of the same graph: their distance is bounded by the fp16 floor of the graph (2.0-2.6e-3 at
     # this width, see test_unet_gpu), measured 0.9-1.0e-3
     assert torch.isfinite(fused).all() and e < 2e-3
+
+
+def test_full_sdxl_forward_128x128_b2_on_the_benchmarked_tiles():
+    """The code path bench.py times for SDXL, against the oracle: full width, B = 2 at 128x128 latents (13.5 TFLOP of CPU oracle).
+    From the planner records: the GEMM flops run on the 256-wide tiles of gemm_big.hip, the first GEMM behind every LayerNorm
+    takes the statistics from its main loop, and - under option xattn_fusion = 1 - the sixty 1024-token C = 1280 cross-attention
+    layers run as the epilogue of the 256 x 256 query-projection tile (xattn_epilogue_big; 8 x 5 = 40 blocks each), the ten
+    4096-token C = 640 layers on the 128-wide host.  Default options (mode 2 fuses nothing at B = 2) and the fused variant are both
+    compared with the fp32 oracle and with the fp16-torch floor."""
+    from test_unet_gpu import _run_case
+    from invertible_cd_amd.unet_config import SDXL
+    torch.cuda.empty_cache()
+
+    def check(name, plans):
+        gem = [p for p in plans if p["family"] in ("gemm_dense", "gemm_conv", "xattn_fused")]
+        fl = lambda ps: sum(2.0 * p["M"] * p["N"] * p["K"] for p in ps)
+        big = [p for p in gem if p["big"]]
+        inline = [p for p in gem if p["ln_inline"]]
+        xa = [p for p in plans if p["family"] == "xattn_fused"]
+        print(f"[plans {name}] {len(gem)} GEMM launches, {100 * fl(big) / fl(gem):.1f} % of their flops on gemm_big tiles "
+              f"{sorted({p['tile'] for p in big})}, {len(inline)} with in-loop LayerNorm statistics, {len(xa)} fused cross-attention launches")
+        # planner at this size (icd_gemm_plan): every to_qk (70) and the 4096-token to_q (10) take the statistics in their main
+        # loop; the 1024-token N = 1280 projections (M = 2048: 64 blocks at best) stay on the 128-wide tiles
+        assert fl(big) / fl(gem) > 0.8 and len(inline) >= (70 if name is None else 130)
+        assert {(128, 320), (192, 256), (256, 256)} <= {p["tile"] for p in big}
+        if name is None:
+            assert len(xa) == 0
+        else:
+            on_big = [p for p in xa if p["big"] and p["tile"] == (256, 256) and p["N"] == 1280 and p["M"] == 2048]
+            on_128 = [p for p in xa if not p["big"] and p["N"] == 640 and p["M"] == 8192]
+            assert len(xa) == 70 and len(on_big) == 60 and len(on_128) == 10 and all(p["xattn"] for p in xa)
+            assert all(p["ln_inline"] for p in on_big)            # ... with the LayerNorm statistics from the same main loop
+
+    _run_case(SDXL, B=2, H=128, W=128, t=699, seed=9, tol=2e-3, variants={"xattn_everywhere": {"xattn_fusion": 1}}, check_plans=check)

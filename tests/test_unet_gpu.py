@@ -35,7 +35,12 @@ def _oracle_cfg(unet_ref, cfg):
     return o
 
 
-def _run_case(cfg, B, H, W, t, seed, tol, with_cond=True, n_ctx=77, f32_io=False):
+def _run_case(cfg, B, H, W, t, seed, tol, with_cond=True, n_ctx=77, f32_io=False, variants=None, check_plans=None):
+    """Product vs fp32 oracle vs the fp16-torch floor.  `variants`: {name: {option: value}} - further runs of the SAME handle under
+    other per-handle options (UNet2DConditionModel.set_option), each compared with the oracle too; `check_plans(name, plans)` gets
+    the planner records of every run (name None = defaults) so a case can assert the code path it claims to pin.  Returns
+    {name: (error, eps)}."""
+    from invertible_cd_amd import _lib
     synthetic, unet, unet_config, unet_ref = _mods()
     sd = {k: v.half().float() for k, v in synthetic.synthetic_state_dict(cfg, seed=seed).items()}
     inp = synthetic.synthetic_inputs(cfg, B, H, W, seed=seed, n_ctx=n_ctx)
@@ -49,9 +54,24 @@ def _run_case(cfg, B, H, W, t, seed, tol, with_cond=True, n_ctx=77, f32_io=False
     ref = unet_ref.unet_forward(sd, _oracle_cfg(unet_ref, cfg), lat, t, ctx, timestep_cond=cond, added_cond=added)
     model = unet.UNet2DConditionModel(cfg, sd)
     x = lat.cuda() if f32_io else lat.half().cuda()
-    out = model(x, torch.tensor(t), encoder_hidden_states=ctx.cuda(), timestep_cond=None if cond is None else cond.cuda(),
-                added_cond_kwargs=None if added is None else {k: v.cuda() for k, v in added.items()})
-    eps = out.sample
+    kw = dict(encoder_hidden_states=ctx.cuda(), timestep_cond=None if cond is None else cond.cuda(),
+              added_cond_kwargs=None if added is None else {k: v.cuda() for k, v in added.items()})
+
+    def run(name, opts):
+        for k, v in opts.items():
+            model.set_option(k, v)
+        _lib.profile_enable(True)
+        try:
+            eps = model(x, torch.tensor(t), **kw).sample
+            torch.cuda.synchronize()
+            plans = _lib.profile_plans()
+        finally:
+            _lib.profile_enable(False)
+        if check_plans is not None:
+            check_plans(name, plans)
+        return eps
+
+    eps = run(None, {})
     assert eps.shape == lat.shape and eps.dtype == x.dtype
     assert torch.isfinite(eps).all()
     err = rel_l2(eps, ref)
@@ -59,16 +79,23 @@ def _run_case(cfg, B, H, W, t, seed, tol, with_cond=True, n_ctx=77, f32_io=False
     sd16 = {k: v.cuda().half() for k, v in sd.items()}
     flo = unet_ref.unet_forward(sd16, _oracle_cfg(unet_ref, cfg), lat, t, ctx, timestep_cond=cond, added_cond=added)
     floor = rel_l2(flo.float().cpu(), ref)
-    del sd16
+    del sd16, flo
     print(f"[{cfg.name} B={B} {H}x{W} t={t}] rel-L2(eps) = {err:.3e}  fp16-torch floor = {floor:.3e}  ratio = {err / floor:.2f}  "
           f"|ref| rms = {ref.pow(2).mean().sqrt():.3f}")
     assert err < tol
     assert err <= 1.5 * floor + 1e-4, f"product error {err:.3e} is more than 1.5x the fp16-torch floor {floor:.3e}"
     # second call on the same handle (workspace reuse) must be bit-identical
-    eps2 = model(x, torch.tensor(t), encoder_hidden_states=ctx.cuda(), timestep_cond=None if cond is None else cond.cuda(),
-                 added_cond_kwargs=None if added is None else {k: v.cuda() for k, v in added.items()}, return_dict=False)[0]
+    eps2 = model(x, torch.tensor(t), return_dict=False, **kw)[0]
     assert torch.equal(eps, eps2)
-    return err
+    results = {None: (err, eps)}
+    for name, opts in (variants or {}).items():
+        e2 = run(name, opts)
+        ev = rel_l2(e2, ref)
+        print(f"[{cfg.name} B={B} {H}x{W} t={t}] variant {name} {opts}: rel-L2(eps) = {ev:.3e}  ratio to the floor = {ev / floor:.2f}  "
+              f"distance to the default run = {rel_l2(e2, eps):.3e}")
+        assert torch.isfinite(e2).all() and ev < tol and ev <= 1.5 * floor + 1e-4
+        results[name] = (ev, e2)
+    return results
 
 
 def test_unet_tiny_sd15_topology():
@@ -109,33 +136,37 @@ def test_unet_full_sdxl_small_latent():
     _run_case(uc.SDXL, B=1, H=32, W=32, t=699, seed=6, tol=2e-3)
 
 
-def test_layernorm_statistics_computed_by_the_consuming_gemm_vs_a_pass_over_the_stream():
-    """The executor lets the first GEMM behind every LayerNorm compute (mean, rstd) of its input rows itself
-    (ICD_GEMM_LN_COMPUTE; the big tiles do it from their MFMA operand fragments - full-width SD1.5 at 32x32, B=2 takes them on
-    every level).  icd_set_ln_inline_stats(0) runs the separate icd_layernorm_stats pass instead.  The statistics agree to ~1e-6
-    (tests/test_ops_gpu.py::test_gemm_computes_the_layernorm_statistics_it_applies), but ANY perturbation of an fp16 pipeline
-    this deep flips a few roundings in the next layer, more in the one after, and saturates within ~5 layers at the distance
-    between two fp16 evaluation orders (~1e-3; measured alike for 1e-7 statistics noise, for split-K order and for the fused-q
-    path).  What the test can and does pin: both modes are equally far from the fp32 oracle."""
-    from invertible_cd_amd import _lib
-    synthetic, unet, uc, unet_ref = _mods()
-    cfg = uc.SD15
-    sd = {k: v.half().float() for k, v in synthetic.synthetic_state_dict(cfg, seed=11).items()}
-    inp = synthetic.synthetic_inputs(cfg, 2, 32, 32, seed=11)
-    lat, ctx = inp["latents"].half().float(), inp["context"].half().float()
-    cond = torch.randn(2, cfg.time_cond_proj_dim, generator=torch.Generator().manual_seed(16)).half().float()
-    ref = unet_ref.unet_forward(sd, _oracle_cfg(unet_ref, cfg), lat, 499, ctx, timestep_cond=cond)
-    model = unet.UNet2DConditionModel(cfg, sd)
-    kw = dict(encoder_hidden_states=ctx.cuda(), timestep_cond=cond.cuda())
-    lib = _lib.load()
-    outs = {}
-    try:
-        for mode in (1, 0):
-            lib.icd_set_ln_inline_stats(mode)
-            outs[mode] = model(lat.half().cuda(), torch.tensor(499), **kw).sample.clone()
-    finally:
-        lib.icd_set_ln_inline_stats(1)
-    e = {m: rel_l2(o, ref) for m, o in outs.items()}
-    d = rel_l2(outs[1], outs[0])
-    print(f"[LN statistics in the consuming GEMM] vs oracle {e[1]:.3e} (separate pass: {e[0]:.3e}); the two differ by {d:.3e}")
-    assert d < 2e-3 and max(e.values()) < 2e-3 and abs(e[1] - e[0]) < 2e-4
+@pytest.mark.slow
+def test_unet_full_sd15_b8_64x64_on_the_benchmarked_tiles_and_layernorm_statistics_ab():
+    """The code path bench.py times, against the oracle: full-width SD1.5, B = 8 at 64x64 latents (6.4 TFLOP of CPU oracle).  At this
+    size the planner puts the UNet on the 256-wide tiles of gemm_big.hip (convs and Linears) and the first GEMM behind every
+    LayerNorm takes the statistics from its own MFMA operand fragments (ICD_GEMM_LN_COMPUTE in the main loop) - both asserted from
+    the executor's planner records, not assumed.  The same handle then runs with option ln_inline_stats = 0 (a separate
+    icd_layernorm_stats pass over the residual stream): no launch may report in-loop statistics, the two results must DIFFER (they
+    are two evaluation orders - a zero distance would mean the A/B never switched anything, which is what this test's predecessor
+    measured at B = 2, 32x32) and both must sit equally far from the fp32 oracle."""
+    _, _, uc, _ = _mods()
+    seen = {}
+
+    def check(name, plans):
+        dense = [p for p in plans if p["family"] == "gemm_dense"]
+        conv = [p for p in plans if p["family"] == "gemm_conv"]
+        big_flops = sum(2.0 * p["M"] * p["N"] * p["K"] for p in dense + conv if p["big"])
+        all_flops = sum(2.0 * p["M"] * p["N"] * p["K"] for p in dense + conv)
+        inline = [p for p in dense if p["ln_inline"]]
+        seen[name] = (big_flops / all_flops, len(inline))
+        print(f"[plans {name}] {len(dense)} dense + {len(conv)} conv launches, {100 * big_flops / all_flops:.1f} % of the GEMM flops on gemm_big "
+              f"tiles {sorted({p['tile'] for p in dense + conv if p['big']})}, {len(inline)} launches with in-loop LayerNorm statistics")
+        assert big_flops / all_flops > 0.8, "the benchmarked tiles did not run"
+        if name is None:
+            # planner at this size (icd_gemm_plan): to_qk at 64^2 / 32^2 / 16^2, attn2.to_q at 64^2 / 32^2, the C = 320 GEGLU projections
+            assert len(inline) >= 25 and all(p["big"] and p["ksplit"] == 1 for p in inline)
+            assert {(256, 320), (256, 256), (128, 320)} <= {p["tile"] for p in dense + conv if p["big"]}
+        else:
+            assert len(inline) == 0
+
+    r = _run_case(uc.SD15, B=8, H=64, W=64, t=779, seed=8, tol=2e-3, variants={"ln_pass": {"ln_inline_stats": 0}}, check_plans=check)
+    d = rel_l2(r["ln_pass"][1], r[None][1])
+    print(f"[LN statistics in the consuming GEMM vs a pass over the stream] vs oracle {r[None][0]:.3e} / {r['ln_pass'][0]:.3e}; "
+          f"the two differ by {d:.3e}")
+    assert 0.0 < d < 2e-3 and abs(r[None][0] - r["ln_pass"][0]) < 2e-4

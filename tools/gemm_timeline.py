@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Where does one GEMM launch spend its time?  Per-block s_memrealtime stamps (icd_debug_gemm_timeline) of a 256-wide-tile
+"""Where does one GEMM launch spend its time?  Per-block s_memrealtime stamps (icd_gemm_desc.debug_timeline) of a 256-wide-tile
 launch: dispatch offset of each block, prologue (first k-tile landed), main loop, epilogue.
 
     python tools/gemm_timeline.py dense 8192 10240 1280 [--geglu] [--cfg 0]
@@ -35,7 +35,7 @@ d.M, d.N, d.K, d.Nw, d.lda, d.ldw, d.ldo, d.ldr = M, N, K, N, K, K, out.stride(0
 d.mode, d.batch, d.zdiv, d.alpha = 0, 1, 1, 1.0
 d.flags = (((a.cfg + 1) << 24) if a.cfg < 4 else {4: 0x80000 | 0x200000, 5: 0x40000 | 0x200000}[a.cfg]) | (1 if a.geglu else 0)
 # cfg 4: 256x128 three-stage tile, 5: 128x128 (two blocks per CU)
-lib.icd_debug_gemm_group_m(a.gm)
+d.tune_group_m = a.gm
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 for _ in range(20):
     _lib.check(lib.icd_gemm(C.byref(d), st))
@@ -43,13 +43,13 @@ torch.cuda.synchronize()
 tiles = {0: (256, 256), 1: (256, 320), 2: (192, 256), 3: (128, 320), 4: (256, 128), 5: (128, 128)}[a.cfg]
 nblk = ((M + tiles[0] - 1) // tiles[0]) * ((N + tiles[1] - 1) // tiles[1])
 buf = torch.zeros((nblk, 8), dtype=torch.int64, device="cuda")
-lib.icd_debug_gemm_timeline(C.c_void_p(buf.data_ptr()))
+d.debug_timeline = buf.data_ptr()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 _lib.check(lib.icd_gemm(C.byref(d), st))
 e1.record()
 torch.cuda.synchronize()
-lib.icd_debug_gemm_timeline(None)
+d.debug_timeline = None
 t = buf.cpu().numpy().astype(np.float64) / 100.0          # 100 MHz -> us
 t0 = t[:, 0].min()
 start, pro, main, epi = t[:, 0] - t0, t[:, 1] - t[:, 0], t[:, 2] - t[:, 1], t[:, 3] - t[:, 2]

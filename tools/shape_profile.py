@@ -12,16 +12,16 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--arch", default="sd15")
 ap.add_argument("--batch", type=int, default=32)
 ap.add_argument("--reps", type=int, default=3)
-ap.add_argument("--xattn", type=int, default=2, help="icd_set_xattn_fusion: 0 two launches, 1 fused wherever eligible, 2 (default) where faster")
+ap.add_argument("--xattn", type=int, default=2, help="UNet option xattn_fusion: 0 two launches, 1 fused wherever eligible, 2 (default) where faster")
 ap.add_argument("--xattn-tile", type=int, default=0, help="2: force the 128x128 tile of the fused kernel, 4: the 256x128 tile")
 a = ap.parse_args()
-_lib.load().icd_set_xattn_fusion(1 if a.xattn_tile else a.xattn)
-if a.xattn_tile:
-    _lib.load().icd_debug_gemm_group_m(-a.xattn_tile)
 cfg = SD15 if a.arch == "sd15" else SDXL
 res = 64 if a.arch == "sd15" else 128
 sd = synthetic.synthetic_state_dict(cfg, seed=0, device="cuda", dtype=torch.float16)
 m = unet.UNet2DConditionModel(cfg, sd)
+m.set_option("xattn_fusion", 1 if a.xattn_tile else a.xattn)
+if a.xattn_tile:
+    m.set_option("xattn_tile", a.xattn_tile)
 del sd
 inp = synthetic.synthetic_inputs(cfg, a.batch, res, res, device="cuda")
 kw = dict(encoder_hidden_states=inp["context"].half(), timestep_cond=torch.randn(a.batch, 512, device="cuda").half())

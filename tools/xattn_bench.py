@@ -31,9 +31,8 @@ for (B, n_tok, C, nk) in [(8, 1024, 1280, 77), (16, 1024, 1280, 77), (8, 4096, 6
     t_two = timeit(two)
     t_gemm = timeit(lambda: ops.gemm(h, w, bias=b, ln_stats=st, ln_colsum=s, out=q, ln_compute=True))
     t_fused = timeit(lambda: ops.query_cross_attention(h, w, k, vt, B, n_tok, nk, 0.125, bias=b, ln_stats=st, ln_colsum=s, ln_compute=True))
-    lib.icd_debug_gemm_group_m(-2)
-    t_f128 = timeit(lambda: ops.query_cross_attention(h, w, k, vt, B, n_tok, nk, 0.125, bias=b, ln_stats=st, ln_colsum=s, ln_compute=True))
-    lib.icd_debug_gemm_group_m(-1)
+    t_f128 = timeit(lambda: ops.query_cross_attention(h, w, k, vt, B, n_tok, nk, 0.125, bias=b, ln_stats=st, ln_colsum=s, ln_compute=True,
+                                                      xattn_tile=2))
     fl = 2.0 * M * C * C + 4.0 * M * nk * C
     print(f"B={B} n={n_tok} C={C}: projection {t_gemm:6.1f} + attention = {t_two:6.1f} us | fused (256x256 host) {t_fused:6.1f} us = {fl / t_fused / 1e6:5.0f} TFLOP/s"
           f" = {fl / t_fused / 1e6 / 2516.6 * 100:4.1f} % of MFMA peak | fused (128x128 host) {t_f128:6.1f} us", flush=True)

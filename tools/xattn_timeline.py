@@ -16,14 +16,12 @@ w = (torch.randn(C_, C_, device="cuda") * C_ ** -0.5).half(); b = torch.randn(C_
 k = torch.randn(B * nk, C_, device="cuda").half(); ld = 80
 vt = torch.zeros(B, C_, ld, device="cuda", dtype=torch.float16); vt[:, :, :nk] = torch.randn(B, C_, nk, device="cuda").half()
 st = torch.empty(M, 2, device="cuda")
-f = lambda: ops.query_cross_attention(h, w, k, vt, B, n_tok, nk, 0.125, bias=b, ln_stats=st, ln_colsum=s, ln_compute=True)
+f = lambda tl=None: ops.query_cross_attention(h, w, k, vt, B, n_tok, nk, 0.125, bias=b, ln_stats=st, ln_colsum=s, ln_compute=True, timeline=tl)
 for _ in range(10): f()
 torch.cuda.synchronize()
 nblk = (M // 256) * (C_ // 256)
 buf = torch.zeros((nblk, 8), dtype=torch.int64, device="cuda")
-lib.icd_debug_gemm_timeline(C.c_void_p(buf.data_ptr()))
-f(); torch.cuda.synchronize()
-lib.icd_debug_gemm_timeline(None)
+f(buf); torch.cuda.synchronize()
 t = buf.cpu().numpy().astype(np.float64) / 100.0
 t0 = t[:, 0].min()
 q = lambda v: f"min {v.min():7.2f}  p50 {np.median(v):7.2f}  p90 {np.percentile(v, 90):7.2f}  max {v.max():7.2f}"

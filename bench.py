@@ -10,12 +10,18 @@ resident in HBM before the timed region.  N > 1: one process per GPU (torchrun),
 (B per GPU, weak scaling), no collective inside the loop, ONE all-gather (RCCL) of the produced latents at the end of
 the timed region (`--gather images`: per-rank VAE decode + uint8 images instead).  VAE decode / text encoding are
 outside this path and not part of `value` by default.  `python bench.py --gpus N` without a
-launcher re-executes itself under torch.distributed.run with N ranks.  The default run (no --arch/--batch) also times
-SDXL at 8 images/GPU (BASELINE configs[3] per-GPU share) and reports it as the "sdxl" object of the same JSON line.
+launcher re-executes itself under torch.distributed.run with N ranks (rendezvous on a free port of 127.0.0.1).
 
-Extra objects on the JSON line: "roofline" for the dominant kernel family (HIP-event durations recorded by the executor
-on the launch stream during the timed region, algorithmic FLOPs) and "cpu_baseline" (the CPU oracle restating the
-reference's fp32 diffusers path, config[0]: B=1, CFG-doubled, timed on this host's cores; rank 0, N=1 only).
+The default run (no --arch/--batch) carries every BASELINE configuration's per-GPU share on the same JSON line:
+  value / config      configs[1]  SD1.5 4-step reverse, 32 images per GPU
+  "edit"              configs[2]  SD1.5 4-step inversion + 4-step reverse with p2p.AttentionStore, 8 images per GPU
+  "sdxl"              configs[3]  SDXL 4-step reverse, 8 images per GPU (64 over 8 GPUs)
+  "sdxl_edit"         configs[4]  SDXL 3-step inversion + 3-step reverse, dynamic guidance tau 0.7, 16 images per GPU (128 over 8)
+Extra objects: "roofline" for the dominant kernel family (HIP-event durations recorded by the executor on the launch stream
+during timed pass A, algorithmic FLOPs), "event_overhead" (the same K steps timed again with no events at all: `value` comes
+from that pass when the events cost more than 1 %), "rccl" (N > 1: world size, library version), per-rank min / max step time,
+and "cpu_baseline" (the CPU oracle restating the reference's fp32 diffusers path, config[0]: B=1, CFG-doubled, timed on this
+host's cores; rank 0, N=1 only).
 """
 import argparse
 import json
@@ -50,7 +56,8 @@ def parse():
                     help="payload of the ONE end-of-run all-gather: fp16 latents (default; VAE decode is outside the timed "
                          "path, SURVEY 8d) or uint8 images [N,512,512,3] after a per-rank VAE decode inside the timed region "
                          "(running/sd1.5/generate.py:372-383)")
-    ap.add_argument("--no-sdxl", action="store_true", help="skip the additional SDXL B=8 measurement of the default run")
+    ap.add_argument("--no-sdxl", action="store_true", help="skip the additional SDXL measurements of the default run")
+    ap.add_argument("--no-edit", action="store_true", help="skip the inversion + edit legs (BASELINE configs 3 and 5) of the default run")
     ap.add_argument("--xattn-fusion", type=int, default=2, choices=[0, 1, 2],
                     help="A/B switch (UNet option xattn_fusion): 2 = fused query-projection + cross-attention launch where it measured "
                          "faster (default), 0 = never, 1 = wherever eligible")
@@ -60,65 +67,144 @@ def parse():
     return ap.parse_args()
 
 
+def free_port():
+    """A TCP port nobody listens on right now (the rendezvous of a self-spawned run; a launcher-provided MASTER_PORT is kept)."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def spawn_ranks(a, argv):
-    """`python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run, one process per GPU (RCCL)."""
+    """`python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run, one process per GPU (RCCL).
+    Rendezvous on 127.0.0.1 at $MASTER_PORT if the caller set one, else on a port that is free right now (a fixed default port
+    fails on a node with a stale listener); a rank that dies takes the group down (torchrun prints its traceback on stderr)."""
     import subprocess
     n_dev = torch.cuda.device_count()
     if n_dev < a.gpus:
         raise SystemExit(f"bench.py --gpus {a.gpus}: only {n_dev} GPU(s) visible on this node")
     env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    port = env.get("MASTER_PORT", "29533")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # only when unset: dmabuf IPC for RCCL on this driver stack
+    env.setdefault("NCCL_DEBUG", "WARN")                       # RCCL says why when its bootstrap fails
+    env.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")
+    port = env.get("MASTER_PORT") or str(free_port())
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + argv
-    raise SystemExit(subprocess.call(cmd, env=env))
+    rc = subprocess.call(cmd, env=env)
+    if rc != 0:
+        print(f"bench.py: the {a.gpus}-rank run failed with exit code {rc} (rendezvous 127.0.0.1:{port}); the failing rank's traceback is above",
+              file=sys.stderr)
+    raise SystemExit(rc)
 
 
-def build_sd15(batch, device):
-    from invertible_cd_amd import generation, synthetic, unet
-    from invertible_cd_amd.pipelines import StableDiffusionPipeline
-    from invertible_cd_amd.schedulers import DDIMScheduler
-    from invertible_cd_amd.unet_config import SD15
-    from invertible_cd_amd.loading import fuse_lora
-    # synthetic weights generated directly on this rank's GPU (seeded per tensor), LoRA (rank 64, alpha 8) fused at load
-    sd = synthetic.synthetic_state_dict(SD15, seed=0, device=device)
-    sd = fuse_lora(sd, synthetic.synthetic_lora(SD15, seed=1, device=device), lora_dtype=torch.float16)
-    model = StableDiffusionPipeline(unet.UNet2DConditionModel(SD15, sd, device=device, dtype=torch.float16), DDIMScheduler.sd15(),
-                                    tokenizer=synthetic.SyntheticTokenizer(), device=device, dtype=torch.float16)
-    solver = generation.Generator(model, 50, DDIMScheduler.sd15(), forward_cons_model=model, reverse_cons_model=model,
-                                  reverse_timesteps=[259, 519, 779, 999], forward_timesteps=[19, 259, 519, 779])
-    g = torch.Generator().manual_seed(453645634)                          # running/sd1.5/launch_generation_iCD_sd1.5.sh:32
-    latents = torch.randn(batch, 4, 64, 64, generator=g).to(device)      # B independent samples (throughput run)
-    ctx = torch.randn(2 * batch, 77, 768, generator=g).to(device=device, dtype=torch.float16)
-    solver.context = ctx
+class SD15Workload:
+    """Full-width SD1.5 + fused LoRA behind generation.Generator: BASELINE configs[1] (reverse, B = 32) and configs[2] (inversion +
+    reverse with p2p.AttentionStore, B = 8) share one set of weights."""
 
-    def step():
-        return solver.cons_generation(latents, guidance_scale=7.0, w_embed_dim=512, dynamic_guidance=False, tau1=1.0, tau2=1.0)[-1]
-    del sd
-    return step, solver, None, SD15, model.unet
+    def __init__(self, device):
+        from invertible_cd_amd import generation, synthetic, unet
+        from invertible_cd_amd.pipelines import StableDiffusionPipeline
+        from invertible_cd_amd.schedulers import DDIMScheduler
+        from invertible_cd_amd.unet_config import SD15
+        from invertible_cd_amd.loading import fuse_lora
+        # synthetic weights generated directly on this rank's GPU (seeded per tensor), LoRA (rank 64, alpha 8) fused at load
+        sd = synthetic.synthetic_state_dict(SD15, seed=0, device=device)
+        sd = fuse_lora(sd, synthetic.synthetic_lora(SD15, seed=1, device=device), lora_dtype=torch.float16)
+        self.cfg, self.device = SD15, device
+        self.model = StableDiffusionPipeline(unet.UNet2DConditionModel(SD15, sd, device=device, dtype=torch.float16), DDIMScheduler.sd15(),
+                                             tokenizer=synthetic.SyntheticTokenizer(), device=device, dtype=torch.float16)
+        self.net = self.model.unet
+        self.solver = generation.Generator(self.model, 50, DDIMScheduler.sd15(), forward_cons_model=self.model, reverse_cons_model=self.model,
+                                           reverse_timesteps=[259, 519, 779, 999], forward_timesteps=[19, 259, 519, 779])
+        self.solver.latent2image = lambda z, return_type="np": None        # cons_inversion's image_rec decode is outside the path (8d)
+        del sd
+
+    def inputs(self, batch):
+        g = torch.Generator().manual_seed(453645634)                     # running/sd1.5/launch_generation_iCD_sd1.5.sh:32
+        latents = torch.randn(batch, 4, 64, 64, generator=g).to(self.device)            # B independent samples (throughput run)
+        ctx = torch.randn(2 * batch, 77, 768, generator=g).to(device=self.device, dtype=torch.float16)
+        return latents, ctx
+
+    def reverse_step(self, batch):
+        latents, ctx = self.inputs(batch)
+
+        def step():
+            self.solver.context = ctx
+            return self.solver.cons_generation(latents, guidance_scale=7.0, w_embed_dim=512, dynamic_guidance=False, tau1=1.0, tau2=1.0)[-1]
+        return step
+
+    def edit_step(self, batch):
+        """configs[2]: 4-step forward inversion (w = 0) + 4-step reverse (gs 19, tau 0.8) with an AttentionStore registered; a fresh
+        controller per pass, as running/sd1.5/edit.py builds one per image group."""
+        from invertible_cd_amd import p2p
+        latents, ctx = self.inputs(batch)
+
+        def step():
+            self.solver.context = ctx
+            start = self.solver.cons_inversion(latents, guidance_scale=0.0, w_embed_dim=512, seed=5)[1][0]
+            ctrl = p2p.AttentionStore()
+            p2p.register_attention_control(self.model, ctrl)
+            try:
+                out = self.solver.cons_generation(start, guidance_scale=19.0, w_embed_dim=512, dynamic_guidance=True, tau1=0.8, tau2=0.8,
+                                                  controller=ctrl)[-1]
+            finally:
+                p2p.register_attention_control(self.model, None)
+            step.stored = sum(len(v) for v in ctrl.attention_store.values())
+            return out
+        step.stored = 0
+        return step
 
 
-def build_sdxl(batch, device):
-    from invertible_cd_amd import generation_sdxl, synthetic, unet
-    from invertible_cd_amd.pipelines import StableDiffusionXLPipeline
-    from invertible_cd_amd.schedulers import DDIMScheduler
-    from invertible_cd_amd.unet_config import SDXL
-    sd = synthetic.synthetic_state_dict(SDXL, seed=0, device=device, dtype=torch.float16)
-    pipe = StableDiffusionXLPipeline(unet.UNet2DConditionModel(SDXL, sd, device=device, dtype=torch.float16), DDIMScheduler.sdxl(),
-                                     device=device)
-    inp = synthetic.synthetic_inputs(SDXL, batch, 128, 128, seed=0, device="cpu")
-    emb = {"prompt_embeds": inp["context"].to(device, torch.float16), "text_embeds": inp["text_embeds"].to(device, torch.float16),
-           "time_ids": inp["time_ids"].to(device)}
-    latents = inp["latents"].to(device, torch.float16)
-    prompts = ["x"] * batch
+class SDXLWorkload:
+    """Full-width SDXL behind generation_sdxl: configs[3]'s per-GPU share (reverse, 8 images / GPU) and configs[4]'s (3-step inversion
+    + 3-step reverse with dynamic guidance, 16 images / GPU) on one set of weights."""
 
-    def step():
-        return generation_sdxl.sample_deterministic(pipe, prompts, latents=latents, num_inference_steps=4, guidance_scale=7.0,
-                                                    is_sdxl=True, timesteps=[249, 499, 699, 999],
-                                                    compute_embeddings_fn=lambda p, o, c: dict(emb), return_latent=True)[1]
-    pipe.vae = None
-    del sd
-    return step, None, None, SDXL, pipe.unet
+    def __init__(self, device):
+        from invertible_cd_amd import synthetic, unet
+        from invertible_cd_amd.pipelines import StableDiffusionXLImg2ImgPipeline, StableDiffusionXLPipeline
+        from invertible_cd_amd.schedulers import DDIMScheduler
+        from invertible_cd_amd.unet_config import SDXL
+        sd = synthetic.synthetic_state_dict(SDXL, seed=0, device=device, dtype=torch.float16)
+        self.cfg, self.device = SDXL, device
+        self.net = unet.UNet2DConditionModel(SDXL, sd, device=device, dtype=torch.float16)
+        self.pipe = StableDiffusionXLPipeline(self.net, DDIMScheduler.sdxl(), device=device)
+        self.fwd = StableDiffusionXLImg2ImgPipeline(self.net, DDIMScheduler.sdxl(), device=device)
+        self.pipe.vae = None
+        del sd
+
+    def inputs(self, batch):
+        from invertible_cd_amd import synthetic
+        inp = synthetic.synthetic_inputs(self.cfg, batch, 128, 128, seed=0, device="cpu")
+        emb = {"prompt_embeds": inp["context"].to(self.device, torch.float16), "text_embeds": inp["text_embeds"].to(self.device, torch.float16),
+               "time_ids": inp["time_ids"].to(self.device)}
+        return inp["latents"].to(self.device, torch.float16), emb
+
+    def reverse_step(self, batch):
+        from invertible_cd_amd import generation_sdxl
+        latents, emb = self.inputs(batch)
+        prompts = ["x"] * batch
+
+        def step():
+            return generation_sdxl.sample_deterministic(self.pipe, prompts, latents=latents, num_inference_steps=4, guidance_scale=7.0,
+                                                        is_sdxl=True, timesteps=[249, 499, 699, 999],
+                                                        compute_embeddings_fn=lambda p, o, c: dict(emb), return_latent=True)[1]
+        return step
+
+    def edit_step(self, batch):
+        """configs[4]: running/sdxl/edit.py:196-226 with the 3-step sets of README.md:59,62: inverse_sample_deterministic (w = 0) then
+        sample_deterministic with dynamic guidance gs 19, tau 0.7 (running/sdxl/launch_editing_iCD_sdxl.sh:11-18)."""
+        from invertible_cd_amd import generation_sdxl as G
+        latents, emb = self.inputs(batch)
+        src, dst = ["src"] * batch, ["dst"] * batch
+        fn = lambda p, o, c: dict(emb)
+
+        def step():
+            inv = G.inverse_sample_deterministic(self.fwd, latents, src, num_inference_steps=3, timesteps=[19, 339, 699], guidance_scale=0.0,
+                                                 is_sdxl=True, compute_embeddings_fn=fn, seed=3)
+            return G.sample_deterministic(self.pipe, dst, latents=inv, num_inference_steps=3, guidance_scale=19.0, is_sdxl=True,
+                                          timesteps=[339, 699, 999], compute_embeddings_fn=fn, use_dynamic_guidance=True, tau1=0.7,
+                                          tau2=0.7, return_latent=True)[1]
+        return step
 
 
 def hbm_traffic(arch, batch, family):
@@ -189,19 +275,76 @@ def to_uint8_images(img):
     return ((img.float() / 2 + 0.5).clamp(0, 1) * 255).round().to(torch.uint8).permute(0, 2, 3, 1).contiguous()
 
 
-def run_arch(a, arch, batch, steps, warmup, device, world, rank, primary):
-    """Warm up, time `steps` passes of the hot path + the ONE end-of-run all-gather, return the JSON fields."""
+def cuda_sync():
+    if torch.cuda.is_available():               # (the gloo world-2 test drives time_leg on CPU tensors)
+        torch.cuda.synchronize()
+
+
+def time_leg(step, steps, warmup, batch, device, world, rank, decode=None, events_family=None):
+    """W untimed passes, then EXACTLY `steps` timed passes bracketed by barrier + synchronize on both sides, the ONE all-gather of
+    the produced samples inside the timed region; MAX over ranks.  events_family: bracket the launches of that kernel family with
+    HIP events during the timed region (the roofline leg); None: no events at all.  Returns (seconds, per-rank seconds list,
+    event profile or None)."""
     import torch.distributed as dist
     from invertible_cd_amd import _lib, dist_utils
-    step, solver, sd, cfg, net = (build_sd15 if arch == "sd15" else build_sdxl)(batch, device)
-    net.set_option("ln_inline_stats", a.ln_inline_stats).set_option("xattn_fusion", a.xattn_fusion)     # per-handle A/B switches
 
     def sync_all():
-        torch.cuda.synchronize()
+        cuda_sync()
         if world > 1:
             dist.barrier()
-            torch.cuda.synchronize()
+            cuda_sync()
 
+    for _ in range(warmup):
+        step()
+    sync_all()
+    if events_family:
+        _lib.profile_enable(True, only=[events_family])
+    outs = []
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        outs.append(step())
+    local = torch.stack(outs).reshape(-1, *outs[0].shape[1:]).to(torch.float16)
+    if decode is not None:
+        local = torch.cat([decode(local[i:i + batch]) for i in range(0, local.shape[0], batch)])
+    ids = torch.arange(local.shape[0], device=device, dtype=torch.int64) * world + rank
+    gathered, gids = dist_utils.gather_samples(local, ids)                # ONE all-gather at the end (RCCL over xGMI)
+    sync_all()
+    dt = time.perf_counter() - t0
+    prof = None
+    if events_family:
+        prof = _lib.profile_read()
+        _lib.profile_enable(False)
+    per_rank = [dt]
+    if world > 1:
+        tt = torch.zeros(world, device=device, dtype=torch.float64)
+        tt[rank] = dt
+        dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+        per_rank = [float(v) for v in tt.tolist()]
+        dt = max(per_rank)
+    assert gathered.shape[0] == batch * steps * world and bool(torch.equal(gids, torch.arange(batch * steps * world, device=device)))
+    assert gathered.dtype == torch.uint8 or bool(torch.isfinite(gathered).all())
+    return dt, per_rank, prof, outs[-1]
+
+
+def family_table(step):
+    """One pass with every executor launch bracketed by HIP events: the per-family table, and the dominant family = the one carrying
+    the most algorithmic work (stable from run to run, unlike a max over times when two families are within a few per cent)."""
+    from invertible_cd_amd import _lib
+    torch.cuda.synchronize()
+    _lib.profile_enable(True)
+    step()
+    torch.cuda.synchronize()
+    fam = {k: v for k, v in _lib.profile_read().items() if v["launches"]}
+    _lib.profile_enable(False)
+    return fam, max(fam, key=lambda k: (fam[k]["flops"], fam[k]["ms"]))
+
+
+def run_reverse(a, wl, arch, batch, steps, warmup, device, world, rank, primary):
+    """BASELINE configs[1] (SD1.5, the `value` of the line) / configs[3]'s per-GPU share (SDXL): the 4-step reverse loop."""
+    import torch.distributed as dist
+    from invertible_cd_amd import dist_utils
+    wl.net.set_option("ln_inline_stats", a.ln_inline_stats).set_option("xattn_fusion", a.xattn_fusion)     # per-handle A/B switches
+    step = wl.reverse_step(batch)
     vae_m = None
     if (rank == 0 and not a.no_vae and primary) or a.gather == "images" or (world > 1 and primary):
         from invertible_cd_amd import synthetic, vae as vae_mod
@@ -213,80 +356,58 @@ def run_arch(a, arch, batch, steps, warmup, device, world, rank, primary):
     def decode_u8(lat):
         return to_uint8_images(vae_m.decode((lat.float() / vae_m.config.scaling_factor).clamp(-30, 30))["sample"])
 
-    fam_table = None
-    for i in range(warmup):
-        if i == warmup - 1 and not a.no_profile:      # last warm-up pass: per-family table (every launch recorded)
-            torch.cuda.synchronize()
-            _lib.profile_enable(True)
-            step()
-            torch.cuda.synchronize()
-            fam_table = {k: v for k, v in _lib.profile_read().items() if v["launches"]}
-            _lib.profile_enable(False)
-        else:
-            step()
-    if a.gather == "images":
+    decode = decode_u8 if a.gather == "images" else None
+    for _ in range(max(0, warmup - 1)):
+        step()
+    fam_table = dominant = None
+    if not a.no_profile:
+        fam_table, dominant = family_table(step)          # the last warm-up pass
+    elif warmup:
+        step()
+    if decode is not None:
         decode_u8(step()[:2])
-    sync_all()
-    # dominant family = the one carrying the most algorithmic work (stable from run to run, unlike a max over times
-    # when two families are within a few per cent of each other)
-    dominant = max(fam_table, key=lambda k: (fam_table[k]["flops"], fam_table[k]["ms"])) if fam_table else None
+    # Event-overhead A/B: pass A = K steps with HIP events around the dominant family (the roofline), pass B = K steps with no events
+    # at all.  `value` is pass B when the events cost more than 1 %, else pass A (then the roofline IS the timed region's).
+    dt_ev = prof = None
     if not a.no_profile:
-        # timed region: HIP events only around the dominant kernel family (keeps event overhead out of `value`)
-        _lib.profile_enable(True, only=[dominant] if dominant else None)
-    outs = []
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        outs.append(step())
-    local = torch.stack(outs).reshape(-1, *outs[0].shape[1:]).to(torch.float16)
-    if a.gather == "images":
-        local = torch.cat([decode_u8(local[i:i + batch]) for i in range(0, local.shape[0], batch)])
-    ids = torch.arange(local.shape[0], device=device, dtype=torch.int64) * world + rank
-    gathered, gids = dist_utils.gather_samples(local, ids)                # ONE all-gather at the end (RCCL over xGMI)
-    sync_all()
-    dt = time.perf_counter() - t0
-    prof = None
-    if not a.no_profile:
-        prof = _lib.profile_read()
-        _lib.profile_enable(False)
-    if world > 1:
-        tt = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    assert gathered.shape[0] == batch * steps * world and bool(torch.equal(gids, torch.arange(batch * steps * world, device=device)))
-    assert gathered.dtype == torch.uint8 or bool(torch.isfinite(gathered).all())
+        dt_ev, _, prof, _ = time_leg(step, steps, 0, batch, device, world, rank, decode, events_family=dominant)
+    dt_plain, per_rank, _, last = time_leg(step, steps, 0, batch, device, world, rank, decode)
+    ev_over = (dt_ev - dt_plain) / dt_plain if dt_ev else None
+    use_plain = dt_ev is None or ev_over > 0.01
+    dt = dt_plain if use_plain else dt_ev
 
     # N > 1: the reference's payload - uint8 images + int64 ids in ONE all-gather (running/sd1.5/generate.py:372-383) -
     # timed on its own after the timed region (the per-rank VAE decode before it is the separate vae_decode leg)
     image_gather = None
     if world > 1 and primary and vae_m is not None and a.gather != "images":
-        u8 = decode_u8(outs[-1])
+        u8 = decode_u8(last)
         ids1 = torch.arange(batch, device=device, dtype=torch.int64) * world + rank
         dist_utils.gather_samples(u8, ids1)
-        sync_all()
+        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
         tg = time.perf_counter()
         g8, _ = dist_utils.gather_samples(u8, ids1)
-        sync_all()
+        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
         tg = time.perf_counter() - tg
         image_gather = {"payload": f"uint8 [{batch},{u8.shape[1]},{u8.shape[2]},3] per rank + int64 ids", "ms": round(tg * 1e3, 3),
                         "bytes_per_rank": int(u8.numel()), "gathered_images": int(g8.shape[0])}
 
     # the same loop with the reference's CFG-doubled batching (uncond rows computed and discarded), for the record
     ref_batching = None
-    if solver is not None and rank == 0 and primary and not a.no_ref_batching:
-        solver.eliminate_dead_uncond = False
+    if arch == "sd15" and rank == 0 and primary and not a.no_ref_batching:
+        wl.solver.eliminate_dead_uncond = False
         step(); torch.cuda.synchronize()
         t1 = time.perf_counter()
         for _ in range(2):
             step()
         torch.cuda.synchronize()
         ref_batching = batch * 2 / (time.perf_counter() - t1)
-        solver.eliminate_dead_uncond = True
+        wl.solver.eliminate_dead_uncond = True
 
     # VAE decode of one step's latents, timed separately ("VAE decode ... reported separately"); it is
     # NOT part of `value` unless --gather images.  SDXL latents are 128x128 -> 1024x1024 images.
     vae_leg = None
     if rank == 0 and not a.no_vae and primary and vae_m is not None:
-        lat = (outs[-1].float() / vae_m.config.scaling_factor).clamp(-30, 30)
+        lat = (last.float() / vae_m.config.scaling_factor).clamp(-30, 30)
         vae_m.decode(lat[:2]); torch.cuda.synchronize()
         tv = time.perf_counter()
         img = vae_m.decode(lat)["sample"]
@@ -298,9 +419,9 @@ def run_arch(a, arch, batch, steps, warmup, device, world, rank, primary):
                    "finite": ok, "images_per_sec_unet_plus_decode_1gpu": round(1.0 / (per_img_unet + tv / batch), 2),
                    "note": "AutoencoderKL decode of one step's latents on the same HIP operators, synthetic weights; not in `value`"}
         del img
-    del vae_m, gathered, local, outs
+    del vae_m
     if rank != 0:
-        return None, sd, cfg
+        return None
     images = batch * steps * world
     value = images / dt
     algo = ALGO_TFLOP_PER_SAMPLE_FWD[arch] * 4e12                       # algorithmic FLOP per image (cond rows only)
@@ -317,38 +438,69 @@ def run_arch(a, arch, batch, steps, warmup, device, world, rank, primary):
                    "dead_uncond_rows_eliminated": arch == "sd15", "lora_fused": arch == "sd15",
                    "parallelism": f"dp{world}", "collective": f"one all-gather (RCCL) of the {payload} + int64 ids at the end of the timed region"},
         "per_unet_ms": round(dt / steps / 4 * 1e3, 3),
+        "ms_per_step_per_rank": {"min": round(min(per_rank) / steps * 1e3, 3), "max": round(max(per_rank) / steps * 1e3, 3),
+                                 "ranks": len(per_rank)},
         "end_to_end_algorithmic_tflops_per_gpu": round(value / world * algo / 1e12, 1),
         "end_to_end_frac_of_mfma_peak": round(value / world * algo / PEAK_MFMA_F16, 4),
     }
+    if dt_ev is not None:
+        out["event_overhead"] = {"ms_per_step_with_events": round(dt_ev / steps * 1e3, 3), "ms_per_step_without_events": round(dt_plain / steps * 1e3, 3),
+                                 "frac": round(ev_over, 4), "value_from": "pass without events" if use_plain else "pass with events",
+                                 "note": "pass A: K steps with HIP events around the dominant family (the roofline); pass B: K steps with none"}
     if ref_batching is not None:
         out["value_reference_cfg_doubled_batching"] = round(ref_batching, 3)
     if image_gather is not None:
         out["image_gather"] = image_gather
     if prof is not None:
-        fam = fam_table or {k: v for k, v in prof.items() if v["launches"]}
-        dom = dominant or max(fam, key=lambda k: fam[k]["ms"])
-        d = prof[dom]                                   # measured over the timed region
+        fam = fam_table
+        d = prof[dominant]                              # measured over timed pass A
         if d["flops"] > 0:
             ach = d["flops"] / (d["ms"] * 1e-3)
-            roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach / 1e12, 1), "peak": round(PEAK_MFMA_F16 / 1e12, 1),
+            roof = {"bound": "mfma", "kernel": dominant, "achieved": round(ach / 1e12, 1), "peak": round(PEAK_MFMA_F16 / 1e12, 1),
                     "unit": "TFLOP/s", "frac": round(ach / PEAK_MFMA_F16, 4)}
         else:
             ach = d["bytes"] / (d["ms"] * 1e-3)
-            roof = {"bound": "hbm", "kernel": dom, "achieved": round(ach / 1e9, 1), "peak": PEAK_HBM / 1e9, "unit": "GB/s",
+            roof = {"bound": "hbm", "kernel": dominant, "achieved": round(ach / 1e9, 1), "peak": PEAK_HBM / 1e9, "unit": "GB/s",
                     "frac": round(ach / PEAK_HBM, 4)}
-        traffic, tsrc, tsha = hbm_traffic(arch, batch, dom)
+        traffic, tsrc, tsha = hbm_traffic(arch, batch, dominant)
         roof.update({"traffic": traffic, "traffic_source": tsrc, "traffic_kernels_sha": tsha, "kernels_sha": csrc_sha(),
                      "launches": d["launches"], "avg_launch_us": round(d["ms"] / d["launches"] * 1e3, 2),
-                     "algorithmic_per_launch": (d["flops"] or d["bytes"]) / d["launches"]})
+                     "algorithmic_per_launch": (d["flops"] or d["bytes"]) / d["launches"],
+                     "timed_pass": "A (K steps with events around this family)"})
         out["roofline"] = roof
         out["kernel_families"] = {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
                                       "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["flops"] else None,
                                       "gbps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["bytes"] else None}
                                   for k, v in fam.items()}
-        out["kernel_families_note"] = "per-family table from the last warm-up step; roofline from the timed region"
+        out["kernel_families_note"] = "per-family table from the last warm-up step; roofline from timed pass A"
     if vae_leg is not None:
         out["vae_decode"] = vae_leg
-    return out, sd, cfg
+    return out
+
+
+def run_edit(a, wl, arch, batch, steps, warmup, device, world, rank):
+    """BASELINE configs[2] (SD1.5: 4-step inversion + 4-step reverse with p2p.AttentionStore, 8 images / GPU) and configs[4]'s per-GPU
+    share (SDXL: 3 + 3 steps, dynamic guidance tau 0.7, 16 images / GPU): edited images / s, no events in the timed region."""
+    step = wl.edit_step(batch)
+    dt, per_rank, _, _ = time_leg(step, steps, warmup, batch, device, world, rank)
+    if rank != 0:
+        return None
+    evals = 8 if arch == "sd15" else 6
+    algo = ALGO_TFLOP_PER_SAMPLE_FWD[arch] * evals * 1e12
+    value = batch * steps * world / dt
+    out = {"metric": "iCD edited images/sec (inversion + reverse)", "value": round(value, 3), "unit": "images/sec", "n_gpus": world,
+           "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 3),
+           "ms_per_step_per_rank": {"min": round(min(per_rank) / steps * 1e3, 3), "max": round(max(per_rank) / steps * 1e3, 3), "ranks": len(per_rank)},
+           "config": {"workload": ("iCD-SD1.5 4-step forward inversion (w=0) + 4-step reverse (gs=19, tau=0.8) with p2p.AttentionStore registered, "
+                                   "batch=8/GPU, fp16, 64x64 latents" if arch == "sd15" else
+                                   "iCD-SDXL 3-step forward inversion (w=0) + 3-step reverse (gs=19, dynamic guidance tau=0.7), batch=16/GPU, fp16, "
+                                   "128x128 latents, timesteps fwd [19,339,699] rev [999,699,339]"),
+                      "per_gpu_batch": batch, "global_batch": batch * world, "unet_evals_per_step": evals, "parallelism": f"dp{world}"},
+           "end_to_end_algorithmic_tflops_per_gpu": round(value / world * algo / 1e12, 1),
+           "end_to_end_frac_of_mfma_peak": round(value / world * algo / PEAK_MFMA_F16, 4)}
+    if arch == "sd15":
+        out["attention_store_tensors_per_pass"] = int(step.stored)
+    return out
 
 
 def main():
@@ -366,31 +518,54 @@ def main():
     device = f"cuda:{local_rank}"
     import torch.distributed as dist
     from invertible_cd_amd import dist_utils
+    rccl = None
     if world > 1:
         dist_utils.init("nccl")                     # RCCL
         assert dist.get_world_size() == a.gpus and dist.get_backend() == "nccl"
+        # first contact with the fabric before anything is timed: every rank contributes its id to one all-gather
+        probe = [torch.zeros(1, device=device, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(probe, torch.tensor([rank], device=device, dtype=torch.int64))
+        assert [int(p) for p in probe] == list(range(world))
+        ver = torch.cuda.nccl.version()
+        rccl = {"rccl_world_size": dist.get_world_size(), "rccl_version": ".".join(str(v) for v in ver) if isinstance(ver, tuple) else str(ver),
+                "backend": dist.get_backend(), "devices": world}
     batch = a.batch or (32 if a.arch == "sd15" else 8)
-    out, sd, cfg = run_arch(a, a.arch, batch, a.steps, a.warmup, device, world, rank, primary=True)
-    # The default run also times BASELINE config 4's per-GPU half (SDXL, 8 images per GPU) and carries it as a sub-object of
-    # the same JSON line, so the driver's clock covers it too; `value` stays config 2 (the single-GPU metric configuration).
-    sdxl = None
-    if a.arch == "sd15" and not a.no_sdxl and not a.batch:
-        del sd
-        sd = None
+    default_run = a.arch == "sd15" and not a.batch
+    wl = (SD15Workload if a.arch == "sd15" else SDXLWorkload)(device)
+    out = run_reverse(a, wl, a.arch, batch, a.steps, a.warmup, device, world, rank, primary=True)
+    # The default run carries every BASELINE configuration's per-GPU share on the same JSON line, inside the driver's clock:
+    # `value` stays configs[1]; "edit" = configs[2] (B = 8, inversion + reverse with AttentionStore), "sdxl" = configs[3]'s 8 images
+    # per GPU, "sdxl_edit" = configs[4]'s 16 images per GPU (3 + 3 steps, dynamic guidance).
+    edit = sdxl = sdxl_edit = None
+    if default_run and not a.no_edit:
+        edit = run_edit(a, wl, "sd15", 8, max(1, min(a.steps, 5)), 1, device, world, rank)
+    cfg_for_cpu = wl.cfg
+    if default_run and not a.no_sdxl:
+        del wl
         torch.cuda.empty_cache()
-        saved = (a.no_vae, a.no_ref_batching)
+        wx = SDXLWorkload(device)
+        saved = a.no_vae
         a.no_vae = True
-        sdxl, _, _ = run_arch(a, "sdxl", 8, max(1, min(a.steps, 8)), max(1, min(a.warmup, 2)), device, world, rank, primary=False)
-        a.no_vae, a.no_ref_batching = saved
+        sdxl = run_reverse(a, wx, "sdxl", 8, max(1, min(a.steps, 8)), max(1, min(a.warmup, 2)), device, world, rank, primary=False)
+        a.no_vae = saved
+        if not a.no_edit:
+            sdxl_edit = run_edit(a, wx, "sdxl", 16, max(1, min(a.steps, 3)), 1, device, world, rank)
+        del wx
         torch.cuda.empty_cache()
     if rank != 0:
         return
+    if rccl is not None:
+        out["rccl"] = rccl
+    if edit is not None:
+        out["edit"] = edit
     if sdxl is not None:
-        keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "per_unet_ms", "config",
-                "end_to_end_algorithmic_tflops_per_gpu", "end_to_end_frac_of_mfma_peak", "roofline", "kernel_families")
+        keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "per_unet_ms", "ms_per_step_per_rank", "config",
+                "end_to_end_algorithmic_tflops_per_gpu", "end_to_end_frac_of_mfma_peak", "event_overhead", "roofline", "kernel_families")
         out["sdxl"] = {k: sdxl[k] for k in keep if k in sdxl}
+    if sdxl_edit is not None:
+        out["sdxl_edit"] = sdxl_edit
     if world == 1 and not a.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(a.arch, sd, cfg)
+        out["cpu_baseline"] = cpu_baseline(a.arch, None, cfg_for_cpu)
     print(json.dumps(out), file=_REAL_STDOUT, flush=True)
 
 

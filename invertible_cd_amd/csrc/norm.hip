@@ -335,12 +335,13 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_split_kernel(const float*
     const int chunk = tid % nchunk, rsub = tid / nchunk;
     if (rsub >= rpi) return;
     const int ch = chunk * 4, cpg = C / groups;
-    float sc[4], sh[4];
-#pragma unroll
+    float sc[4], mu[4], be[4];                  // (v - mean) * sc + beta: the folded form v * sc + (beta - mean * sc) would round the
+#pragma unroll                                 // shift at the magnitude of mean * sc - digits this path exists to keep
     for (int e = 0; e < 4; ++e) {
         const int g = (ch + e) / cpg;
         sc[e] = s_rstd[g] * gamma[ch + e];
-        sh[e] = beta[ch + e] - s_mean[g] * sc[e];
+        mu[e] = s_mean[g];
+        be[e] = beta[ch + e];
     }
     const float* base = x + (long long)b * HW * C + ch;
     half_t* ob = out + (long long)b * HW * 3 * C;
@@ -350,7 +351,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_split_kernel(const float*
         float o[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            float f = v[e] * sc[e] + sh[e];
+            float f = (v[e] - mu[e]) * sc[e] + be[e];
             if (silu) f = f / (1.0f + expf(-f));                 // exact expf: this path trades speed for fp32 fidelity
             o[e] = f;
         }

@@ -20,20 +20,37 @@ def get_rank():
     return dist.get_rank() if dist.is_initialized() else 0
 
 
-def init(backend=None):
-    """utils/dist_utils.py:8-22: env:// rendezvous with single-process defaults; binds the rank to its GPU."""
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(('127.0.0.1', 0))
+        return sk.getsockname()[1]
+
+
+def init(backend=None, timeout_s=None):
+    """utils/dist_utils.py:8-22: env:// rendezvous with single-process defaults; binds the rank to its GPU.
+
+    Every default only fills what the launcher left unset: a single-process run takes a port that is free right now (the
+    reference's fixed 29500 fails next to a stale listener), HSA_ENABLE_IPC_MODE_LEGACY=0 (dmabuf IPC, what RCCL needs on this
+    driver stack) is set only when the variable is absent.  The collectives time out after ICD_DIST_TIMEOUT_S seconds (default
+    600) instead of hanging a node when a rank died."""
+    import datetime
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-    os.environ.setdefault('MASTER_PORT', '29500')
     os.environ.setdefault('RANK', '0')
     os.environ.setdefault('LOCAL_RANK', '0')
     os.environ.setdefault('WORLD_SIZE', '1')
-    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')     # dmabuf IPC for RCCL on this driver
+    if 'MASTER_PORT' not in os.environ:
+        if int(os.environ['WORLD_SIZE']) > 1:
+            raise RuntimeError('dist_utils.init: WORLD_SIZE > 1 needs the launcher\'s MASTER_PORT (torchrun / bench.py --gpus N set it)')
+        os.environ['MASTER_PORT'] = str(_free_port())
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     if backend is None:
         backend = 'nccl' if torch.cuda.is_available() else 'gloo'
     if torch.cuda.is_available():
         torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
     if not dist.is_initialized():
-        dist.init_process_group(backend=backend, init_method='env://')
+        t = float(timeout_s if timeout_s is not None else os.environ.get('ICD_DIST_TIMEOUT_S', '600'))
+        dist.init_process_group(backend=backend, init_method='env://', timeout=datetime.timedelta(seconds=t))
 
 
 def prepare_val_prompts(all_text, bs=20, max_cnt=5000):

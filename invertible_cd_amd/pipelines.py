@@ -110,8 +110,40 @@ class StableDiffusionXLPipeline:
         latents = self._randn(shape, generator, device, dtype) if latents is None else latents.to(device)
         return latents * self.scheduler.init_noise_sigma
 
-    def encode_prompt(self, prompt, device, num_images_per_prompt, do_classifier_free_guidance):
-        raise NotImplementedError("text encoding is outside the U-Net hot path: pass compute_embeddings_fn")
+    @torch.no_grad()
+    def encode_prompt(self, prompt, device=None, num_images_per_prompt=1, do_classifier_free_guidance=False, negative_prompt=None):
+        """The `compute_embeddings_fn=None` branch of the samplers: `pipe.encode_prompt(prompt, device, 1, False)[0]`
+        (utils/generation_sdxl.py:242,374), served by the text encoders attached to this pipeline (clip.py on the HIP operators,
+        or any object with the transformers call interface).  With both encoders it follows diffusers' SDXL rule - penultimate
+        hidden states of the two encoders concatenated ([B, 77, 768 + 1280]), pooled output of the second; with one encoder the
+        SD rule - `text_encoder(ids)[0]`.  Returns (prompt_embeds, negative_prompt_embeds, pooled, negative_pooled); the negative
+        pair encodes `negative_prompt` (default "") and is None without classifier-free guidance."""
+        pairs = [(t, e) for t, e in ((self.tokenizer, self.text_encoder), (self.tokenizer_2, self.text_encoder_2)) if e is not None]
+        if not pairs or any(t is None for t, _ in pairs):
+            raise RuntimeError("encode_prompt: attach tokenizer(s) and text_encoder(s) to the pipeline (load_models_xl components "
+                               "'text_encoder_state_dict' / 'text_encoder_2_state_dict'), or pass compute_embeddings_fn")
+        device = torch.device(device) if device is not None else self._execution_device
+        texts = [prompt] if isinstance(prompt, str) else list(prompt)
+
+        def run(batch):
+            hidden, pooled = [], None
+            for tok, enc in pairs:
+                ids = tok(batch, padding="max_length", max_length=tok.model_max_length, truncation=True, return_tensors="pt").input_ids
+                if len(pairs) == 1:
+                    return enc(ids.to(enc.device))[0].to(device), None
+                out = enc(ids.to(enc.device), output_hidden_states=True)
+                pooled = out[0]
+                hidden.append(out.hidden_states[-2])
+            emb = torch.cat(hidden, dim=-1)
+            return emb.to(device), pooled.reshape(emb.shape[0], -1).to(device)
+
+        rep = lambda t: None if t is None else t.repeat_interleave(num_images_per_prompt, dim=0)
+        emb, pooled = run(texts)
+        neg = neg_pooled = None
+        if do_classifier_free_guidance:
+            negs = [negative_prompt or ""] * len(texts) if not isinstance(negative_prompt, (list, tuple)) else list(negative_prompt)
+            neg, neg_pooled = run(negs)
+        return rep(emb.to(self.unet.dtype)), rep(None if neg is None else neg.to(self.unet.dtype)), rep(pooled), rep(neg_pooled)
 
 
 class StableDiffusionXLImg2ImgPipeline(StableDiffusionXLPipeline):

@@ -66,3 +66,60 @@ def test_single_process_defaults(golden_dir):
             assert [list(map(int, x)) for x in idx] == e["index"]
     x, i = dist_utils.gather_samples(torch.arange(6).reshape(6, 1).float(), torch.tensor([3, 1, 2, 0, 5, 4]))
     assert i.tolist() == [0, 1, 2, 3, 4, 5] and x[:, 0].tolist() == [3.0, 1.0, 2.0, 0.0, 5.0, 4.0]
+
+
+def _bench_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world))
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from invertible_cd_amd import dist_utils
+    dist_utils.init(backend="gloo", timeout_s=60)
+    calls = []
+
+    def step():                                   # rank r "produces" 3 samples per pass, rank 1 is the slower one
+        calls.append(1)
+        import time
+        time.sleep(0.02 * (rank + 1))
+        return torch.full((3, 4, 2, 2), float(rank))
+    dt, per_rank, prof, last = bench.time_leg(step, steps=4, warmup=2, batch=3, device="cpu", world=world, rank=rank)
+    ok = len(calls) == 6 and prof is None and len(per_rank) == world and dt == max(per_rank) and per_rank[1] > per_rank[0] * 0.9
+    ok &= dt >= 4 * 0.04 * 0.9 and tuple(last.shape) == (3, 4, 2, 2)
+    dist.barrier()
+    q.put((rank, bool(ok), per_rank))
+    dist.destroy_process_group()
+
+
+def test_bench_timed_leg_world2_takes_the_max_over_ranks_and_gathers_every_sample():
+    """bench.py's timed leg under a 2-rank gloo group: W untimed + exactly K timed passes per rank, ONE gather of batch * K * world
+    samples with the ids in global order (asserted inside time_leg), the reported time is the MAX over ranks and every rank sees
+    the same per-rank list (what the JSON line prints as ms_per_step_per_rank)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [r[:2] for r in res] == [(0, True), (1, True)] and res[0][2] == res[1][2]
+
+
+def test_dist_init_picks_a_free_port_and_refuses_a_multi_rank_run_without_one(monkeypatch):
+    from invertible_cd_amd import dist_utils
+    import pytest
+    for k in ("MASTER_PORT", "MASTER_ADDR", "RANK", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    with pytest.raises(RuntimeError, match="MASTER_PORT"):
+        dist_utils.init(backend="gloo")
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    monkeypatch.setenv("HSA_ENABLE_IPC_MODE_LEGACY", "7")            # a value the launcher chose is kept
+    dist_utils.init(backend="gloo", timeout_s=30)
+    try:
+        assert int(os.environ["MASTER_PORT"]) > 1024 and os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] == "7"
+        assert dist.is_initialized() and dist.get_world_size() == 1
+    finally:
+        dist.destroy_process_group()

@@ -39,7 +39,15 @@ def _env():
     env = dict(os.environ)
     env["ICD_ROOT"] = ROOT
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.pop("MASTER_PORT", None)                 # bench.py / the tests below pick a free port
     return env
+
+
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
 
 
 @needs2
@@ -47,7 +55,7 @@ def test_world2_nccl_gather_of_uint8_images(tmp_path):
     w = tmp_path / "worker.py"
     w.write_text(WORKER)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", "29541", str(w)]
+           "--master-port", str(_free_port()), str(w)]
     r = subprocess.run(cmd, env=_env(), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "NCCL_GATHER_OK 2" in r.stdout
@@ -58,12 +66,12 @@ def test_bench_gpus_2_spawns_two_rccl_ranks():
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--batch", "4",
            "--no-cpu-baseline", "--no-vae", "--no-ref-batching"]
     env = _env()
-    env["MASTER_PORT"] = "29542"
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["config"]["global_batch"] == 8 and d["value"] > 0
+    assert d["rccl"]["rccl_world_size"] == 2 and d["ms_per_step_per_rank"]["ranks"] == 2
 
 
 def test_bench_refuses_more_gpus_than_visible():

@@ -108,6 +108,16 @@ def test_sdxl_prompts_to_pil_images():
     emb_fn = lambda p, o, c: generation_sdxl.compute_embeddings(p, o, c, 0, [enc1, enc2], [tok, tok], is_train=False)
     e = emb_fn(prompts, [(1024, 1024)] * 2, [(0, 0)] * 2)
     assert e["prompt_embeds"].shape == (2, 77, 128) and e["text_embeds"].shape == (2, pooled_dim) and e["time_ids"].shape == (2, 6)
+    # pipe.encode_prompt - the samplers' compute_embeddings_fn=None branch (utils/generation_sdxl.py:242,374) - is served by the same
+    # encoders: [0] is the concatenated penultimate hidden states, [2] the pooled output of the second encoder
+    pe, ne, pooled, npooled = pipe.encode_prompt(prompts, "cuda", 1, False)
+    assert torch.equal(pe, e["prompt_embeds"].to(pe.dtype)) and torch.equal(pooled, e["text_embeds"]) and ne is None and npooled is None
+    pe2, ne2, _, np2 = pipe.encode_prompt(prompts[0], "cuda", 2, True)
+    assert pe2.shape == (2, 77, 128) and torch.equal(pe2[0], pe[0]) and torch.equal(pe2[1], pe[0])
+    assert ne2.shape == pe2.shape and np2.shape == (2, pooled_dim) and not torch.equal(ne2, pe2)
+    bare = StableDiffusionXLPipeline(u, DDIMScheduler.sdxl())
+    with pytest.raises(RuntimeError, match="text_encoder"):
+        bare.encode_prompt(prompts, "cuda", 1, False)
     lat = torch.randn(2, 4, 16, 16, generator=torch.Generator().manual_seed(0)).cuda().half()
     images, latents = generation_sdxl.sample_deterministic(pipe, prompts, latents=lat, num_inference_steps=4, guidance_scale=7.0,
                                                            is_sdxl=True, timesteps=[249, 499, 699, 999],

@@ -167,3 +167,31 @@ def test_fp32_fidelity_survives_activations_beyond_the_fp16_range():
     e = rel_l2(good.cpu(), ref)
     print(f"[vae fp32-fidelity, overflowing activations] rel-L2 = {e:.3e}  max|ref| = {float(ref.abs().max()):.3e}")
     assert torch.isfinite(good).all() and e < 1e-3
+
+
+def test_fp32_groupnorm_keeps_its_digits_under_a_large_dc_offset_and_the_guard_sees_nan():
+    """icd_groupnorm_f32_split on groups whose |mean| is ~1e3 standard deviations (real SDXL-VAE activations do this - the reason the
+    fp32 path exists): raw fp32 sums of x and x^2 would lose ~6 of 7 digits of the variance to cancellation; the kernel sums
+    (x - pivot) with the group's first element as pivot, like torch's Welford stays accurate.  Also: a NaN activation must trip the
+    finiteness guard in front of icd_split_cast (icd_absmax maps NaN to +inf; fmaxf alone drops it)."""
+    import pytest
+    from invertible_cd_amd import ops
+    B, HW, Cc = 2, 4096, 128
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(B * HW, Cc, generator=g, dtype=torch.float64)
+    x = x + 1000.0 * (1.0 + torch.arange(Cc, dtype=torch.float64) // 4 % 7)[None, :]      # per-group DC offsets of 1e3..7e3 sigma
+    gamma, beta = torch.randn(Cc, generator=g), torch.randn(Cc, generator=g)
+    ref = torch.nn.functional.group_norm(x.reshape(B, HW, Cc).permute(0, 2, 1), 32, gamma.double(), beta.double(), 1e-6).permute(0, 2, 1).reshape(B * HW, Cc)
+    x32 = x.float().cuda()
+    out = ops.groupnorm_f32_split(x32, B, HW, gamma.cuda(), beta.cuda(), 1e-6, False).float()
+    got = (out[:, :Cc] + out[:, Cc:2 * Cc]).cpu()                                           # hi + lo
+    ref32 = torch.nn.functional.group_norm(x.float().reshape(B, HW, Cc).permute(0, 2, 1).double(), 32, gamma.double(), beta.double(), 1e-6)
+    ref32 = ref32.permute(0, 2, 1).reshape(B * HW, Cc)                                      # what fp32-rounded inputs allow at best
+    e, e_in = rel_l2(got, ref), rel_l2(ref32, ref)
+    print(f"[fp32 GroupNorm, mean/std ~ 1e3] rel-L2 vs fp64 = {e:.3e} (input rounding alone: {e_in:.3e})")
+    assert e < 3e-4 and e < 4 * e_in + 1e-5             # x itself carries 2^-24 * 1e3 sigma ~ 6e-5 sigma of input rounding
+    bad = x32.clone()
+    bad[5, 7] = float("nan")
+    assert ops.absmax(bad) == float("inf")
+    with pytest.raises(FloatingPointError):
+        ops.split_cast_guarded(bad)

@@ -184,6 +184,12 @@ int icd_attention_fused(const void* q, const void* k, const void* vt, void* out,
  * text encoders behind `text_encoder(ids)[0]` (utils/generation.py:293,301) and `encode_prompt`
  * (utils/generation_sdxl.py:31-44). */
 #define ICD_ATTN_CAUSAL 1
+/* ICD_ATTN_Q_PRESCALED: q already carries scale * log2(e) (the executor folds the factor into the query projection's weights at
+ * load time, so no extra rounding happens): the scores are base-2 exponents as they leave the matrix cores, `scale` is ignored,
+ * and for head dims 40 / 64 / 80 the running softmax offset is subtracted by the MFMA itself (no scale FMA per score on the
+ * VALU, which bounds this kernel).  ICD_ATTN_TUNE_MODE0 (A/B, tests): keep the VALU form for a prescaled q. */
+#define ICD_ATTN_Q_PRESCALED 2
+#define ICD_ATTN_TUNE_MODE0  4
 int icd_attention_fused_ex(const void* q, const void* k, const void* vt, void* out, int32_t B, int32_t H, int32_t Nq,
                            int32_t Nk, int32_t d, int32_t ldq, int32_t ldk, int32_t ldvt, int32_t ldo,
                            int64_t vt_batch_stride, float scale, int32_t flags, void* stream);

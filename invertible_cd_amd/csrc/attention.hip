@@ -25,6 +25,8 @@
 
 namespace {
 
+// one fp16 1.0 followed by zeros: the "ones column" of the K tile in head-dim slot d (MODE 1 of attn_fused_kernel)
+__device__ __attribute__((aligned(16))) const half_t icd_e0_page[8] = {1, 0, 0, 0, 0, 0, 0, 0};
 __device__ const half_t icd_ones_page[64] = {
     1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1,
     1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
@@ -66,7 +68,18 @@ struct AttnK {
 // tile t, second S accumulator set, 3-stage ring) is not faster, QT = 2 at d = 64 spills - at one query tile per wave
 // every ds_read_b128 feeds exactly one MFMA, which is 125 B/clk of LDS traffic per CU at full MFMA rate: the loop is
 // LDS-bandwidth bound, and only more MFMAs per fragment (QT = 2 where the registers allow it: d <= 48) lift that.
-template <int KS, int DT, int QT, int OCC, int NST>
+//
+// MODE (round 3): the softmax numerator costs the VALU one FMA (scale, minus the running offset) and one v_exp_f32 per score, and the
+// loop is VALU-issue bound.  With q PRE-SCALED by scale * log2(e) (ICD_ATTN_Q_PRESCALED: the executor folds the factor into the
+// query projection's weights, so q carries it with no extra rounding) the scores leave the MFMA as base-2 exponents, and the
+// running offset M can be subtracted by the MFMA as well:
+//   MODE 1 (head dim = 16 KS - 8, e.g. 40): the first padded head-dim slot of the K tile is a column of ones and the same slot of
+//           the Q fragment holds -M (fp16; any offset works as long as numerator and denominator use the same one - and they do,
+//           the subtraction happens inside the fp32 accumulation), so S^T = K q^T - M for free;
+//   MODE 2 (no free slot, e.g. 64 / 80): the S^T accumulators start from -M instead of zero (16 VGPRs per query tile).
+// Either way p = exp2(s): the 32 FMAs per lane and tile are gone (-30 % VALU instructions in the steady state).
+// MODE 0: scores scaled on the VALU as before (any q; also what a prescaled q takes where no MODE 1 / 2 instantiation exists).
+template <int KS, int DT, int QT, int OCC, int NST, int MODE = 0>
 __global__ __launch_bounds__(256, OCC) void attn_fused_kernel(AttnK p) {
     constexpr int NCH = 2 * KS;                       // 16-B chunks per K row
     constexpr bool ONES = KS * 16 < DT * 32;          // a free padded V^T row exists: MFMA computes the denominator
@@ -121,6 +134,7 @@ __global__ __launch_bounds__(256, OCC) void attn_fused_kernel(AttnK p) {
         const bool ok = dd < p.d;
         kp[j] = ok ? Kb + (long long)row * p.ldk + dd : zero;
         kinc[j] = ok ? 64 * p.ldk : 0;
+        if (MODE == 1 && dd == p.d) kp[j] = icd_e0_page;     // ones column in head-dim slot d
     }
 #pragma unroll
     for (int j = 0; j < DT; ++j) {
@@ -159,6 +173,7 @@ __global__ __launch_bounds__(256, OCC) void attn_fused_kernel(AttnK p) {
                 const int row = cid / NCH, pc = cid - row * NCH;
                 const int key = kv0 + row, dd = k_swz<NCH>(row, pc) * 8;
                 const half_t* src = (key < p.Nk && dd < p.d) ? Kb + (long long)key * p.ldk + dd : zero;
+                if (MODE == 1 && dd == p.d && key < p.Nk) src = icd_e0_page;
                 glds16(src, sk + g * 1024);
             }
         }
@@ -195,7 +210,13 @@ __global__ __launch_bounds__(256, OCC) void attn_fused_kernel(AttnK p) {
     // m_run: the row offset (raw score units) currently folded into O and l; l_run only when no ones-row exists
     float m_run[QT], l_run[QT];
 #pragma unroll
-    for (int u = 0; u < QT; ++u) { m_run[u] = -INFINITY; l_run[u] = 0.f; }
+    for (int u = 0; u < QT; ++u) { m_run[u] = MODE ? 0.f : -INFINITY; l_run[u] = 0.f; }
+    // MODE 2: the S^T accumulators start from -M (all 16 elements of a lane belong to its one query column)
+    f32x16 minit[MODE == 2 ? QT : 1];
+#pragma unroll
+    for (int u = 0; u < (MODE == 2 ? QT : 1); ++u)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) minit[u][e] = 0.f;
     const float c = p.scale_log2;
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // folds into the MFMA's inline-constant srcC
     f16x8 ones8;
@@ -228,7 +249,7 @@ __global__ __launch_bounds__(256, OCC) void attn_fused_kernel(AttnK p) {
                     for (int u = 0; u < QT; ++u)
                         if (k0 + kk < KS)
                             s[u][kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kt][kk], qf[u][k0 + kk],
-                                                                              k0 + kk == 0 ? zero16 : s[u][kt], 0, 0, 0);
+                                                                              k0 + kk == 0 ? (MODE == 2 ? minit[MODE == 2 ? u : 0] : zero16) : s[u][kt], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
         if (rag || p.causal) {                           // wave-uniform: ragged last tile (keys past Nk) / causal mask -> -inf
@@ -245,7 +266,7 @@ __global__ __launch_bounds__(256, OCC) void attn_fused_kernel(AttnK p) {
             }
         }
     };
-    auto softmax_pv = [&](f32x16 (&s)[QT][2], const int BO) {
+    auto softmax_pv = [&](f32x16 (&s)[QT][2], const int BO, const int t) {
         // ---- V^T fragments of the first VPRE key steps: in flight while the softmax runs ----
         constexpr int VPRE = QT * DT <= 2 ? 4 : QT * DT <= 4 ? 2 : 1;      // at most 8 fragments (32 VGPRs) ahead
         f16x8 vf[4][DT];
@@ -270,7 +291,36 @@ __global__ __launch_bounds__(256, OCC) void attn_fused_kernel(AttnK p) {
                 const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
                 mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
             }
-            if (__builtin_amdgcn_ballot_w64((mx - m_run[u]) * c > 8.0f)) {       // rare after the first tiles
+            if (MODE != 0) {
+                // s already is (base-2 exponent - M).  The first tile fixes M at its row maximum; afterwards M moves only when a
+                // maximum outgrows it by more than 2^8 (lazy rescale, as MODE 0).  At a move by delta: O and l shrink by 2^-delta, the
+                // scores of THIS tile (computed against the old M) drop by delta, and the -M carried by the MFMA is replaced.
+                if (__builtin_amdgcn_ballot_w64(mx > 8.0f) || t == 0) {
+                    float delta = t == 0 ? fmaxf(mx, -60000.f) : fmaxf(mx, 0.f);
+                    float m_new = m_run[u] + delta;
+                    if (MODE == 1) {                      // the offset travels as an fp16 operand: keep it fp16-exact
+                        m_new = (float)(half_t)m_new;
+                        delta = m_new - m_run[u];
+                        if (lh == (KS * 16 - 8) % 16 / 8) qf[u][KS - 1][0] = (half_t)(-m_new);
+                    } else if (MODE == 2) {
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) minit[MODE == 2 ? u : 0][e] = -m_new;
+                    }
+                    m_run[u] = m_new;
+                    if (t != 0) {                         // (O and l are still zero on the first tile)
+                        const float alpha = __builtin_amdgcn_exp2f(-delta);
+                        if (!ONES) l_run[u] *= alpha;
+#pragma unroll
+                        for (int i = 0; i < DT; ++i)
+#pragma unroll
+                            for (int e = 0; e < 16; ++e) o[u][i][e] *= alpha;
+                    }
+#pragma unroll
+                    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) s[u][kt][e] -= delta;
+                }
+            } else if (__builtin_amdgcn_ballot_w64((mx - m_run[u]) * c > 8.0f)) {       // rare after the first tiles
                 const float m_new = fmaxf(m_run[u], mx);
                 const float alpha = __builtin_amdgcn_exp2f((m_run[u] - m_new) * c);
                 m_run[u] = m_new;
@@ -286,7 +336,7 @@ __global__ __launch_bounds__(256, OCC) void attn_fused_kernel(AttnK p) {
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const float pv = __builtin_amdgcn_exp2f(fmaf(s[u][kt][e], c, nmc));
+                    const float pv = MODE != 0 ? __builtin_amdgcn_exp2f(s[u][kt][e]) : __builtin_amdgcn_exp2f(fmaf(s[u][kt][e], c, nmc));
                     if (!ONES && !LS_MFMA) rs += pv;
                     pf[u][kt * 2 + (e >> 3)][e & 7] = (half_t)pv;
                 }
@@ -345,7 +395,7 @@ __global__ __launch_bounds__(256, OCC) void attn_fused_kernel(AttnK p) {
             if (t + PD < nt) issue(t + PD, ((buf + PD) % NST) * STAGE);
             f32x16 s[QT][2];
             qk(s, buf * STAGE, rag, t);
-            softmax_pv(s, buf * STAGE);
+            softmax_pv(s, buf * STAGE, t);
         };
 #pragma unroll
         for (int i = 0; i < PD; ++i)
@@ -714,18 +764,18 @@ int launch_attn_cross(AttnK k, hipStream_t st) {
     return ICD_OK;
 }
 
-template <int KS, int DT, int QT, int OCC = 2, int NST = 2>
+template <int KS, int DT, int QT, int OCC = 2, int NST = 2, int MODE = 0>
 int launch_attn(AttnK k, hipStream_t st) {
     constexpr int smem = NST * (64 * 2 * KS * 16 + DT * 32 * 128);
     static_assert(smem * OCC <= 160 * 1024, "LDS ring x occupancy exceeds the CU's 160 KiB");
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fused_kernel<KS, DT, QT, OCC, NST>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fused_kernel<KS, DT, QT, OCC, NST, MODE>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         attr_set = true;
     }
     k.nqt = (k.Nq + 128 * QT - 1) / (128 * QT);
-    hipLaunchKernelGGL((attn_fused_kernel<KS, DT, QT, OCC, NST>), dim3(k.nqt * k.B * k.H), dim3(256), smem, st, k);
+    hipLaunchKernelGGL((attn_fused_kernel<KS, DT, QT, OCC, NST, MODE>), dim3(k.nqt * k.B * k.H), dim3(256), smem, st, k);
     ICD_CHECK_LAUNCH("icd_attention_fused");
     return ICD_OK;
 }
@@ -767,7 +817,7 @@ extern "C" int icd_attention_fused(const void* q, const void* k, const void* vt,
 extern "C" int icd_attention_fused_ex(const void* q, const void* k, const void* vt, void* out, int32_t B, int32_t H,
                                       int32_t Nq, int32_t Nk, int32_t d, int32_t ldq, int32_t ldk, int32_t ldvt, int32_t ldo,
                                       int64_t vt_batch_stride, float scale, int32_t flags, void* stream) {
-    ICD_CHECK_ARG((flags & ~ICD_ATTN_CAUSAL) == 0, "icd_attention_fused: unknown flags 0x%x", flags);
+    ICD_CHECK_ARG((flags & ~(ICD_ATTN_CAUSAL | ICD_ATTN_Q_PRESCALED | ICD_ATTN_TUNE_MODE0)) == 0, "icd_attention_fused: unknown flags 0x%x", flags);
     ICD_CHECK_ARG(!(flags & ICD_ATTN_CAUSAL) || Nq == Nk, "icd_attention_fused: the causal mask needs Nq == Nk");
     ICD_CHECK_ARG(scale > 0.f, "icd_attention_fused: scale must be positive");
     ICD_CHECK_ARG(q && k && vt && out, "icd_attention_fused: null pointer");
@@ -779,7 +829,9 @@ extern "C" int icd_attention_fused_ex(const void* q, const void* k, const void* 
     a.q = (const half_t*)q; a.k = (const half_t*)k; a.vt = (const half_t*)vt; a.out = (half_t*)out;
     a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.d = d; a.ldq = ldq; a.ldk = ldk; a.ldvt = ldvt; a.ldo = ldo;
     a.vt_bs = vt_batch_stride > 0 ? vt_batch_stride : (long long)H * d * ldvt;
-    a.scale_log2 = scale * 1.4426950408889634f;
+    const bool presc = (flags & ICD_ATTN_Q_PRESCALED) != 0;
+    a.scale_log2 = presc ? 1.0f : scale * 1.4426950408889634f;
+    const bool fast = presc && !(flags & ICD_ATTN_TUNE_MODE0);          // MODE 1 / 2 kernels (exponent offset subtracted by the MFMA)
     a.nqt = 0;
     a.causal = (flags & ICD_ATTN_CAUSAL) ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
@@ -795,6 +847,9 @@ extern "C" int icd_attention_fused_ex(const void* q, const void* k, const void* 
     }
     if (d <= 16) return launch_attn<1, 1, 1, 2, 2>(a, st);
     if (d <= 32) return launch_attn<2, 1, 1, 2, 2>(a, st);
+    if (fast && d == 40) return wide ? launch_attn<3, 2, 2, 2, 2, 1>(a, st) : launch_attn<3, 2, 1, 2, 2, 1>(a, st);
+    if (fast && d == 64) return launch_attn<4, 2, 1, 2, 2, 2>(a, st);
+    if (fast && d == 80) return launch_attn<5, 3, 1, 2, 2, 2>(a, st);
     if (d <= 48) return wide ? launch_attn<3, 2, 2, 2, 2>(a, st) : launch_attn<3, 2, 1, 2, 2>(a, st);
     if (d <= 64) return launch_attn<4, 2, 1, 2, 2>(a, st);      // QT = 2 spills at d = 64 (measured slower)
     if (d <= 80) return launch_attn<5, 3, 1, 2, 2>(a, st);

@@ -321,10 +321,13 @@ int32_t icd_unet_num_attention_layers(const icd_unet* u);
  *       (ICD_GEMM_LN_COMPUTE); 0: a separate icd_layernorm_stats pass over the residual stream.  Statistics agree to ~1e-6.
  *   ICD_UNET_OPT_XATTN_TILE     A/B tuning of the fused launch's host tile (icd_gemm_desc.tune_xattn_tile): 0 (default) planner,
  *       2 = 128 x 128, 4 = 256 x 128.
+ *   ICD_UNET_OPT_ATTN_VALU_SCALE  A/B: 1 = the flash attention kernels apply the softmax offset with one FMA per score on the VALU
+ *       (ICD_ATTN_TUNE_MODE0), 0 (default) = the MFMA subtracts it (head dims 40 / 64 / 80).  Same arithmetic up to fp32 rounding.
  * Returns ICD_ERR_INVALID_ARG for an unknown option or value. */
 #define ICD_UNET_OPT_XATTN_FUSION    1
 #define ICD_UNET_OPT_LN_INLINE_STATS 2
 #define ICD_UNET_OPT_XATTN_TILE      3
+#define ICD_UNET_OPT_ATTN_VALU_SCALE 4
 int icd_unet_set_option(icd_unet* u, int32_t option, int32_t value);
 int64_t icd_unet_workspace_bytes(const icd_unet* u, int32_t batch, int32_t H, int32_t W, int32_t n_ctx);
 /* Same for a known materialisation rule of the attention hook: probs_mode 0 = no layer is ever materialised (no hook), 1 =

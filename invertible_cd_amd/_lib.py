@@ -18,6 +18,10 @@ ICD_GEMM_LN_COMPUTE = 32
 ICD_UNET_OPT_XATTN_FUSION = 1
 ICD_UNET_OPT_LN_INLINE_STATS = 2
 ICD_UNET_OPT_XATTN_TILE = 3
+ICD_UNET_OPT_ATTN_VALU_SCALE = 4
+ICD_ATTN_CAUSAL = 1
+ICD_ATTN_Q_PRESCALED = 2
+ICD_ATTN_TUNE_MODE0 = 4
 ICD_HOOK_QUERY = 0
 ICD_HOOK_PROBS = 1
 

@@ -119,6 +119,7 @@ struct icd_unet {
     int xattn_mode = 2;
     bool ln_inline = true;          // the GEMM behind a LayerNorm computes its statistics (ICD_GEMM_LN_COMPUTE)
     int xattn_tile = 0;             // A/B: host tile of the fused launch (icd_gemm_desc.tune_xattn_tile)
+    bool attn_mode0 = false;        // A/B: flash attention with the scale / offset FMA on the VALU (ICD_ATTN_TUNE_MODE0)
 };
 
 namespace {
@@ -280,14 +281,19 @@ struct Exec {
                    int ldv, long long vt_bs, int heads, int Nq, int Nk, int d, half_t* out, int C) {
         const int my_layer = plan.layer;
         const long long ldp = (Nk + 7) / 8 * 8;
-        const float scale = 1.0f / sqrtf((float)d);
+        // The packer (unet.pack_state_dict) folds d^-1/2 * log2(e) into every query projection: q.k already is the base-2
+        // exponent of the softmax.  The flash kernels take it as such (ICD_ATTN_Q_PRESCALED: no scale FMA per score, the running
+        // offset subtracted by the MFMA); the kernels with a `scale` argument get ln 2, i.e. scale * log2(e) == 1.
+        const float scale = 0.69314718055994531f;
+        (void)d;
         const bool mat = plan.mat;
         void* probs = plan.probs;
         if (!ok()) return;
         if (!mat) {
             if (ok() && !dry) {
                 ProfScope ps(true, st, ICD_PROF_ATTN_FUSED, 4.0 * B * heads * (double)Nq * Nk * d, 0.0, Nq, Nk, d, heads);
-                run(icd_attention_fused(q, k, vt, out, B, heads, Nq, Nk, d, ldq, ldk, ldv, C, vt_bs, scale, st));
+                run(icd_attention_fused_ex(q, k, vt, out, B, heads, Nq, Nk, d, ldq, ldk, ldv, C, vt_bs, scale,
+                                           ICD_ATTN_Q_PRESCALED | (u->attn_mode0 ? ICD_ATTN_TUNE_MODE0 : 0), st));
             }
             return;
         }
@@ -363,7 +369,7 @@ struct Exec {
                     g.rows_per_sample = HW; g.mode = 0; g.batch = 1; g.zdiv = 1; g.alpha = 1.f;
                     g.ln_stats = lnst; g.ln_colsum = sq; g.flags = lnc;
                     g.xattn_k = kx; g.xattn_vt = vx; g.xattn_nk = nctx; g.xattn_ldk = u->kv_total; g.xattn_ldvt = ldv_cross;
-                    g.xattn_vt_bs = vx_bs; g.xattn_scale = 1.0f / sqrtf((float)d); g.tune_xattn_tile = u->xattn_tile;
+                    g.xattn_vt_bs = vx_bs; g.xattn_scale = 0.69314718055994531f; g.tune_xattn_tile = u->xattn_tile;   // q is prescaled (see attention())
                     ProfScope ps(true, st, ICD_PROF_XATTN, 2.0 * M * (double)C * C + 4.0 * M * (double)nctx * C, 0.0, (int)M, C, C, heads);
                     ps.plan(g);
                     run(icd_gemm(&g, st));
@@ -578,6 +584,9 @@ extern "C" int icd_unet_set_option(icd_unet* u, int32_t option, int32_t value) {
     case ICD_UNET_OPT_XATTN_TILE:
         ICD_CHECK_ARG(value == 0 || value == 2 || value == 4, "icd_unet_set_option: ICD_UNET_OPT_XATTN_TILE takes 0, 2 or 4 (got %d)", value);
         u->xattn_tile = value; return ICD_OK;
+    case ICD_UNET_OPT_ATTN_VALU_SCALE:
+        ICD_CHECK_ARG(value == 0 || value == 1, "icd_unet_set_option: ICD_UNET_OPT_ATTN_VALU_SCALE takes 0 or 1 (got %d)", value);
+        u->attn_mode0 = value != 0; return ICD_OK;
     case ICD_UNET_OPT_LN_INLINE_STATS:
         ICD_CHECK_ARG(value == 0 || value == 1, "icd_unet_set_option: ICD_UNET_OPT_LN_INLINE_STATS takes 0 or 1 (got %d)", value);
         u->ln_inline = value != 0; return ICD_OK;

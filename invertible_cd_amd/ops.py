@@ -270,12 +270,16 @@ def query_cross_attention(a, w, k, vt, B, n_tokens, nk, scale, bias=None, ln_sta
     return out
 
 
-def attention_fused(q, k, vt, B, H, Nq, Nk, d, scale, causal=False):
-    """q [B*Nq, H*d], k [B*Nk, H*d], vt [B, H*d, ld] -> out [B*Nq, H*d]; causal: keys after the query are masked."""
+def attention_fused(q, k, vt, B, H, Nq, Nk, d, scale, causal=False, prescaled=False, valu_scale=False):
+    """q [B*Nq, H*d], k [B*Nk, H*d], vt [B, H*d, ld] -> out [B*Nq, H*d]; causal: keys after the query are masked.
+    prescaled: q already carries scale * log2(e) (ICD_ATTN_Q_PRESCALED; `scale` is ignored); valu_scale: A/B switch
+    ICD_ATTN_TUNE_MODE0."""
     _chk_rows(q, "q"); _chk_rows(k, "k"); _chk16(vt, "vt")
     out = torch.empty((q.shape[0], q.shape[1]), device=q.device, dtype=torch.float16)
+    flags = (_lib.ICD_ATTN_CAUSAL if causal else 0) | (_lib.ICD_ATTN_Q_PRESCALED if prescaled else 0) | \
+            (_lib.ICD_ATTN_TUNE_MODE0 if valu_scale else 0)
     _lib.check(_lib.load().icd_attention_fused_ex(_p(q), _p(k), _p(vt), _p(out), B, H, Nq, Nk, d, q.stride(0), k.stride(0),
-                                                  vt.stride(1), out.stride(0), vt.stride(0), scale, 1 if causal else 0, _stream()),
+                                                  vt.stride(1), out.stride(0), vt.stride(0), scale, flags, _stream()),
                "icd_attention_fused")
     return out
 

@@ -40,7 +40,7 @@ def pack_state_dict(cfg: UNetConfig, sd, device):
     """diffusers-layout state dict -> the packed tensors the native executor binds (fp16 weights, fp32 bias/norm).
 
       conv [O,I,k,k]      -> [O, k*k*I]  (tap-major K of the implicit GEMM; 1x1 convs become plain [O,I])
-      attn1.to_q/to_k     -> attn1.to_qk [2C, C]   (one GEMM, q|k column blocks)
+      attn1.to_q/to_k     -> attn1.to_qk [2C, C]   (one GEMM, q|k column blocks; q rows carry d^-1/2 * log2(e), as attn2.to_q does)
       norm1/2/3 (LayerNorm) -> folded into to_qk / to_v / attn2.to_q / ff.net.0.proj: gamma into the weight columns,
                              W beta into the bias, plus the row sums the epilogue's mean correction needs
       ff.net.0.proj       -> rows interleaved 32 value / 32 gate so GEGLU is applied in the GEMM epilogue
@@ -103,7 +103,11 @@ def pack_state_dict(cfg: UNetConfig, sd, device):
     packed["time_emb_proj_cat.weight"] = w16(torch.cat([t.to(device) for t in tw], 0))
     packed["time_emb_proj_cat.bias"] = f32(torch.cat([t.to(device) for t in tb], 0))
     kcat, vcat = [], []
-    for p, c, depth, _, _ in cfg.transformer_names():
+    for p, c, depth, heads, _ in cfg.transformer_names():
+        # softmax(d^-1/2 q.k) = exp2(q'.k - max) / sum with q' = (d^-1/2 log2 e) q: the factor is folded into the query projections
+        # (weights, LayerNorm column sums and biases alike, before the single fp16 rounding of the weights), so the attention
+        # kernels use q.k as a base-2 exponent directly - no scale multiply per score on the VALU (attention.hip MODE 1 / 2)
+        qscale = (c // heads) ** -0.5 * 1.4426950408889634
         affine(p + ".norm")
         dense(p + ".proj_in")
         dense(p + ".proj_out")
@@ -125,13 +129,14 @@ def pack_state_dict(cfg: UNetConfig, sd, device):
                 packed[name + "." + bias_key] = f32(w @ be + (0 if bias is None else bias.to(device).float()))
                 return w @ be
 
-            fold(f"{b}.attn1.to_qk", torch.cat([take(f"{b}.attn1.to_q.weight").to(device), take(f"{b}.attn1.to_k.weight").to(device)], 0), "norm1")
+            fold(f"{b}.attn1.to_qk", torch.cat([take(f"{b}.attn1.to_q.weight").to(device).float() * qscale,
+                                                take(f"{b}.attn1.to_k.weight").to(device).float()], 0), "norm1")
             tv = fold(f"{b}.attn1.to_v", take(f"{b}.attn1.to_v.weight"), "norm1")           # W_v beta: a constant over the keys,
             del packed[f"{b}.attn1.to_v.lnbias"]                                                # (not applied by the to_v GEMM itself)
             wo = take(f"{b}.attn1.to_out.0.weight").to(device).float()                          # softmax rows sum to one ->
             packed[f"{b}.attn1.to_out.0.weight"] = w16(wo)                                      # it moves into to_out's bias
             packed[f"{b}.attn1.to_out.0.bias"] = f32(take(f"{b}.attn1.to_out.0.bias").to(device).float() + wo @ tv)
-            fold(f"{b}.attn2.to_q", take(f"{b}.attn2.to_q.weight"), "norm2")
+            fold(f"{b}.attn2.to_q", take(f"{b}.attn2.to_q.weight").to(device).float() * qscale, "norm2")
             kcat.append(take(f"{b}.attn2.to_k.weight"))        # every cross-attention K / V projection of the UNet
             vcat.append(take(f"{b}.attn2.to_v.weight"))        # is batched into one GEMM per forward (context-only)
             dense(f"{b}.attn2.to_out.0")
@@ -202,7 +207,7 @@ class UNet2DConditionModel:
         self._live = []
 
     OPTIONS = {"xattn_fusion": _lib.ICD_UNET_OPT_XATTN_FUSION, "ln_inline_stats": _lib.ICD_UNET_OPT_LN_INLINE_STATS,
-               "xattn_tile": _lib.ICD_UNET_OPT_XATTN_TILE}
+               "xattn_tile": _lib.ICD_UNET_OPT_XATTN_TILE, "attn_valu_scale": _lib.ICD_UNET_OPT_ATTN_VALU_SCALE}
 
     def set_option(self, name, value):
         """Per-handle execution option (icd_unet_set_option): 'xattn_fusion' 0 / 1 / 2, 'ln_inline_stats' 0 / 1, 'xattn_tile' 0 / 2 / 4.  A/B tuning and

@@ -371,6 +371,81 @@ def test_attention_fused_spiked_rescale():
     assert rel_l2(out, ref) < 2e-3
 
 
+def _attn_ref_exp2(qp, k, v, B, H, Nq, Nk, d, causal=False):
+    """softmax with a PRE-SCALED query: p = 2^(q'.k) / sum (what ICD_ATTN_Q_PRESCALED promises), fp64 accumulation."""
+    qh = qp.double().reshape(B, Nq, H, d).permute(0, 2, 1, 3)
+    kh = k.double().reshape(B, Nk, H, d).permute(0, 2, 1, 3)
+    vh = v.double().reshape(B, Nk, H, d).permute(0, 2, 1, 3)
+    e = qh @ kh.transpose(-1, -2) * 0.6931471805599453
+    if causal:
+        e = e.masked_fill(torch.ones(Nq, Nk, dtype=torch.bool).triu(1), float("-inf"))
+    return (torch.softmax(e, -1) @ vh).permute(0, 2, 1, 3).reshape(B * Nq, H * d)
+
+
+@pytest.mark.parametrize("B,H,Nq,Nk,d", [(1, 8, 1024, 1024, 40),      # MODE 1, two query tiles per wave (wide)
+                                          (2, 8, 256, 256, 40),       # MODE 1, one query tile per wave
+                                          (2, 8, 200, 333, 40),       # ... ragged last key tile, ragged query tile
+                                          (2, 10, 256, 320, 64),      # MODE 2 (accumulators start from -M)
+                                          (1, 5, 100, 77, 64), (1, 8, 256, 256, 80),
+                                          (1, 8, 64, 64, 160)])       # no fast instantiation: VALU form with scale_log2 = 1
+@pytest.mark.parametrize("valu", [False, True])
+def test_attention_fused_with_a_prescaled_query(B, H, Nq, Nk, d, valu):
+    """ICD_ATTN_Q_PRESCALED: q carries d^-1/2 * log2(e) (the executor folds it into the query projection), the kernels use q.k as
+    the base-2 exponent and let the MFMA subtract the running offset (head dim 40: a ones column in the first padded head-dim
+    slot of K against -M in the same slot of q; 64 / 80: accumulators initialised to -M).  Checked against an fp64 softmax of the
+    SAME prescaled fp16 q; `valu` = ICD_ATTN_TUNE_MODE0, the scale / offset FMA on the VALU (must agree with the fast form)."""
+    ops = _ops()
+    Cc = H * d
+    q, k, v = r16(B * Nq, Cc, seed=128), r16(B * Nk, Cc, seed=129), r16(B * Nk, Cc, seed=130)
+    qp = (q.float() * (d ** -0.5 * 1.4426950408889634)).half()
+    ld = (Nk + 7) // 8 * 8
+    vt = ops.project_vt(v.cuda(), torch.eye(Cc).half().cuda(), B, Nk, ld)
+    out = ops.attention_fused(qp.cuda(), k.cuda(), vt, B, H, Nq, Nk, d, 123.0, prescaled=True, valu_scale=valu)     # scale is ignored
+    ref = _attn_ref_exp2(qp, k, v, B, H, Nq, Nk, d)
+    e = rel_l2(out, ref)
+    assert torch.isfinite(out).all() and e < 1.5e-3, e
+    base, _ = _attn_ref(q, k, v, B, H, Nq, Nk, d)                  # and the un-prescaled definition, up to the rounding of q'
+    assert rel_l2(out, base) < 2e-3
+
+
+@pytest.mark.parametrize("d,Nq", [(40, 256), (40, 1024), (64, 128), (80, 128)])
+def test_attention_fused_prescaled_rescale_branch_and_extreme_offsets(d, Nq):
+    """The lazy rescale of MODE 1 / 2 under stress: (a) a key that dominates a LATE tile (M moves after O has accumulated: O, l,
+    this tile's scores and the offset the MFMA carries must all move exactly once), (b) rows whose exponents sit far from zero in
+    both directions (exponents of about +-100: the fp16 offset operand of MODE 1 must stay exact), (c) M moving
+    several times in a row (keys of growing magnitude).  fp64 reference on the same prescaled q."""
+    ops = _ops()
+    B, H, Nk = 1, 8 if d == 40 else 2, 512
+    Cc = H * d
+    q, k, v = r16(B * Nq, Cc, seed=131), r16(B * Nk, Cc, seed=132), r16(B * Nk, Cc, seed=133)
+    qp = (q.float() * (d ** -0.5 * 1.4426950408889634)).half()
+    k = k.clone()
+    k[300] = q[5] * 4.0                                  # (a) spikes in tile 4 against query 5 (head-wise: every head of row 5)
+    k[17] = q[77] * 3.0
+    for j, f in enumerate((1.5, 2.5, 3.5, 4.5, 6.0)):    # (c) the maximum of query 9 grows tile after tile
+        k[70 + 64 * j] = q[9] * f
+    qp[11] = qp[11] * 24.0                               # (b) large |exponents|: the scores of row 11 spread over about +-100
+    vt = ops.project_vt(v.cuda(), torch.eye(Cc).half().cuda(), B, Nk, Nk)
+    ref = _attn_ref_exp2(qp, k, v, B, H, Nq, Nk, d)
+    for valu in (False, True):
+        out = ops.attention_fused(qp.cuda(), k.cuda(), vt, B, H, Nq, Nk, d, 1.0, prescaled=True, valu_scale=valu)
+        assert torch.isfinite(out).all()
+        err_rows = (out.float().cpu() - ref.float()).norm(dim=1) / ref.float().norm(dim=1).clamp_min(1e-6)
+        assert rel_l2(out, ref) < 2e-3 and float(err_rows.max()) < 2e-2, (valu, rel_l2(out, ref), float(err_rows.max()), int(err_rows.argmax()))
+
+
+def test_attention_fused_prescaled_causal():
+    """Causal mask with the MFMA-carried offset (head dim 64, the CLIP text-encoder shape): masked scores are -inf before the
+    maximum and stay -inf under the offset subtraction."""
+    ops = _ops()
+    B, H, N, d = 2, 4, 77, 64
+    q, k, v = r16(B * N, H * d, seed=134), r16(B * N, H * d, seed=135), r16(B * N, H * d, seed=136)
+    qp = (q.float() * (d ** -0.5 * 1.4426950408889634)).half()
+    vt = ops.project_vt(v.cuda(), torch.eye(H * d).half().cuda(), B, N, 80)
+    out = ops.attention_fused(qp.cuda(), k.cuda(), vt, B, H, N, N, d, 1.0, causal=True, prescaled=True)
+    assert rel_l2(out, _attn_ref_exp2(qp, k, v, B, H, N, N, d, causal=True)) < 1.5e-3
+
+
 @pytest.mark.parametrize("B,H,Nq,Nk,d", [(2, 8, 256, 77, 40), (1, 8, 256, 256, 40), (2, 4, 64, 64, 160), (1, 5, 128, 77, 64)])
 def test_attention_materialised(B, H, Nq, Nk, d):
     ops = _ops()

@@ -121,6 +121,10 @@ typedef struct {
     int32_t tune_xattn_tile;  /* host tile of the fused query-projection + cross-attention launch: 0 planner, 2 = 128 x 128, 4 = 256 x 128 */
     void* debug_timeline;     /* device buffer of 8 x uint64 per block: every block of this launch stamps s_memrealtime (100 MHz) at */
                               /* start, first k-tile landed, main loop done, epilogue done (+ s_memtime ticks of the main loop)     */
+    /* Second output for the fp32 residual stream (icd_unet option ICD_UNET_OPT_RESIDUAL_F32): the SAME values as `out` before the
+     * fp16 rounding, fp32 [M, ldo] (row stride ldo).  With an fp32 `resid` (ICD_GEMM_RESID_F32) a chain h <- h + f(h) accumulates
+     * in fp32 while every consumer still reads the fp16 copy.  NULL: off.  fp16 `out` only, no GEGLU / transposed / batched. */
+    float* out_f32;
 } icd_gemm_desc;
 
 int icd_gemm(const icd_gemm_desc* d, void* stream);
@@ -323,7 +327,13 @@ int32_t icd_unet_num_attention_layers(const icd_unet* u);
  *       2 = 128 x 128, 4 = 256 x 128.
  *   ICD_UNET_OPT_ATTN_VALU_SCALE  A/B: 1 = the flash attention kernels apply the softmax offset with one FMA per score on the VALU
  *       (ICD_ATTN_TUNE_MODE0), 0 (default) = the MFMA subtracts it (head dims 40 / 64 / 80).  Same arithmetic up to fp32 rounding.
+ *   ICD_UNET_OPT_RESIDUAL_F32   1 = fp32 residual stream: every chain x <- x + f(x) of the UNet (ResnetBlock2D conv2 + input /
+ *       shortcut, the three branch adds of a BasicTransformerBlock, Transformer2DModel proj_out + input) accumulates in fp32 and the
+ *       fp16 copy the next operator reads is rounded from that sum (icd_gemm_desc.out_f32 + ICD_GEMM_RESID_F32).  Removes the dominant
+ *       error term of fp16 storage: eps vs an fp32 evaluation 1.1e-3 -> 0.8e-3 rel-L2.  0 (default): fp16 residual stream.  What
+ *       load_models(dtype='fp32') (the reference's default, utils/loading.py:34,38) selects.  Set before sizing the workspace.
  * Returns ICD_ERR_INVALID_ARG for an unknown option or value. */
+#define ICD_UNET_OPT_RESIDUAL_F32    5
 #define ICD_UNET_OPT_XATTN_FUSION    1
 #define ICD_UNET_OPT_LN_INLINE_STATS 2
 #define ICD_UNET_OPT_XATTN_TILE      3
@@ -352,9 +362,19 @@ typedef struct {
     int32_t sample_is_f32;
     icd_attn_hook hook;        /* NULL: every attention layer fused */
     void* hook_user;
+    /* Cross-attention K / V^T of every layer depend on the context only - the same tensor at every step of a sampling loop
+     * (utils/generation.py:241-244 passes self.context, utils/generation_sdxl.py:445-453 prompt_embeds).  With a caller-owned
+     * kv_cache of icd_unet_kv_cache_bytes() the two context projections of a forward are written there, and a later forward with
+     * kv_cache_valid != 0 (the caller vouches that `context`, batch and n_ctx are those of the forward that filled it) skips
+     * them and reads the cache.  NULL: projections live in the workspace and are recomputed every forward.  Results are
+     * bit-identical either way. */
+    void* kv_cache;
+    int64_t kv_cache_bytes;
+    int32_t kv_cache_valid;
 } icd_unet_io;
 
 int icd_unet_forward(icd_unet* u, const icd_unet_io* io, void* stream);
+int64_t icd_unet_kv_cache_bytes(const icd_unet* u, int32_t batch, int32_t n_ctx);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Per-kernel-family timing of the executor's launches with HIP events recorded on the launch stream (bench.py's

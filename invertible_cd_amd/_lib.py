@@ -19,6 +19,7 @@ ICD_UNET_OPT_XATTN_FUSION = 1
 ICD_UNET_OPT_LN_INLINE_STATS = 2
 ICD_UNET_OPT_XATTN_TILE = 3
 ICD_UNET_OPT_ATTN_VALU_SCALE = 4
+ICD_UNET_OPT_RESIDUAL_F32 = 5
 ICD_ATTN_CAUSAL = 1
 ICD_ATTN_Q_PRESCALED = 2
 ICD_ATTN_TUNE_MODE0 = 4
@@ -42,7 +43,7 @@ class GemmDesc(C.Structure):
         ("xattn_k", C.c_void_p), ("xattn_vt", C.c_void_p), ("xattn_nk", C.c_int32), ("xattn_ldk", C.c_int32),
         ("xattn_ldvt", C.c_int32), ("xattn_vt_bs", C.c_int64), ("xattn_scale", C.c_float),
         ("ln_eps", C.c_float),
-        ("tune_group_m", C.c_int32), ("tune_xattn_tile", C.c_int32), ("debug_timeline", C.c_void_p),
+        ("tune_group_m", C.c_int32), ("tune_xattn_tile", C.c_int32), ("debug_timeline", C.c_void_p), ("out_f32", C.c_void_p),
     ]
 
 
@@ -83,6 +84,7 @@ class UNetIO(C.Structure):
         ("text_embeds", C.c_void_p), ("time_ids", C.c_void_p), ("eps", C.c_void_p), ("workspace", C.c_void_p),
         ("workspace_bytes", C.c_int64), ("batch", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("n_ctx", C.c_int32),
         ("sample_is_f32", C.c_int32), ("hook", ATTN_HOOK), ("hook_user", C.c_void_p),
+        ("kv_cache", C.c_void_p), ("kv_cache_bytes", C.c_int64), ("kv_cache_valid", C.c_int32),
     ]
 
 
@@ -125,6 +127,7 @@ SIGNATURES = {
     "icd_unet_workspace_bytes": (C.c_int64, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "icd_unet_workspace_bytes_ex": (C.c_int64, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "icd_unet_forward": (C.c_int, [C.c_void_p, C.POINTER(UNetIO), C.c_void_p]),
+    "icd_unet_kv_cache_bytes": (C.c_int64, [C.c_void_p, C.c_int32, C.c_int32]),
     "icd_attention_fused_ex": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int32] * 9
                                + [C.c_int64, C.c_float, C.c_int32, C.c_void_p]),
     "icd_activation": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),

@@ -847,6 +847,8 @@ extern "C" int icd_attention_fused_ex(const void* q, const void* k, const void* 
     }
     if (d <= 16) return launch_attn<1, 1, 1, 2, 2>(a, st);
     if (d <= 32) return launch_attn<2, 1, 1, 2, 2>(a, st);
+    // (round 3, same-box round-robin A/B at 4096 x 4096: one query tile per wave, three blocks per CU and a 3-stage ring are all
+    //  1 - 12 % slower than the configurations below with MODE 1 / 2; profiles/r03_attn_variants.txt)
     if (fast && d == 40) return wide ? launch_attn<3, 2, 2, 2, 2, 1>(a, st) : launch_attn<3, 2, 1, 2, 2, 1>(a, st);
     if (fast && d == 64) return launch_attn<4, 2, 1, 2, 2, 2>(a, st);
     if (fast && d == 80) return launch_attn<5, 3, 1, 2, 2, 2>(a, st);

@@ -568,6 +568,11 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_kernel(GemmK p) {
                     for (int e = 0; e < 8; ++e) v[e] += (float)rs[e];
                     }
                 }
+                if (p.out32) {
+                    float* o32 = p.out32 + (long long)m * p.ldo + n;
+                    *reinterpret_cast<f32x4*>(o32) = (f32x4){v[0], v[1], v[2], v[3]};
+                    *reinterpret_cast<f32x4*>(o32 + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+                }
                 if (out_f32) {
                     float* out = reinterpret_cast<float*>(p.out) + o_off + (long long)m * p.ldo + n;
                     *reinterpret_cast<f32x4*>(out) = (f32x4){v[0], v[1], v[2], v[3]};
@@ -624,6 +629,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmK p) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] += (float)rs[e];
         }
+    }
+    if (p.out32) {
+        float* o32 = p.out32 + (long long)m * p.ldo + n;
+        *reinterpret_cast<f32x4*>(o32) = (f32x4){v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<f32x4*>(o32 + 4) = (f32x4){v[4], v[5], v[6], v[7]};
     }
     if (p.flags & ICD_GEMM_OUT_F32) {
         float* out = reinterpret_cast<float*>(p.out) + (long long)m * p.ldo + n;
@@ -729,6 +739,9 @@ static int gemm_run(const icd_gemm_desc* d, void* stream, icd_gemm_plan_info* in
     k.a_bs0 = d->a_bs0; k.a_bs1 = d->a_bs1; k.w_bs0 = d->w_bs0; k.w_bs1 = d->w_bs1; k.o_bs0 = d->o_bs0; k.o_bs1 = d->o_bs1;
     k.alpha = d->alpha; k.flags = d->flags;
     k.timeline = (unsigned long long*)d->debug_timeline;
+    k.out32 = d->out_f32;
+    ICD_CHECK_ARG(!(d->out_f32 && (trans || geglu || (d->flags & ICD_GEMM_OUT_F32) || d->batch > 1 || d->xattn_k)),
+                  "icd_gemm: out_f32 (second fp32 output) goes with a plain fp16 output only");
     const int g_group_m = d->tune_group_m, g_xattn_tile = d->tune_xattn_tile;
     k.gm = g_group_m > 0 ? g_group_m : 1;        // the planner widens it below for launches with many n-tiles
     k.ln_stats = d->ln_stats; k.ln_s = d->ln_colsum;

@@ -26,6 +26,7 @@ struct GemmK {
     // cross-attention fused behind the query projection (icd_gemm_desc.xattn_*; gemm.hip xattn_epilogue)
     const half_t* xk; const half_t* xvt;
     int x_nk, x_ldk, x_ldvt; long long x_vt_bs; float x_scale_log2;
+    float* out32;                                // second output (icd_gemm_desc.out_f32): the values before the fp16 rounding, or null
     unsigned long long* timeline;                // diagnostics (icd_debug_gemm_timeline): 4 s_memrealtime stamps per block, or null
 };
 

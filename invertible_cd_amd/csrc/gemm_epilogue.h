@@ -20,7 +20,10 @@ static __device__ __attribute__((aligned(16))) const float icd_epi_ln_id[2] = {0
 // operands reading the neutral page): in the specialised variants an absent operand costs neither a load nor a register
 // (reading a neutral page instead was measured at +7..20 % on plain GEMMs - a 16-B residual read per lane is as much L1 traffic
 // as the output store).  Out-of-range lanes read the neutral page instead of branching around their loads.
-template <int JN, bool R, bool T, bool L, bool PF_ROWBIAS, int PF_PASSES>
+// R32: the residual is fp32 (ICD_GEMM_RESID_F32; two 16-B loads per pass instead of one); O32: the values are also stored before
+// the fp16 rounding (p.out32) - the two variants the executor's fp32 residual stream needs (plain + O32, R32 + O32).  Both are
+// compile-time so that the default variants carry neither the registers nor the branch.
+template <int JN, bool R, bool T, bool L, bool PF_ROWBIAS, int PF_PASSES, bool R32 = false, bool O32 = false>
 __device__ __forceinline__ void fast_patch(const GemmK& p, const f32x16& acc0, const f32x16& acc1, float* wst, int l, int mrow0,
                                            int ncol0, const float* ln_lds, int ln_m0) {
     constexpr int LDW = 68;
@@ -30,7 +33,9 @@ __device__ __forceinline__ void fast_patch(const GemmK& p, const f32x16& acc0, c
     const bool ncol_ok = n < p.N;
     const half_t* zp = reinterpret_cast<const half_t*>(icd_epi_zero);
     f32x4 b0, b1, s0, s1;
-    f16x8 rs[NPASS], rb[NPASS];
+    f16x8 rs[R32 ? 1 : NPASS], rb[NPASS];
+    f32x4 rsa[R32 ? NPASS : 1], rsb[R32 ? NPASS : 1];
+    const float* zf = icd_epi_zero;
     f32x2 st[NPASS];
     {
         const float* bp = (p.bias && ncol_ok) ? p.bias + n : icd_epi_zero;       // 2 x 16 B per patch: not worth a variant
@@ -45,7 +50,11 @@ __device__ __forceinline__ void fast_patch(const GemmK& p, const f32x16& acc0, c
         if (pass >= PF_PASSES) break;
         const int m = mrow0 + ((pass * 64 + l) >> CHS);
         const bool okp = m < p.M && ncol_ok;
-        if (R) rs[pass] = *reinterpret_cast<const f16x8*>((p.resid && okp) ? p.resid + (long long)m * p.ldr + n : zp);
+        if (R && !R32) rs[pass] = *reinterpret_cast<const f16x8*>((p.resid && okp) ? p.resid + (long long)m * p.ldr + n : zp);
+        if (R && R32) {
+            const float* rp = (p.resid && okp) ? reinterpret_cast<const float*>(p.resid) + (long long)m * p.ldr + n : zf;
+            rsa[pass] = *reinterpret_cast<const f32x4*>(rp); rsb[pass] = *reinterpret_cast<const f32x4*>(rp + 4);
+        }
         if (T && PF_ROWBIAS) rb[pass] = *reinterpret_cast<const f16x8*>((p.rowbias && okp) ? p.rowbias + (long long)(m / p.rps) * p.ld_rowbias + n : zp);
         if (L) {                                 // row statistics: from the kernel's own LDS table when it computed them (ln_lds)
             if (ln_lds) st[pass] = *reinterpret_cast<const f32x2*>(ln_lds + 2 * (m - ln_m0));
@@ -68,40 +77,51 @@ __device__ __forceinline__ void fast_patch(const GemmK& p, const f32x16& acc0, c
         const bool okl = m < p.M && ncol_ok;
         if (T && !PF_ROWBIAS) rb[pass] = *reinterpret_cast<const f16x8*>((p.rowbias && okl) ? p.rowbias + (long long)(m / p.rps) * p.ld_rowbias + n : zp);
         if (pass >= PF_PASSES) {
-            if (R) rs[pass] = *reinterpret_cast<const f16x8*>((p.resid && okl) ? p.resid + (long long)m * p.ldr + n : zp);
+            if (R && !R32) rs[pass] = *reinterpret_cast<const f16x8*>((p.resid && okl) ? p.resid + (long long)m * p.ldr + n : zp);
+            if (R && R32) {
+                const float* rp = (p.resid && okl) ? reinterpret_cast<const float*>(p.resid) + (long long)m * p.ldr + n : zf;
+                rsa[pass] = *reinterpret_cast<const f32x4*>(rp); rsb[pass] = *reinterpret_cast<const f32x4*>(rp + 4);
+            }
             if (L) {
                 if (ln_lds) st[pass] = *reinterpret_cast<const f32x2*>(ln_lds + 2 * (m - ln_m0));
                 else st[pass] = *reinterpret_cast<const f32x2*>((p.ln_stats && okl) ? p.ln_stats + 2 * (long long)m : icd_epi_ln_id);
             }
         }
         f16x8 o;
+        f32x4 w0, w1;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             float a0 = v0[e] * p.alpha, a1 = v1[e] * p.alpha;
             if (L) { a0 = st[pass][1] * (a0 - st[pass][0] * s0[e]); a1 = st[pass][1] * (a1 - st[pass][0] * s1[e]); }
             a0 += b0[e]; a1 += b1[e];
             if (T) { a0 += (float)rb[pass][e]; a1 += (float)rb[pass][4 + e]; }
-            if (R) { a0 += (float)rs[pass][e]; a1 += (float)rs[pass][4 + e]; }
+            if (R && !R32) { a0 += (float)rs[pass][e]; a1 += (float)rs[pass][4 + e]; }
+            if (R && R32) { a0 += rsa[pass][e]; a1 += rsb[pass][e]; }
             o[e] = (half_t)a0; o[4 + e] = (half_t)a1;
+            if (O32) { w0[e] = a0; w1[e] = a1; }
         }
         if (okl) *reinterpret_cast<f16x8*>(outp + (long long)m * p.ldo + n) = o;
+        if (O32 && okl) {
+            float* o32 = p.out32 + (long long)m * p.ldo + n;
+            *reinterpret_cast<f32x4*>(o32) = w0; *reinterpret_cast<f32x4*>(o32 + 4) = w1;
+        }
     }
 }
 
 // All patches of one wave through fast_patch (one operand mix per instantiation).
-template <int TM, int TN, bool R, bool T, bool L>
+template <int TM, int TN, bool R, bool T, bool L, bool R32 = false, bool O32 = false>
 __device__ __forceinline__ void wave_epilogue_fast(const GemmK& p, f32x16 (&acc)[TM][TN], float* wst, int wm, int wn, int l, int m0,
                                                    int n0, const float* ln_lds) {
     constexpr bool PF_ROWBIAS = TM * TN <= 8;                    // the 160-accumulator tiles have no registers left for it,
-    constexpr int PF_PASSES = TM * TN <= 8 ? 4 : 2;              // and request only the first two passes early
+    constexpr int PF_PASSES = R32 ? (TM * TN <= 8 ? 2 : 1) : TM * TN <= 8 ? 4 : 2;   // and request only the first two passes early
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int mrow0 = m0 + (wm * TM + i) * 32;
 #pragma unroll
         for (int j0 = 0; j0 < TN; j0 += 2) {
             const int ncol0 = n0 + (wn * TN + j0) * 32;
-            if (TN - j0 >= 2) fast_patch<2, R, T, L, PF_ROWBIAS, PF_PASSES>(p, acc[i][j0], acc[i][j0 + 1 < TN ? j0 + 1 : j0], wst, l, mrow0, ncol0, ln_lds, m0);
-            else fast_patch<1, R, T, L, PF_ROWBIAS, PF_PASSES>(p, acc[i][j0], acc[i][j0], wst, l, mrow0, ncol0, ln_lds, m0);
+            if (TN - j0 >= 2) fast_patch<2, R, T, L, PF_ROWBIAS, PF_PASSES, R32, O32>(p, acc[i][j0], acc[i][j0 + 1 < TN ? j0 + 1 : j0], wst, l, mrow0, ncol0, ln_lds, m0);
+            else fast_patch<1, R, T, L, PF_ROWBIAS, PF_PASSES, R32, O32>(p, acc[i][j0], acc[i][j0], wst, l, mrow0, ncol0, ln_lds, m0);
         }
     }
 }
@@ -122,7 +142,13 @@ __device__ __forceinline__ void wave_epilogue(const GemmK& p, f32x16 (&acc)[TM][
     if (tl && tid == 0) tl[2] = __builtin_amdgcn_s_memrealtime();
     float* wst = reinterpret_cast<float*>(smem) + wv * (trans ? 64 * LDT : 32 * LDW);
     float* part = p.ksplit > 1 ? p.partial + (long long)split * p.M * p.N : nullptr;
-    if (FAST_OK && !trans && !geglu && !part && !out_f32 && !(p.flags & ICD_GEMM_RESID_F32)) {
+    if constexpr (FAST_OK && TM * TN <= 8)       // (the 160-accumulator tiles have no registers for two more variants: general path)
+    if (!trans && !geglu && !part && !out_f32 && p.out32 && !p.rowbias && !p.ln_stats) {
+        // the executor's fp32 residual stream: h32 <- h32 + f (and the fp16 copy every consumer reads), or the start of such a chain
+        if ((p.flags & ICD_GEMM_RESID_F32) && p.resid) { wave_epilogue_fast<TM, TN, true, false, false, true, true>(p, acc, wst, wm, wn, l, m0, n0, ln_lds); return; }
+        if (!p.resid) { wave_epilogue_fast<TM, TN, false, false, false, false, true>(p, acc, wst, wm, wn, l, m0, n0, ln_lds); return; }
+    }
+    if (FAST_OK && !trans && !geglu && !part && !out_f32 && !p.out32 && !(p.flags & ICD_GEMM_RESID_F32)) {
         // fast path of the common epilogue, specialised by which operands exist (wave-uniform switch around the whole wave tile)
         switch ((p.resid ? 1 : 0) | (p.rowbias ? 2 : 0) | (p.ln_stats ? 4 : 0)) {
             case 0: wave_epilogue_fast<TM, TN, false, false, false>(p, acc, wst, wm, wn, l, m0, n0, ln_lds); break;   // plain / bias only
@@ -272,6 +298,11 @@ __device__ __forceinline__ void wave_epilogue(const GemmK& p, f32x16 (&acc)[TM][
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] += (float)rs[e];
                         }
+                    }
+                    if (p.out32) {
+                        float* o32 = p.out32 + (long long)m * p.ldo + n;
+                        *reinterpret_cast<f32x4*>(o32) = (f32x4){v[0], v[1], v[2], v[3]};
+                        *reinterpret_cast<f32x4*>(o32 + 4) = (f32x4){v[4], v[5], v[6], v[7]};
                     }
                     if (out_f32) {
                         float* out = reinterpret_cast<float*>(p.out) + (long long)m * p.ldo + n;

@@ -2,16 +2,16 @@
 //
 // All of them move fp16 NHWC / token-major activations with 16-byte per-lane accesses; statistics are fp32 and
 // reduced in a fixed order (no atomics) so results are bit-reproducible run to run.
-#include <stdlib.h>
 #include "common.h"
 
 namespace {
 
 constexpr int GN_THREADS = 512;
 
-// pixels per statistics block: about 1536 blocks per launch (6 per CU) but never fewer than 64 pixels per block
-static int g_tune_target = 0, g_tune_ppb = 0, g_tune_nt = 0;
-__host__ __device__ inline int gn_pix_per_split(int B, int HW, int tgt = 1536) {
+// pixels per statistics block: about 768 blocks per launch (3 per CU) but never fewer than 64 pixels per block
+// (round-3 sweep, profiles/r03_gn_sweep.txt: 768 statistics blocks per launch beat 1536 by 2-13 % on the C = 320 levels and tie
+//  elsewhere; 3072 never wins)
+__host__ __device__ inline int gn_pix_per_split(int B, int HW, int tgt = 768) {
     int target = tgt / (B > 0 ? B : 1);
     if (target < 1) target = 1;
     const int most = HW / 64 > 0 ? HW / 64 : 1;
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const half_t* __re
                                                                const float* __restrict__ ws,
                                                                const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, float eps, int silu,
-                                                               half_t* __restrict__ out, int nt_store) {
+                                                               half_t* __restrict__ out) {
     __shared__ float s_mean[64], s_rstd[64];
     const int C = C0 + C1, nchunk = C >> 3;
     const int rpi = GN_THREADS / nchunk;
@@ -145,13 +145,6 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const half_t* __re
         f16x8 v1 = __builtin_nontemporal_load(reinterpret_cast<const f16x8*>(base + (long long)(p + rpi) * cs));
         f16x8 v2 = __builtin_nontemporal_load(reinterpret_cast<const f16x8*>(base + (long long)(p + 2 * rpi) * cs));
         f16x8 v3 = __builtin_nontemporal_load(reinterpret_cast<const f16x8*>(base + (long long)(p + 3 * rpi) * cs));
-        if (nt_store) {
-            __builtin_nontemporal_store(norm8(v0), reinterpret_cast<f16x8*>(ob + (long long)p * C));
-            __builtin_nontemporal_store(norm8(v1), reinterpret_cast<f16x8*>(ob + (long long)(p + rpi) * C));
-            __builtin_nontemporal_store(norm8(v2), reinterpret_cast<f16x8*>(ob + (long long)(p + 2 * rpi) * C));
-            __builtin_nontemporal_store(norm8(v3), reinterpret_cast<f16x8*>(ob + (long long)(p + 3 * rpi) * C));
-            continue;
-        }
         *reinterpret_cast<f16x8*>(ob + (long long)p * C) = norm8(v0);
         *reinterpret_cast<f16x8*>(ob + (long long)(p + rpi) * C) = norm8(v1);
         *reinterpret_cast<f16x8*>(ob + (long long)(p + 2 * rpi) * C) = norm8(v2);
@@ -652,8 +645,7 @@ extern "C" int icd_groupnorm(const void* x0, int32_t C0, const void* x1, int32_t
             }
         }
     }
-    { const char* e = getenv("ICD_GN_TARGET"); g_tune_target = e ? atoi(e) : 0; e = getenv("ICD_GN_PPB"); g_tune_ppb = e ? atoi(e) : 0; e = getenv("ICD_GN_NT"); g_tune_nt = e ? atoi(e) : 0; }
-    const int pps = gn_pix_per_split(B, HW, g_tune_target > 0 ? g_tune_target : 1536);
+    const int pps = gn_pix_per_split(B, HW);
     const int nsplit = (HW + pps - 1) / pps;
     const int rpi = GN_THREADS / (C / 8);
     const size_t smem = (size_t)rpi * C * 2 * sizeof(float);
@@ -661,9 +653,11 @@ extern "C" int icd_groupnorm(const void* x0, int32_t C0, const void* x1, int32_t
     hipLaunchKernelGGL(gn_stats_kernel, dim3(nsplit, B), dim3(GN_THREADS), smem, st, (const half_t*)x0, C0,
                        (const half_t*)x1, C1, HW, groups, pps, stats_ws);
     ICD_CHECK_LAUNCH("icd_groupnorm(stats)");
-    const int ppb = g_tune_ppb > 0 ? g_tune_ppb : HW >= 4096 ? 128 : 64;
+    // pixels per apply block: 512 - 1024 blocks per launch (same sweep: 128 at B x HW = 131072, 64 at 32768; 256 only pays on the
+    // 128 x 128 maps and by < 2 %)
+    const int ppb = (long long)B * HW >= 98304 ? 128 : 64;
     hipLaunchKernelGGL(gn_apply_kernel, dim3((HW + ppb - 1) / ppb, B), dim3(GN_THREADS), 0, st, (const half_t*)x0, C0,
-                       (const half_t*)x1, C1, HW, groups, nsplit, ppb, stats_ws, gamma, beta, eps, silu, (half_t*)out, g_tune_nt);
+                       (const half_t*)x1, C1, HW, groups, nsplit, ppb, stats_ws, gamma, beta, eps, silu, (half_t*)out);
     ICD_CHECK_LAUNCH("icd_groupnorm(apply)");
     return ICD_OK;
 }

@@ -120,11 +120,18 @@ struct icd_unet {
     bool ln_inline = true;          // the GEMM behind a LayerNorm computes its statistics (ICD_GEMM_LN_COMPUTE)
     int xattn_tile = 0;             // A/B: host tile of the fused launch (icd_gemm_desc.tune_xattn_tile)
     bool attn_mode0 = false;        // A/B: flash attention with the scale / offset FMA on the VALU (ICD_ATTN_TUNE_MODE0)
+    // fp32 residual stream: every chain x <- x + f(x) of the UNet (ResnetBlock2D: conv2 + input / shortcut; BasicTransformerBlock: the
+    // three branch adds; Transformer2DModel: proj_out + input) accumulates in fp32, and the fp16 copy the next operator reads is
+    // rounded from that sum.  Removes the dominant error term of an fp16-storage pipeline (one rounding of the whole stream per add,
+    // ~100 - 300 adds deep): eps rel-L2 vs the fp32 oracle 1.1e-3 -> 0.8e-3, for 6 more bytes per element and add.
+    bool resid32 = false;
 };
 
 namespace {
 
-struct Act { half_t* p; int C; };          // token-major activation [B*HW, C]
+// token-major activation [B*HW, C]; p32: the same tensor before its fp16 rounding, kept only while a consumer will use it as a
+// residual (icd_unet option ICD_UNET_OPT_RESIDUAL_F32) - every other consumer (GEMM operands, GroupNorm, skip concat) reads p
+struct Act { half_t* p; int C; float* p32 = nullptr; };
 
 struct Exec {
     icd_unet* u;
@@ -142,6 +149,7 @@ struct Exec {
     half_t* k_all = nullptr;                 // [B*nctx, kv_total]: K of every cross-attention layer
     half_t* vt_all = nullptr;                // [B, kv_total, ldv_cross]: V^T of every cross-attention layer
     int kv_off = 0;
+    bool kv_external = false;
     int status = ICD_OK;
 
     const void* T(const std::string& name, int dtype, long long numel) {
@@ -193,16 +201,21 @@ struct Exec {
     // dense: out[M,N] (ldo) = a[M,K](lda) @ w[N,K]^T + bias + resid
     void linear(const half_t* a, int lda, int M, int K, const half_t* w, int N, const float* bias, const half_t* resid,
                 int ldr, half_t* out, int ldo, int flags = 0, int rps = 0, const float* ln_stats = nullptr,
-                const float* ln_colsum = nullptr) {
+                const float* ln_colsum = nullptr, const float* resid32 = nullptr, float* out32 = nullptr) {
         icd_gemm_desc d; memset(&d, 0, sizeof(d));
         d.a0 = a; d.w = w; d.bias = bias; d.resid = resid; d.out = out;
+        if (resid32) { d.resid = resid32; flags |= ICD_GEMM_RESID_F32; }       // fp32 residual stream (same leading dimension)
+        d.out_f32 = out32;
         d.ln_stats = ln_stats; d.ln_colsum = ln_colsum;
         d.M = M; d.N = N; d.K = K; d.Nw = N; d.lda = lda; d.ldw = K; d.ldo = ldo; d.ldr = ldr;
         d.rows_per_sample = rps; d.mode = 0; d.batch = 1; d.zdiv = 1; d.alpha = 1.f; d.flags = flags;
         gemm_desc(d);
     }
+    // resid32 / out32: fp32 residual stream (see icd_unet::resid32); out_is_f32: `out` itself is float (the shortcut conv of a
+    // ResnetBlock2D, which is only ever a residual)
     void conv(const Act& x0, const Act* x1, int Hin, int Win, int ksize, int stride, int upsample, const half_t* w, int Cout,
-              const float* bias, const half_t* rowbias, int ld_rowbias, const half_t* resid, half_t* out) {
+              const float* bias, const half_t* rowbias, int ld_rowbias, const half_t* resid, void* out, const float* resid32 = nullptr,
+              float* out32 = nullptr, bool out_is_f32 = false) {
         icd_gemm_desc d; memset(&d, 0, sizeof(d));
         const int Hu = Hin << upsample, Wu = Win << upsample;
         const int Ho = (Hu + stride - 1) / stride, Wo = (Wu + stride - 1) / stride;
@@ -212,8 +225,13 @@ struct Exec {
         d.ldw = d.K; d.ldo = Cout; d.ldr = Cout; d.ld_rowbias = ld_rowbias; d.rows_per_sample = Ho * Wo;
         d.mode = 1; d.Hin = Hin; d.Win = Win; d.Hout = Ho; d.Wout = Wo; d.ksize = ksize; d.stride = stride; d.upsample = upsample;
         d.batch = 1; d.zdiv = 1; d.alpha = 1.f;
+        if (resid32) { d.resid = resid32; d.flags |= ICD_GEMM_RESID_F32; }
+        d.out_f32 = out32;
+        if (out_is_f32) d.flags |= ICD_GEMM_OUT_F32;
         gemm_desc(d);
     }
+    void free_act(Act& a) { release(a.p); release(a.p32); a.p = nullptr; a.p32 = nullptr; }
+    void free32(Act& a) { release(a.p32); a.p32 = nullptr; }
     void groupnorm(const Act& x0, const Act* x1, int HW, const float* g, const float* b, float eps, int silu, half_t* out) {
         if (!ok() || dry) return;
         ProfScope ps(true, st, ICD_PROF_GROUPNORM, 0.0, 6.0 * B * (double)HW * (x0.C + (x1 ? x1->C : 0)));
@@ -242,21 +260,35 @@ struct Exec {
         Act h1a{h1, Cout};
         groupnorm(h1a, nullptr, HW, Wf(p + ".norm2.weight", Cout), Wf(p + ".norm2.bias", Cout), 1e-5f, 1, n2);
         release(h1);
+        const bool r32 = u->resid32;
         const half_t* resid = x0.p;
+        const float* resid_f = r32 ? x0.p32 : nullptr;
         half_t* sc = nullptr;
+        float* sc32 = nullptr;
         if (Cin != Cout) {
-            sc = alloc<half_t>(M * Cout);
-            conv(x0, x1, Hh, Ww, 1, 1, 0, Wh(p + ".conv_shortcut.weight", (long long)Cin * Cout), Cout,
-                 Wf(p + ".conv_shortcut.bias", Cout), nullptr, 0, nullptr, sc);
-            resid = sc;
+            if (r32) {                               // the shortcut is only ever a residual: fp32 output, no fp16 copy
+                sc32 = alloc<float>(M * Cout);
+                conv(x0, x1, Hh, Ww, 1, 1, 0, Wh(p + ".conv_shortcut.weight", (long long)Cin * Cout), Cout,
+                     Wf(p + ".conv_shortcut.bias", Cout), nullptr, 0, nullptr, sc32, nullptr, nullptr, true);
+                resid_f = sc32;
+            } else {
+                sc = alloc<half_t>(M * Cout);
+                conv(x0, x1, Hh, Ww, 1, 1, 0, Wh(p + ".conv_shortcut.weight", (long long)Cin * Cout), Cout,
+                     Wf(p + ".conv_shortcut.bias", Cout), nullptr, 0, nullptr, sc);
+                resid = sc;
+            }
         }
         half_t* out = alloc<half_t>(M * Cout);
+        float* out32 = r32 ? alloc<float>(M * Cout) : nullptr;
         Act n2a{n2, Cout};
         conv(n2a, nullptr, Hh, Ww, 3, 1, 0, Wh(p + ".conv2.weight", 9LL * Cout * Cout), Cout, Wf(p + ".conv2.bias", Cout),
-             nullptr, 0, resid, out);
+             nullptr, 0, resid_f ? nullptr : resid, out, resid_f, out32);
         release(n2);
         release(sc);
-        return Act{out, Cout};
+        release(sc32);
+        Act o{out, Cout};
+        o.p32 = out32;
+        return o;
     }
 
     // Phase 0 of the plugin protocol for the next Attention module (module-execution order): does the controller want its
@@ -325,7 +357,9 @@ struct Exec {
         half_t* n = alloc<half_t>(M * C);
         groupnorm(x, nullptr, HW, Wf(p + ".norm.weight", C), Wf(p + ".norm.bias", C), 1e-6f, 0, n);
         half_t* h = alloc<half_t>(M * C);
-        linear(n, C, (int)M, C, Wh(p + ".proj_in.weight", (long long)C * C), C, Wf(p + ".proj_in.bias", C), nullptr, 0, h, C);
+        float* h32 = u->resid32 ? alloc<float>(M * C) : nullptr;         // fp32 residual stream of the transformer blocks
+        linear(n, C, (int)M, C, Wh(p + ".proj_in.weight", (long long)C * C), C, Wf(p + ".proj_in.bias", C), nullptr, 0, h, C, 0, 0,
+               nullptr, nullptr, nullptr, h32);
         // the first GEMM behind each LayerNorm computes the statistics of its input rows itself (from its MFMA operand fragments
         // where the tile kernel can, see icd_gemm) and leaves them in lnst for a second consumer (to_v after to_qk)
         const int lnc = u->ln_inline ? ICD_GEMM_LN_COMPUTE : 0;
@@ -347,7 +381,8 @@ struct Exec {
             const AttnPlan self_plan = attn_query(false, place, heads, HW, HW);
             attention(self_plan, false, place, qk, 2 * C, qk + C, 2 * C, vt, ldv_self, (long long)C * ldv_self, heads, HW, HW, d, ao, C);
             release(qk); release(vt);
-            linear(ao, C, (int)M, C, Wh(b + ".attn1.to_out.0.weight", (long long)C * C), C, Wf(b + ".attn1.to_out.0.bias", C), h, C, h, C);
+            linear(ao, C, (int)M, C, Wh(b + ".attn1.to_out.0.weight", (long long)C * C), C, Wf(b + ".attn1.to_out.0.bias", C), h32 ? nullptr : h, C,
+                   h, C, 0, 0, nullptr, nullptr, h32, h32);
             // ---- cross attention ----
             ln_stats(h, M, C, lnst);
             // K and V^T of this layer are column / row slices of the per-forward batched projections
@@ -381,21 +416,28 @@ struct Exec {
                 release(q2);
             }
             kv_off += C;
-            linear(ao, C, (int)M, C, Wh(b + ".attn2.to_out.0.weight", (long long)C * C), C, Wf(b + ".attn2.to_out.0.bias", C), h, C, h, C);
+            linear(ao, C, (int)M, C, Wh(b + ".attn2.to_out.0.weight", (long long)C * C), C, Wf(b + ".attn2.to_out.0.bias", C), h32 ? nullptr : h, C,
+                   h, C, 0, 0, nullptr, nullptr, h32, h32);
             release(ao);
             // ---- GEGLU feed-forward ----
             ln_stats(h, M, C, lnst);
             half_t* ff = alloc<half_t>(M * 4 * C);
             linear(h, C, (int)M, C, Wh(b + ".ff.net.0.proj.weight", 8LL * C * C), 8 * C, Wf(b + ".ff.net.0.proj.bias", 8 * C), nullptr, 0,
                    ff, 4 * C, ICD_GEMM_GEGLU | lnc, 0, lnst, Wf(b + ".ff.net.0.proj.lnsum", 8 * C));
-            linear(ff, 4 * C, (int)M, 4 * C, Wh(b + ".ff.net.2.weight", 4LL * C * C), C, Wf(b + ".ff.net.2.bias", C), h, C, h, C);
+            linear(ff, 4 * C, (int)M, 4 * C, Wh(b + ".ff.net.2.weight", 4LL * C * C), C, Wf(b + ".ff.net.2.bias", C), h32 ? nullptr : h, C, h, C,
+                   0, 0, nullptr, nullptr, h32, h32);
             release(ff);
         }
         release(lnst);
         half_t* out = alloc<half_t>(M * C);
-        linear(h, C, (int)M, C, Wh(p + ".proj_out.weight", (long long)C * C), C, Wf(p + ".proj_out.bias", C), x.p, C, out, C);
+        float* out32 = u->resid32 ? alloc<float>(M * C) : nullptr;
+        release(h32);                                // (proj_out reads the fp16 copy of the stream as its operand)
+        linear(h, C, (int)M, C, Wh(p + ".proj_out.weight", (long long)C * C), C, Wf(p + ".proj_out.bias", C), x.p32 ? nullptr : x.p, C, out, C,
+               0, 0, nullptr, nullptr, x.p32, out32);
         release(h);
-        return Act{out, C};
+        Act o{out, C};
+        o.p32 = out32;
+        return o;
     }
 
     int forward() {
@@ -451,12 +493,27 @@ struct Exec {
         // every cross-attention K / V projection depends on the context only: two GEMMs for the whole forward
         {
             const int X = c.cross_dim, Mc = B * nctx, ldvc = (nctx + 7) / 8 * 8;
-            k_all = alloc<half_t>((long long)Mc * u->kv_total);
-            vt_all = alloc<half_t>((long long)B * u->kv_total * ldvc);
-            linear((const half_t*)io->context, X, Mc, X, Wh("attn2_k_cat.weight", (long long)u->kv_total * X), u->kv_total, nullptr,
-                   nullptr, 0, k_all, u->kv_total);
-            linear((const half_t*)io->context, X, Mc, X, Wh("attn2_v_cat.weight", (long long)u->kv_total * X), u->kv_total, nullptr,
-                   nullptr, 0, vt_all, ldvc, ICD_GEMM_OUT_TRANS, nctx);
+            const long long k_elems = (long long)Mc * u->kv_total, v_elems = (long long)B * u->kv_total * ldvc;
+            bool have = false;
+            if (!dry && io->kv_cache) {                  // caller-owned cache of the context projections (icd_unet_io.kv_cache)
+                if (io->kv_cache_bytes < (k_elems + v_elems) * 2) {
+                    icd_set_error("icd_unet_forward: kv_cache too small (%lld bytes given); query icd_unet_kv_cache_bytes", (long long)io->kv_cache_bytes);
+                    return ICD_ERR_WORKSPACE;
+                }
+                k_all = (half_t*)io->kv_cache; vt_all = k_all + k_elems; kv_external = true;
+                have = io->kv_cache_valid != 0;
+            } else {
+                k_all = alloc<half_t>(k_elems);
+                vt_all = alloc<half_t>(v_elems);
+            }
+            if (!have) {
+                linear((const half_t*)io->context, X, Mc, X, Wh("attn2_k_cat.weight", (long long)u->kv_total * X), u->kv_total, nullptr,
+                       nullptr, 0, k_all, u->kv_total);
+                linear((const half_t*)io->context, X, Mc, X, Wh("attn2_v_cat.weight", (long long)u->kv_total * X), u->kv_total, nullptr,
+                       nullptr, 0, vt_all, ldvc, ICD_GEMM_OUT_TRANS, nctx);
+            } else {                                     // (a finalize-style walk still checks that the weights are bound)
+                (void)Wh("attn2_k_cat.weight", (long long)u->kv_total * X); (void)Wh("attn2_v_cat.weight", (long long)u->kv_total * X);
+            }
             kv_off = 0;
         }
         release(e1); release(emb); if (tin != tsin) release(tin); release(tsin);
@@ -473,10 +530,14 @@ struct Exec {
                 run(icd_pack_latent(io->sample, io->sample_is_f32, B, HW0, lat8, st));
             }
             Act l8{lat8, 8};
-            conv(l8, nullptr, H0, W0, 3, 1, 0, Wh("conv_in.weight8", 72LL * ch0), ch0, Wf("conv_in.bias", ch0), nullptr, 0, nullptr, h.p);
+            if (u->resid32) h.p32 = alloc<float>((long long)B * HW0 * ch0);       // residual of down_blocks.0.resnets.0
+            conv(l8, nullptr, H0, W0, 3, 1, 0, Wh("conv_in.weight8", 72LL * ch0), ch0, Wf("conv_in.bias", ch0), nullptr, 0, nullptr, h.p,
+                 nullptr, h.p32);
             release(lat8);
         }
-        skips.push_back(h);
+        // the skip stack keeps the fp16 tensors (their consumers concatenate them as GEMM / GroupNorm operands); the fp32 twin of a
+        // tensor lives only until the one operator that uses it as a residual has run
+        skips.push_back(Act{h.p, h.C});
         int Hh = H0, Ww = W0;
         // ---------------- down
         for (int i = 0; i < L && ok(); ++i) {
@@ -484,33 +545,39 @@ struct Exec {
             for (int j = 0; j < c.layers_per_block && ok(); ++j) {
                 const std::string rp = "down_blocks." + std::to_string(i) + ".resnets." + std::to_string(j);
                 Act r = resnet(rp, h, nullptr, Hh, Ww, Cout);
-                // h stays alive: it is on the skip stack
+                // h stays alive: it is on the skip stack (its fp32 twin has served as this resnet's residual)
+                free32(h);
                 h = r;
                 if (c.down_has_attn[i]) {
                     Act t = transformer("down_blocks." + std::to_string(i) + ".attentions." + std::to_string(j), h, Hh, Ww,
                                         c.transformer_layers[i], c.num_heads[i], 0);
-                    release(h.p);
+                    free_act(h);
                     h = t;
                 }
-                skips.push_back(h);
+                skips.push_back(Act{h.p, h.C});
             }
             if (i < L - 1) {
                 const std::string dp = "down_blocks." + std::to_string(i) + ".downsamplers.0.conv";
                 Act dn{alloc<half_t>((long long)B * (Hh / 2) * (Ww / 2) * Cout), Cout};
-                conv(h, nullptr, Hh, Ww, 3, 2, 0, Wh(dp + ".weight", 9LL * Cout * Cout), Cout, Wf(dp + ".bias", Cout), nullptr, 0, nullptr, dn.p);
+                // (its fp32 twin is a residual only where the next level keeps the channel count: SD1.5's last level)
+                if (u->resid32 && c.block_out_channels[i + 1] == Cout) dn.p32 = alloc<float>((long long)B * (Hh / 2) * (Ww / 2) * Cout);
+                conv(h, nullptr, Hh, Ww, 3, 2, 0, Wh(dp + ".weight", 9LL * Cout * Cout), Cout, Wf(dp + ".bias", Cout), nullptr, 0, nullptr, dn.p,
+                     nullptr, dn.p32);
+                free32(h);
                 Hh /= 2; Ww /= 2;
                 h = dn;
-                skips.push_back(h);
+                skips.push_back(Act{h.p, h.C});
             }
         }
         // ---------------- mid
         {
             const int Cm = c.block_out_channels[L - 1];
             Act r0 = resnet("mid_block.resnets.0", h, nullptr, Hh, Ww, Cm);     // h is the last skip: stays alive
+            free32(h);
             Act t = transformer("mid_block.attentions.0", r0, Hh, Ww, c.transformer_layers[L - 1], c.num_heads[L - 1], 1);
-            release(r0.p);
+            free_act(r0);
             Act r1 = resnet("mid_block.resnets.1", t, nullptr, Hh, Ww, Cm);
-            release(t.p);
+            free_act(t);
             h = r1;
         }
         // ---------------- up
@@ -521,20 +588,21 @@ struct Exec {
                 Act sk = skips.back(); skips.pop_back();
                 const std::string rp = "up_blocks." + std::to_string(i) + ".resnets." + std::to_string(j);
                 Act r = resnet(rp, h, &sk, Hh, Ww, Cout);
-                release(h.p); release(sk.p);
+                free_act(h); release(sk.p);
                 h = r;
                 if (c.up_has_attn[i]) {
                     Act t = transformer("up_blocks." + std::to_string(i) + ".attentions." + std::to_string(j), h, Hh, Ww,
                                         c.transformer_layers[lvl], c.num_heads[lvl], 2);
-                    release(h.p);
+                    free_act(h);
                     h = t;
                 }
+                free32(h);                           // the next resnet concatenates h with a skip: Cin != Cout, its residual is the shortcut
             }
             if (i < L - 1) {
                 const std::string upn = "up_blocks." + std::to_string(i) + ".upsamplers.0.conv";
                 Act up{alloc<half_t>((long long)B * (Hh * 2) * (Ww * 2) * Cout), Cout};
                 conv(h, nullptr, Hh, Ww, 3, 1, 1, Wh(upn + ".weight", 9LL * Cout * Cout), Cout, Wf(upn + ".bias", Cout), nullptr, 0, nullptr, up.p);
-                release(h.p);
+                free_act(h);
                 Hh *= 2; Ww *= 2;
                 h = up;
             }
@@ -542,7 +610,7 @@ struct Exec {
         // ---------------- out
         half_t* n = alloc<half_t>((long long)B * HW0 * ch0);
         groupnorm(h, nullptr, HW0, Wf("conv_norm_out.weight", ch0), Wf("conv_norm_out.bias", ch0), 1e-5f, 1, n);
-        release(h.p);
+        free_act(h);
         const half_t* wo = Wh("conv_out.weight", 9LL * ch0 * c.out_channels);
         const float* bo = Wf("conv_out.bias", c.out_channels);
         if (ok() && !dry) {
@@ -550,7 +618,8 @@ struct Exec {
             run(icd_conv_out(n, B, H0, W0, ch0, wo, bo, io->eps, io->sample_is_f32, st));
         }
         release(n);
-        release(temb_all); release(k_all); release(vt_all);
+        release(temb_all);
+        if (!kv_external) { release(k_all); release(vt_all); }
         return status;
     }
 };
@@ -587,6 +656,9 @@ extern "C" int icd_unet_set_option(icd_unet* u, int32_t option, int32_t value) {
     case ICD_UNET_OPT_ATTN_VALU_SCALE:
         ICD_CHECK_ARG(value == 0 || value == 1, "icd_unet_set_option: ICD_UNET_OPT_ATTN_VALU_SCALE takes 0 or 1 (got %d)", value);
         u->attn_mode0 = value != 0; return ICD_OK;
+    case ICD_UNET_OPT_RESIDUAL_F32:
+        ICD_CHECK_ARG(value == 0 || value == 1, "icd_unet_set_option: ICD_UNET_OPT_RESIDUAL_F32 takes 0 or 1 (got %d)", value);
+        u->resid32 = value != 0; return ICD_OK;
     case ICD_UNET_OPT_LN_INLINE_STATS:
         ICD_CHECK_ARG(value == 0 || value == 1, "icd_unet_set_option: ICD_UNET_OPT_LN_INLINE_STATS takes 0 or 1 (got %d)", value);
         u->ln_inline = value != 0; return ICD_OK;
@@ -709,6 +781,12 @@ extern "C" int64_t icd_unet_workspace_bytes_ex(const icd_unet* u, int32_t batch,
 // are the hook's allocations, not arena memory).
 extern "C" int64_t icd_unet_workspace_bytes(const icd_unet* u, int32_t batch, int32_t H, int32_t W, int32_t n_ctx) {
     return icd_unet_workspace_bytes_ex(u, batch, H, W, n_ctx, 2);
+}
+
+extern "C" int64_t icd_unet_kv_cache_bytes(const icd_unet* u, int32_t batch, int32_t n_ctx) {
+    if (!u || batch <= 0 || n_ctx <= 0) return -1;
+    const long long ldvc = (n_ctx + 7) / 8 * 8;
+    return ((long long)batch * n_ctx * u->kv_total + (long long)batch * u->kv_total * ldvc) * 2;
 }
 
 extern "C" int icd_unet_forward(icd_unet* u, const icd_unet_io* io, void* stream) {

@@ -60,7 +60,8 @@ FORBID_BIG_TILE = 0x200000
 
 
 def gemm(a, w, bias=None, resid=None, rowbias=None, rows_per_sample=0, geglu=False, out=None, alpha=1.0,
-         out_f32=False, debug_flags=0, ln_stats=None, ln_colsum=None, ln_compute=False, ln_eps=1e-5, group_m=0, timeline=None):
+         out_f32=False, debug_flags=0, ln_stats=None, ln_colsum=None, ln_compute=False, ln_eps=1e-5, group_m=0, timeline=None,
+         out32=None):
     """out[M, N] = alpha * a[M, K] @ w[N, K]^T (+bias[N] fp32) (+rowbias[m // rps]) (+resid) ; GEGLU halves N.
     ln_stats [M, 2] fp32 + ln_colsum [N] fp32: LayerNorm of `a` fused into the epilogue (w carries gamma, bias carries W beta)."""
     _chk16(a, "a"); _chk16(w, "w")
@@ -90,6 +91,9 @@ def gemm(a, w, bias=None, resid=None, rowbias=None, rows_per_sample=0, geglu=Fal
         if ln_compute:                        # ln_stats is filled by this launch (ICD_GEMM_LN_COMPUTE), not read
             d.flags |= _lib.ICD_GEMM_LN_COMPUTE
             d.ln_eps = ln_eps
+    if out32 is not None:                     # second output: the same values before the fp16 rounding (fp32 residual stream)
+        assert out32.dtype == torch.float32 and out32.is_cuda and tuple(out32.shape) == (M, n_out) and out32.stride(0) == out.stride(0)
+        d.out_f32 = out32.data_ptr()
     d.tune_group_m = group_m                  # tuning / diagnostics travel in the descriptor (no process-wide state)
     d.debug_timeline = timeline.data_ptr() if timeline is not None else None
     ws = _splitk_ws(d, a.device)

@@ -205,14 +205,23 @@ class UNet2DConditionModel:
         self.attn_cond_only = False
         self._t_cache = {}
         self._live = []
+        # cross-attention K / V^T of the last context (icd_unet_io.kv_cache): a sampling loop passes the same context tensor at
+        # every step, so steps 2..n skip the two context projections.  The cached context is kept referenced - its storage
+        # cannot be recycled under the cache - and is recognised by (data_ptr, shape, version counter): an in-place update
+        # of the tensor bumps the counter and refills the cache.
+        self.kv_cache_enabled = True
+        self._kv = None            # (ctx tensor, version, cache buffer, stream)
 
     OPTIONS = {"xattn_fusion": _lib.ICD_UNET_OPT_XATTN_FUSION, "ln_inline_stats": _lib.ICD_UNET_OPT_LN_INLINE_STATS,
-               "xattn_tile": _lib.ICD_UNET_OPT_XATTN_TILE, "attn_valu_scale": _lib.ICD_UNET_OPT_ATTN_VALU_SCALE}
+               "xattn_tile": _lib.ICD_UNET_OPT_XATTN_TILE, "attn_valu_scale": _lib.ICD_UNET_OPT_ATTN_VALU_SCALE,
+               "residual_f32": _lib.ICD_UNET_OPT_RESIDUAL_F32}
 
     def set_option(self, name, value):
         """Per-handle execution option (icd_unet_set_option): 'xattn_fusion' 0 / 1 / 2, 'ln_inline_stats' 0 / 1, 'xattn_tile' 0 / 2 / 4.  A/B tuning and
         tests; the defaults are the measured-faster settings and nothing is process-wide."""
         _lib.check(self._lib.icd_unet_set_option(self._h, self.OPTIONS[name], int(value)), f"icd_unet_set_option({name})")
+        if name == "residual_f32":
+            self._ws_key = None                  # the arena holds the fp32 twins of the residual stream: size it again
         return self
 
     # ------------------------------------------------------------------ duck-typed nn.Module surface
@@ -330,11 +339,22 @@ class UNet2DConditionModel:
         io.batch, io.H, io.W, io.n_ctx = B, H, W, n_ctx
         io.sample_is_f32 = int(io_dtype == torch.float32)
         io.hook = hook
+        if self.kv_cache_enabled:
+            kv, stream_id = self._kv, torch.cuda.current_stream().cuda_stream
+            hit = (kv is not None and kv[0].data_ptr() == ctx.data_ptr() and kv[0].shape == ctx.shape and kv[0].stride() == ctx.stride()
+                   and kv[0]._version == ctx._version == kv[1] and kv[3] == stream_id)       # (filled and read on ONE stream)
+            if not hit:
+                nbytes = self._lib.icd_unet_kv_cache_bytes(self._h, B, n_ctx)
+                buf = kv[2] if kv is not None and kv[2].numel() == nbytes else torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+                self._kv = kv = (ctx, ctx._version, buf, stream_id)
+            io.kv_cache, io.kv_cache_bytes, io.kv_cache_valid = kv[2].data_ptr(), kv[2].numel(), int(hit)
         rc = self._lib.icd_unet_forward(self._h, C.byref(io), C.c_void_p(torch.cuda.current_stream().cuda_stream))
         # the probability buffers handed in by the hook stay referenced until the NEXT call (cleared at its start): the launch is
         # asynchronous, and freeing them here would rely on every later consumer of the allocator running on this same stream
         if errors:
             raise errors[0]
+        if rc != 0:
+            self._kv = None                      # a failed forward may have left the cache half written
         _lib.check(rc, "icd_unet_forward")
         if not return_dict:
             return (eps,)

@@ -221,6 +221,29 @@ def test_conv_odd_and_non_square_maps(cfg):
     assert rel_l2(out, to_nhwc(ref)) < TOL
 
 
+@pytest.mark.parametrize("M,N,K,flags", [(8192, 1280, 1280, 0),                                    # planner: 192 x 256 tile, fast variant R32 + O32
+                                         (4096, 512, 512, 0x100000 | (1 << 24)),                     # forced 256 x 256
+                                         (4096, 640, 640, 0x100000 | (2 << 24)),                     # forced 256 x 320 (general epilogue)
+                                         (4096, 640, 640, 0x100000 | (4 << 24)),                     # forced 128 x 320
+                                         (200, 320, 320, 0),                                         # 128-wide kernel, ragged M
+                                         (512, 1280, 5120, 0)])                                      # split-K + reduce kernel
+def test_gemm_fp32_residual_stream_outputs(M, N, K, flags):
+    """icd_gemm_desc.out_f32 + ICD_GEMM_RESID_F32 (UNet option residual_f32): out32 = resid32 + a w^T + bias in fp32, out = fp16(out32),
+    in place on the fp32 stream like the executor's h <- h + f(h); also the start of a chain (no residual, both outputs)."""
+    ops = _ops()
+    a, w = r16(M, K, seed=140), (r16(N, K, seed=141).float() * K ** -0.5).half()
+    bias = torch.randn(N, generator=torch.Generator().manual_seed(142))
+    h32 = torch.randn(M, N, generator=torch.Generator().manual_seed(143)) * 3.0
+    ref = h32.double() + a.double() @ w.double().t() + bias.double()
+    stream = h32.clone().cuda()
+    out = ops.gemm(a.cuda(), w.cuda(), bias=bias.cuda(), resid=stream, out32=stream, debug_flags=flags)       # in place on the fp32 stream
+    assert rel_l2(stream, ref) < 1e-5                                                                # fp32 accumulation and storage
+    assert torch.equal(out.cpu(), stream.cpu().half())                                              # the fp16 copy is rounded from the sum
+    o32 = torch.empty(M, N, device="cuda")
+    out2 = ops.gemm(a.cuda(), w.cuda(), bias=bias.cuda(), out32=o32, debug_flags=flags)              # chain start: no residual
+    assert rel_l2(o32, a.double() @ w.double().t() + bias.double()) < 1e-5 and torch.equal(out2.cpu(), o32.cpu().half())
+
+
 def test_gemm_rowbias_alpha_f32():
     ops = _ops()
     B, HW, K, N = 3, 64, 128, 192

@@ -122,6 +122,27 @@ def test_unet_full_sd15_small_latent():
     _run_case(uc.SD15, B=2, H=32, W=32, t=519, seed=4, tol=2e-3)
 
 
+@pytest.mark.parametrize("which", ["sd15_tiny", "sdxl_tiny", "sd15_full_32"])
+def test_fp32_residual_stream_meets_the_north_star_tolerance(which):
+    """UNet option residual_f32 (what load_models(dtype='fp32') selects): every x <- x + f(x) chain of the UNet accumulates in fp32
+    (icd_gemm_desc.out_f32 + ICD_GEMM_RESID_F32), the fp16 copy the next operator reads is rounded from that sum.  The north
+    star's bar is 1e-3 rel-L2; with fp16 activation storage the residual stream's own roundings (one per add, 100-300 adds deep)
+    put a single forward at 1.1e-3 - this option removes that term.  Asserted: eps rel-L2 < 1e-3 against the fp32 oracle, clearly
+    better than the default mode of the SAME handle, and switching the option off restores the default result bit for bit."""
+    _, _, uc, _ = _mods()
+    if which == "sd15_tiny":
+        cfg, B, H = uc.SD15.scaled((64, 128, 256, 256), cross_dim=64), 2, 32
+    elif which == "sdxl_tiny":
+        cfg, B, H = uc.SDXL.scaled((64, 128, 256), cross_dim=128, heads=(2, 4, 8)), 2, 32
+    else:
+        cfg, B, H = uc.SD15, 2, 32
+    r = _run_case(cfg, B=B, H=H, W=H, t=779, seed=31, tol=2e-3, variants={"resid32": {"residual_f32": 1}, "back": {"residual_f32": 0}})
+    e16, e32 = r[None][0], r["resid32"][0]
+    print(f"[{which}] fp16 residual stream {e16:.3e} -> fp32 residual stream {e32:.3e}")
+    assert e32 < 1.0e-3 and e32 < 0.85 * e16
+    assert torch.equal(r["back"][1], r[None][1])
+
+
 @pytest.mark.slow
 def test_unet_full_sd15_64x64():
     """BASELINE config-1 shape: full SD1.5, 64x64 latent (512x512 image), CFG-doubled batch of 2."""
@@ -170,3 +191,54 @@ def test_unet_full_sd15_b8_64x64_on_the_benchmarked_tiles_and_layernorm_statisti
     print(f"[LN statistics in the consuming GEMM vs a pass over the stream] vs oracle {r[None][0]:.3e} / {r['ln_pass'][0]:.3e}; "
           f"the two differ by {d:.3e}")
     assert 0.0 < d < 2e-3 and abs(r[None][0] - r["ln_pass"][0]) < 2e-4
+
+
+def test_context_projection_cache_is_exact_and_notices_a_changed_context():
+    """Steps 2..n of a sampling loop pass the SAME context tensor: the executor then skips the two context-only projections
+    (cross-attention K / V^T of every layer, icd_unet_io.kv_cache).  The cache must (a) never change a bit of the output, (b) refill
+    when the context tensor is updated in place (version counter) or replaced by another tensor - also one that the allocator
+    places at the address of a freed one."""
+    from invertible_cd_amd import _lib
+    synthetic, unet, uc, _ = _mods()
+    cfg = uc.SD15.scaled((64, 128, 256, 256), cross_dim=64)
+    model = unet.UNet2DConditionModel(cfg, synthetic.synthetic_state_dict(cfg, seed=21))
+    inp = synthetic.synthetic_inputs(cfg, 2, 16, 16, seed=21)
+    x = inp["latents"].half().cuda()
+    ctx = inp["context"].half().cuda()
+    run = lambda c: model(x, 519, encoder_hidden_states=c).sample.clone()
+
+    def dense_launches(c):
+        _lib.profile_enable(True)
+        try:
+            out = run(c)
+            torch.cuda.synchronize()
+            return out, _lib.profile_read()["gemm_dense"]["launches"]
+        finally:
+            _lib.profile_enable(False)
+
+    model.kv_cache_enabled = False
+    ref, n_off = dense_launches(ctx)
+    model.kv_cache_enabled = True
+    a, n_fill = dense_launches(ctx)                   # fills the cache
+    b, n_hit = dense_launches(ctx)                    # reads it
+    assert torch.equal(a, ref) and torch.equal(b, ref)
+    assert n_fill == n_off and n_hit == n_off - 2     # exactly the two context projections are skipped
+    ctx2 = ctx * 1.5
+    ref2 = run(ctx2)                                  # another tensor -> refill
+    model.kv_cache_enabled = False
+    assert torch.equal(ref2, run(ctx2)) and not torch.equal(ref2, ref)
+    model.kv_cache_enabled = True
+    run(ctx2)
+    ctx2.mul_(0.5)                                    # in-place update of the cached tensor -> the version counter moves -> refill
+    got = run(ctx2)
+    model.kv_cache_enabled = False
+    assert torch.equal(got, run(ctx2))
+    model.kv_cache_enabled = True
+    for i in range(3):                                # fresh tensors of one shape: the allocator hands out recycled addresses
+        c = (ctx * (1.0 + 0.25 * i)).contiguous()
+        got = run(c)
+        model.kv_cache_enabled = False
+        want = run(c)
+        model.kv_cache_enabled = True
+        assert torch.equal(got, want)
+        del c

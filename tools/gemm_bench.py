@@ -64,19 +64,41 @@ else:
     ldv = (Nk + 7) // 8 * 8
     vt = torch.zeros(B, H * d, ldv, device=dev, dtype=torch.float16)
     vt[:, :, :Nk] = v.reshape(B, Nk, H * d).transpose(1, 2)
-    fn = lambda: ops.attention_fused(q, k, vt, B, H, Nq, Nk, d, d ** -0.5)
+    import ctypes as C
+    from invertible_cd_amd import _lib
+    out_a = torch.empty_like(q)
+    def fn():
+        # DBGFLAGS here = icd_attention_fused_ex flags (2: prescaled query, 4: VALU scale form, bits 8..11: instantiation variant)
+        _lib.check(_lib.load().icd_attention_fused_ex(q.data_ptr(), k.data_ptr(), vt.data_ptr(), out_a.data_ptr(), B, H, Nq, Nk, d, q.stride(0),
+                                                      k.stride(0), vt.stride(1), out_a.stride(0), vt.stride(0), d ** -0.5, dbg,
+                                                      C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        return out_a
     flops = 4.0 * B * H * Nq * Nk * d
-# DBGFLAGS may be a comma-separated list: every entry is timed in this process (same box, same clocks)
-for dbg_s in os.environ.get("DBGFLAGS", "0").split(","):
-    dbg = int(dbg_s, 0)
-    for _ in range(3):
-        fn()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
-        fn()
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / iters
-    print(f"{kind} {a} flags={dbg_s}: {ms * 1e3:.1f} us/call  {flops / ms / 1e9:.1f} TFLOP/s")
+# DBGFLAGS may be a comma-separated list: every entry is timed in this process (same box).  The entries are visited round-robin
+# ROUNDS times (default 5) and the minimum per entry is reported: the first thing timed after an idle period runs at ramping clocks
+# (10-15 % slower, seen in round 3), which a single pass in list order turns into a bias against the first entry.
+flag_list = os.environ.get("DBGFLAGS", "0").split(",")
+rounds = int(os.environ.get("ROUNDS", "5"))
+best = {}
+for _ in range(20):
+    dbg = int(flag_list[0], 0)
+    fn()
+torch.cuda.synchronize()
+for r in range(rounds):
+    for dbg_s in flag_list:
+        dbg = int(dbg_s, 0)
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / iters
+        best.setdefault(dbg_s, []).append(ms)
+for dbg_s in flag_list:
+    v = sorted(best[dbg_s])
+    ms = v[0]
+    print(f"{kind} {a} flags={dbg_s}: {ms * 1e3:.1f} us/call (min of {rounds}; median {v[len(v) // 2] * 1e3:.1f})  {flops / ms / 1e9:.1f} TFLOP/s")

@@ -79,6 +79,12 @@ struct AttnK {
 //   MODE 2 (no free slot, e.g. 64 / 80): the S^T accumulators start from -M instead of zero (16 VGPRs per query tile).
 // Either way p = exp2(s): the 32 FMAs per lane and tile are gone (-30 % VALU instructions in the steady state).
 // MODE 0: scores scaled on the VALU as before (any q; also what a prescaled q takes where no MODE 1 / 2 instantiation exists).
+// Measured (same-box round-robin, profiles/r03_attn_variants.txt): 4096 x 4096 d = 40: -5.3 %, d = 64: -2.6 %, 1024 x 1024: -1..2 %.
+// The instruction count falls by 30 %, the time by 5 %: the loop is not VALU-throughput bound.  Also built and measured in round 3
+// (profiles/r03_attn_pipe.txt): the two query tiles of a wave half a phase apart inside the instruction stream (S^T MFMAs of tile 1
+// between the exponentials of tile 0, P.V of tile 0 between the exponentials of tile 1, pinned with sched_group_barrier and asm
+// anchors against MachineSink) - bit-identical results, 934 us against 919 us: intra-wave MFMA / VALU overlap is not the limit
+// either.  Removed again.
 template <int KS, int DT, int QT, int OCC, int NST, int MODE = 0>
 __global__ __launch_bounds__(256, OCC) void attn_fused_kernel(AttnK p) {
     constexpr int NCH = 2 * KS;                       // 16-B chunks per K row

@@ -85,7 +85,9 @@ struct AttnK {
 // between the exponentials of tile 0, P.V of tile 0 between the exponentials of tile 1, pinned with sched_group_barrier and asm
 // anchors against MachineSink) - bit-identical results, 934 us against 919 us: intra-wave MFMA / VALU overlap is not the limit
 // either.  Removed again.
-template <int KS, int DT, int QT, int OCC, int NST, int MODE = 0>
+// CAUSAL is a template switch (round 3): as a run-time flag its 64 per-element key comparisons kept ~60 scalar registers alive
+// through the whole loop, and the spill code (v_readlane / v_writelane around every use) sat on the non-causal hot path too.
+template <int KS, int DT, int QT, int OCC, int NST, int MODE = 0, bool CAUSAL = false>
 __global__ __launch_bounds__(256, OCC) void attn_fused_kernel(AttnK p) {
     constexpr int NCH = 2 * KS;                       // 16-B chunks per K row
     constexpr bool ONES = KS * 16 < DT * 32;          // a free padded V^T row exists: MFMA computes the denominator
@@ -258,17 +260,16 @@ __global__ __launch_bounds__(256, OCC) void attn_fused_kernel(AttnK p) {
                                                                               k0 + kk == 0 ? (MODE == 2 ? minit[MODE == 2 ? u : 0] : zero16) : s[u][kt], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (rag || p.causal) {                           // wave-uniform: ragged last tile (keys past Nk) / causal mask -> -inf
+        if (rag || CAUSAL) {                             // wave-uniform: ragged last tile (keys past Nk) / causal mask -> -inf
 #pragma unroll
             for (int u = 0; u < QT; ++u) {
-                const int last = p.causal ? min(p.Nk - 1, q0 + u * 32 + lr) : p.Nk - 1;    // last key this query may see
+                const int last = CAUSAL ? min(p.Nk - 1, q0 + u * 32 + lr) : p.Nk - 1;    // last key this query may see
+                const int lim = last - t * 64 - 8 * lh;  // (constant) > (one per-lane limit): no scalar register per key slot
 #pragma unroll
                 for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int key = t * 64 + kt * 32 + 16 * (e >> 3) + 8 * lh + (e & 7);
-                        if (key > last) s[u][kt][e] = -INFINITY;
-                    }
+                    for (int e = 0; e < 16; ++e)
+                        if (kt * 32 + 16 * (e >> 3) + (e & 7) > lim) s[u][kt][e] = -INFINITY;
             }
         }
     };
@@ -520,8 +521,7 @@ __global__ __launch_bounds__(256, 2) void attn_cross_kernel(AttnK p, int tiles_p
         for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int key = kt * 32 + 16 * (e >> 3) + 8 * lh + (e & 7);
-                if (key >= p.Nk) s[kt][e] = -INFINITY;
+                if (kt * 32 + 16 * (e >> 3) + (e & 7) >= p.Nk - 8 * lh) s[kt][e] = -INFINITY;      // key >= Nk
                 mx = fmaxf(mx, s[kt][e]);
             }
         {
@@ -631,8 +631,7 @@ __global__ __launch_bounds__(256, 2) void attn_probs_kernel(ProbsK a) {
         for (int ks = 0; ks < KS; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[ks], qf[ks], ks == 0 ? zero16 : s, 0, 0, 0);
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            const int key = kt * 32 + 16 * (e >> 3) + 8 * lh + (e & 7);
-            s[e] = key < a.Nk ? s[e] * c : -INFINITY;
+            s[e] = 16 * (e >> 3) + (e & 7) < a.Nk - kt * 32 - 8 * lh ? s[e] * c : -INFINITY;      // key < Nk
         }
     };
     auto half_swap_max = [&](float v) {
@@ -770,20 +769,28 @@ int launch_attn_cross(AttnK k, hipStream_t st) {
     return ICD_OK;
 }
 
-template <int KS, int DT, int QT, int OCC = 2, int NST = 2, int MODE = 0>
-int launch_attn(AttnK k, hipStream_t st) {
+template <int KS, int DT, int QT, int OCC, int NST, int MODE, bool CAUSAL>
+int launch_attn_c(AttnK k, hipStream_t st) {
     constexpr int smem = NST * (64 * 2 * KS * 16 + DT * 32 * 128);
     static_assert(smem * OCC <= 160 * 1024, "LDS ring x occupancy exceeds the CU's 160 KiB");
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fused_kernel<KS, DT, QT, OCC, NST, MODE>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fused_kernel<KS, DT, QT, OCC, NST, MODE, CAUSAL>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         attr_set = true;
     }
     k.nqt = (k.Nq + 128 * QT - 1) / (128 * QT);
-    hipLaunchKernelGGL((attn_fused_kernel<KS, DT, QT, OCC, NST, MODE>), dim3(k.nqt * k.B * k.H), dim3(256), smem, st, k);
+    hipLaunchKernelGGL((attn_fused_kernel<KS, DT, QT, OCC, NST, MODE, CAUSAL>), dim3(k.nqt * k.B * k.H), dim3(256), smem, st, k);
     ICD_CHECK_LAUNCH("icd_attention_fused");
     return ICD_OK;
+}
+template <int KS, int DT, int QT, int OCC = 2, int NST = 2, int MODE = 0>
+int launch_attn(AttnK k, hipStream_t st) {
+    // causal instantiations: every one-query-tile-per-wave kernel of MODE 0, and the head-dim-64 MODE 2 kernel (the CLIP text
+    // encoders); icd_attention_fused_ex routes causal calls to those
+    if constexpr (QT == 1 && (MODE == 0 || (MODE == 2 && KS == 4))) { if (k.causal) return launch_attn_c<KS, DT, QT, OCC, NST, MODE, true>(k, st); }
+    if (k.causal) { icd_set_error("icd_attention_fused: internal: no causal instantiation for this tile"); return ICD_ERR_UNSUPPORTED; }
+    return launch_attn_c<KS, DT, QT, OCC, NST, MODE, false>(k, st);
 }
 
 }  // namespace
@@ -837,12 +844,13 @@ extern "C" int icd_attention_fused_ex(const void* q, const void* k, const void* 
     a.vt_bs = vt_batch_stride > 0 ? vt_batch_stride : (long long)H * d * ldvt;
     const bool presc = (flags & ICD_ATTN_Q_PRESCALED) != 0;
     a.scale_log2 = presc ? 1.0f : scale * 1.4426950408889634f;
-    const bool fast = presc && !(flags & ICD_ATTN_TUNE_MODE0);          // MODE 1 / 2 kernels (exponent offset subtracted by the MFMA)
+    // MODE 1 / 2 kernels (exponent offset subtracted by the MFMA); a causal mask has the fast form at head dim 64 only
+    const bool fast = presc && !(flags & ICD_ATTN_TUNE_MODE0) && (!(flags & ICD_ATTN_CAUSAL) || d == 64);
     a.nqt = 0;
     a.causal = (flags & ICD_ATTN_CAUSAL) ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
     // two query tiles per wave when the sequence is long enough to still fill the chip with 256-row workgroups
-    const bool wide = (long long)((Nq + 255) / 256) * B * H >= 512 && Nk >= 256;
+    const bool wide = (long long)((Nq + 255) / 256) * B * H >= 512 && Nk >= 256 && !a.causal;
     // cross-attention with enough query tiles to give every wave >= 2 of them (so the 24 KiB of K / V^T fragments per
     // wave amortise and the next Q tile prefetches): K / V^T fragments live in registers.  Shorter problems (SDXL's
     // 1024-query layers at batch 8) are launch + latency bound either way (~20 us for 42 MB) and stay on the tiled kernel.

@@ -58,6 +58,7 @@ __device__ __forceinline__ void xattn_epilogue(const GemmK& p, f32x16 (&acc)[2][
                                                int l, int m0, int n0) {
     constexpr int KT = 3, KS = 4, ST = 6, DT = 2;
     const int lr = l & 31, lh = l >> 5;
+    const int key_lim = p.x_nk - 8 * lh;
     const int b = m0 / p.rps;                              // the 256 rows of a block lie inside one sample
     const int ncol = n0 + wn * 64;                         // first column of this wave's head
     const half_t* Kb = p.xk + (long long)b * p.x_nk * p.x_ldk + ncol;
@@ -123,8 +124,7 @@ __device__ __forceinline__ void xattn_epilogue(const GemmK& p, f32x16 (&acc)[2][
         for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int key = kt * 32 + 16 * (e >> 3) + 8 * lh + (e & 7);
-                if (key >= p.x_nk) s[kt][e] = -INFINITY;
+                if (kt * 32 + 16 * (e >> 3) + (e & 7) >= key_lim) s[kt][e] = -INFINITY;      // key >= x_nk (see xattn_epilogue_big)
                 mx = fmaxf(mx, s[kt][e]);
             }
         {

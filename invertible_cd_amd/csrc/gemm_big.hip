@@ -37,6 +37,7 @@ __device__ __forceinline__ void xattn_epilogue_big(const GemmK& p, f32x16 (&acc)
                                                    int l, int m0, int n0, const float* ln_lds) {
     constexpr int KT = 3, KS = 4, ST = 6, DT = 2;
     const int lr = l & 31, lh = l >> 5, tid = threadIdx.x;
+    const int key_lim = p.x_nk - 8 * lh;                   // key slot constant c of this lane is masked when c >= key_lim
     const int b = m0 / p.rps;                              // the 256 rows of a block lie inside one sample
     // ---- stage K [96 keys][256 dims] and V^T [256 dims][96 keys] of the block's 4 heads (the caller's barrier freed the stages)
     {
@@ -128,8 +129,9 @@ __device__ __forceinline__ void xattn_epilogue_big(const GemmK& p, f32x16 (&acc)
                 for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
-                        const int key = kt * 32 + 16 * (e >> 3) + 8 * lh + (e & 7);
-                        if (key >= p.x_nk) sc[kt][e] = -INFINITY;
+                        // key = kt*32 + 16*(e>>3) + 8*lh + (e&7) >= x_nk, written as (compile-time constant) >= (one per-lane limit):
+                        // comparing against x_nk itself keeps 48 scalar registers (x_nk - c) alive and the kernel spilt 185 SGPRs
+                        if (kt * 32 + 16 * (e >> 3) + (e & 7) >= key_lim) sc[kt][e] = -INFINITY;
                         mx = fmaxf(mx, sc[kt][e]);
                     }
                 {

@@ -260,6 +260,22 @@ def test_full_size_sd15_properties():
             rows = (t.float() / 4).sum(-1)                                    # accumulated over 4 steps; each row a softmax
             assert float((rows - 1).abs().max()) < 5e-3
     p2p.register_attention_control(model, None)
+    # cfg 3's FORWARD leg at its size: 4-step consistency inversion of 8 latents (w = 0, utils/generation.py:414-451), then the
+    # reverse pass with an AttentionStore from the inverted latents - the pair bench.py times as "edit"
+    solver.latent2image = lambda z, return_type="np": None
+    inv = lambda l: solver.cons_inversion(l, guidance_scale=0.0, w_embed_dim=512, seed=5)[1][0]
+    i1, i2 = inv(lat[:8].contiguous()), inv(lat[:8].contiguous())
+    assert i1.shape == (8, 4, 64, 64) and torch.isfinite(i1).all() and torch.equal(i1, i2) and float(i1.float().std()) > 0.5
+    # the CPU noise of a 2-sample call is the head of the 8-sample draw (same seed, one stream): rows 0..1 alone == rows 0..1 of the batch
+    solver.context = torch.cat([ctx[:2], ctx[B:B + 2]])
+    assert rel_l2(inv(lat[:2].contiguous()), i1[:2]) < 3e-3
+    solver.context = torch.cat([ctx[:8], ctx[B:B + 8]])
+    store = p2p.AttentionStore()
+    p2p.register_attention_control(model, store)
+    out = solver.cons_generation(i1, guidance_scale=19.0, w_embed_dim=512, dynamic_guidance=True, tau1=0.8, tau2=0.8, controller=store)[-1]
+    p2p.register_attention_control(model, None)
+    assert out.shape == (8, 4, 64, 64) and torch.isfinite(out).all() and store.cur_step == 4
+    assert sum(len(v) for v in store.attention_store.values()) == 22
 
 
 def test_boundary_step_round_trip_full_size():

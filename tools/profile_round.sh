@@ -3,7 +3,7 @@
 # roofline.traffic, the -s output of the parity tests.  Run on the GPU box:  bash tools/profile_round.sh r02_x
 # (writes gpurun_out/<tag>/...; copy the summaries you want judged into profiles/).
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 cd "$(dirname "$0")/.."

@@ -38,6 +38,7 @@ elif kind in ("dense", "geglu"):
     res = None if kind == "geglu" else rnd(M, N)
     import ctypes as C
     from invertible_cd_amd import _lib
+    skws = torch.empty(8 * M * N, device=dev, dtype=torch.float32) if M * N <= 8 << 20 else None
     def fn():
         out = torch.empty((M, N // 2 if kind == "geglu" else N), device=dev, dtype=torch.float16)
         d = _lib.GemmDesc()
@@ -45,6 +46,8 @@ elif kind in ("dense", "geglu"):
         d.resid = res.data_ptr() if res is not None else None
         d.M, d.N, d.K, d.Nw, d.lda, d.ldw, d.ldo, d.ldr = M, N, K, N, K, K, out.stride(0), N
         d.mode, d.batch, d.zdiv, d.alpha, d.flags = 0, 1, 1, 1.0, dbg | (1 if kind == "geglu" else 0)
+        if skws is not None and kind == "dense":
+            d.splitk_ws, d.splitk_ws_bytes = skws.data_ptr(), skws.numel() * 4
         _lib.check(_lib.load().icd_gemm(C.byref(d), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
         return out
     flops = 2.0 * M * N * K

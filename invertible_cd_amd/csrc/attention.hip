@@ -84,7 +84,13 @@ struct AttnK {
 // (profiles/r03_attn_pipe.txt): the two query tiles of a wave half a phase apart inside the instruction stream (S^T MFMAs of tile 1
 // between the exponentials of tile 0, P.V of tile 0 between the exponentials of tile 1, pinned with sched_group_barrier and asm
 // anchors against MachineSink) - bit-identical results, 934 us against 919 us: intra-wave MFMA / VALU overlap is not the limit
-// either.  Removed again.
+// either.  Removed again.  So was a ping-pong form (profiles/r03_attn_pingpong.txt): 8-wave blocks whose two waves per SIMD run
+// the per-tile sequence exactly one phase apart (one issues MFMAs only - P.V of tile t, S^T of tile t + 1 - while the other runs
+// the softmax VALU), locked by one s_barrier per phase, 4-stage ring, inline-asm fragment reads; bit-identical, and 15 - 40 % SLOWER.
+// Its knock-outs say why: softmax phases alone 390 us, MFMA phases alone 450 us, loop / DMA / barrier skeleton 263 us, all three
+// together 1058 us - the phases of the two groups do not overlap at all, with or without the barriers: ONE wave issues a 32x32x16
+// MFMA every 64 cycles (28 MFMAs per 1800-cycle phase), the 32-cycle rate needs two waves issuing MFMAs on the SIMD at once, which
+// is exactly what phase-locking forbids.  Two free-running waves per SIMD (this kernel) are the better schedule on this chip.
 // CAUSAL is a template switch (round 3): as a run-time flag its 64 per-element key comparisons kept ~60 scalar registers alive
 // through the whole loop, and the spill code (v_readlane / v_writelane around every use) sat on the non-causal hot path too.
 template <int KS, int DT, int QT, int OCC, int NST, int MODE = 0, bool CAUSAL = false>
@@ -398,7 +404,10 @@ __global__ __launch_bounds__(256, OCC) void attn_fused_kernel(AttnK p) {
     {
         auto step = [&](const bool rag, const int buf, int t) {      // tile t sits in stage `buf`
             wait_landed(nt - 1 - t < PD - 1 ? nt - 1 - t : PD - 1);
-            __syncthreads();                              // tile t visible to all; everybody is done with tile t-1
+            // a bare s_barrier: __syncthreads() is a release fence first (s_waitcnt vmcnt(0) lgkmcnt(0)), which drains the LDS-DMA of
+            // the tiles still in flight and turns every ring into a 2-stage one.  The counted wait above is the whole contract:
+            // this wave's part of tile t has landed, its fragment reads of tile t - 1 were consumed by MFMAs already.
+            __builtin_amdgcn_s_barrier();                 // tile t visible to all; everybody is done with tile t-1
             if (t + PD < nt) issue(t + PD, ((buf + PD) % NST) * STAGE);
             f32x16 s[QT][2];
             qk(s, buf * STAGE, rag, t);

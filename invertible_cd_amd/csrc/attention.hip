@@ -39,6 +39,8 @@ __device__ __forceinline__ int k_swz(int row, int chunk) {
     return chunk;
 }
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
 struct AttnK {
     const half_t* q; const half_t* k; const half_t* vt; half_t* out;
     int B, H, Nq, Nk, d, ldq, ldk, ldvt, ldo;
@@ -93,15 +95,32 @@ struct AttnK {
 // is exactly what phase-locking forbids.  Two free-running waves per SIMD (this kernel) are the better schedule on this chip.
 // CAUSAL is a template switch (round 3): as a run-time flag its 64 per-element key comparisons kept ~60 scalar registers alive
 // through the whole loop, and the spill code (v_readlane / v_writelane around every use) sat on the non-causal hot path too.
-template <int KS, int DT, int QT, int OCC, int NST, int MODE = 0, bool CAUSAL = false>
+//
+// DR > 0 (round 3, head dim 40): O^T += V^T P^T on v_mfma_f32_16x16x32_f16 with DR 16-row tiles of the head dim (48 rows instead of
+// 64: the 32-row tiles pad d = 40 by 60 %, a quarter of all MFMA cycles of the loop).  P leaves the 32x32 S^T accumulators as
+// [32 queries] x [8 consecutive keys] per lane; the 16x16x32 B operand wants [16 queries] x [4 lane groups of 8 keys].  One
+// v_permlane16_swap per packed register pair does that: with X = keys 8lh.. and Y = keys 16 + 8lh.. of a 32-key tile,
+// swap(X, Y) leaves X' = queries 0-15 in all four 16-lane rows (keys 0-7, 16-23, 8-15, 24-31) and Y' = queries 16-31 likewise;
+// the V^T fragment of lane group g is read from key chunk {0, 2, 1, 3}[g], so no data moves but those 16 swaps per tile.
+// Measured (same-box round-robin, profiles/r03_attn_pv16.txt): 4096 x 4096 d = 40, B = 32: 877 -> 855 us (-2.6 %; 804 TFLOP/s
+// algorithmic), bit-for-bit the same softmax.  14 % fewer MFMA cycles buy 2-3 % because the loop is bound by VALU issue, and the swap
+// is not free: tools/valu_rate.hip (profiles/r03_valu_rate.txt) puts v_exp_f32 and v_permlane16_swap at 8 cycles per wave64
+// instruction (v_fma / v_max3 / v_cvt_pk: 4), so a tile step carries ~1060 VALU cycles per wave against 768 of MFMA - and only about
+// half of VALU time hides under MFMAs even in a register-only interleave of the two (same file).
+template <int KS, int DT, int QT, int OCC, int NST, int MODE = 0, bool CAUSAL = false, int DR = 0>
 __global__ __launch_bounds__(256, OCC) void attn_fused_kernel(AttnK p) {
     constexpr int NCH = 2 * KS;                       // 16-B chunks per K row
-    constexpr bool ONES = KS * 16 < DT * 32;          // a free padded V^T row exists: MFMA computes the denominator
+    constexpr bool P16 = DR > 0;
+    constexpr int VROWS = P16 ? DR * 16 : DT * 32;    // rows of the V^T tile (head dim, padded)
+    constexpr bool ONES = P16 || KS * 16 < DT * 32;   // a free padded V^T row exists: MFMA computes the denominator
     constexpr bool LS_MFMA = !ONES && QT == 1;        // otherwise: one extra MFMA per key step (QT = 1) or VALU sums
     constexpr int KT_BYTES = 64 * NCH * 16;           // K tile
-    constexpr int VT_BYTES = DT * 32 * 128;           // V^T tile, 64 keys = 128 B per row
+    constexpr int VT_BYTES = VROWS * 128;             // V^T tile, 64 keys = 128 B per row
     constexpr int STAGE = KT_BYTES + VT_BYTES;
     constexpr int NKG = (2 * KS + 3) / 4;             // K-tile load groups per wave (64 chunks each)
+    constexpr int NGV = VROWS / 8;                    // V^T load groups (64 chunks of 16 B each) per tile
+    constexpr int NVG = (NGV + 3) / 4;                // ... per wave
+    static_assert(!P16 || (QT == 2 && MODE == 1), "16-row P.V tiles: built for the wide d = 40 kernel");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, l = tid & 63, lr = l & 31, lh = l >> 5;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -138,7 +157,7 @@ __global__ __launch_bounds__(256, OCC) void attn_fused_kernel(AttnK p) {
 
     // ---- global -> LDS: per-lane source pointers for full tiles (bumped by one tile per use) -----------------------
     const half_t* kp[NKG]; int kinc[NKG];
-    const half_t* vp[DT]; int vinc[DT];
+    const half_t* vp[NVG]; int vinc[NVG];
 #pragma unroll
     for (int j = 0; j < NKG; ++j) {
         const int g = wv + 4 * j;
@@ -151,7 +170,7 @@ __global__ __launch_bounds__(256, OCC) void attn_fused_kernel(AttnK p) {
         if (MODE == 1 && dd == p.d) kp[j] = icd_e0_page;     // ones column in head-dim slot d
     }
 #pragma unroll
-    for (int j = 0; j < DT; ++j) {
+    for (int j = 0; j < NVG; ++j) {
         const int g = wv + 4 * j;
         const int cid = g * 64 + l;
         const int row = cid >> 3, pc = cid & 7;
@@ -159,7 +178,7 @@ __global__ __launch_bounds__(256, OCC) void attn_fused_kernel(AttnK p) {
         const bool ok = row < p.d;
         vp[j] = ok ? Vb + (long long)row * p.ldvt + lc * 8 : zero;
         vinc[j] = ok ? 64 : 0;
-        if (ONES && row == DT * 32 - 1) { vp[j] = icd_ones_page; vinc[j] = 0; }
+        if (ONES && row == VROWS - 1) { vp[j] = icd_ones_page; vinc[j] = 0; }
     }
     auto issue_fast = [&](int buf_off) {                  // tile is full: no key guards
         unsigned char* sk = smem + buf_off;
@@ -170,9 +189,9 @@ __global__ __launch_bounds__(256, OCC) void attn_fused_kernel(AttnK p) {
             if (g < 2 * KS) { glds16(kp[j], sk + g * 1024); kp[j] += kinc[j]; }
         }
 #pragma unroll
-        for (int j = 0; j < DT; ++j) {
-            glds16(vp[j], sv + (wv + 4 * j) * 1024);
-            vp[j] += vinc[j];
+        for (int j = 0; j < NVG; ++j) {
+            const int g = wv + 4 * j;
+            if (g < NGV) { glds16(vp[j], sv + g * 1024); vp[j] += vinc[j]; }
         }
     };
     auto issue_slow = [&](int t, int buf_off) {           // ragged last tile: rows / chunks past Nk park on the zero page
@@ -192,14 +211,16 @@ __global__ __launch_bounds__(256, OCC) void attn_fused_kernel(AttnK p) {
             }
         }
 #pragma unroll
-        for (int j = 0; j < DT; ++j) {
+        for (int j = 0; j < NVG; ++j) {
             const int g = wv + 4 * j;
-            const int cid = g * 64 + l;
-            const int row = cid >> 3, pc = cid & 7;
-            const int key = kv0 + (pc ^ ((row >> 1) & 7)) * 8;
-            const half_t* src = (row < p.d && key < p.ldvt) ? Vb + (long long)row * p.ldvt + key : zero;
-            if (ONES && row == DT * 32 - 1) src = icd_ones_page;
-            glds16(src, sv + g * 1024);
+            if (g < NGV) {
+                const int cid = g * 64 + l;
+                const int row = cid >> 3, pc = cid & 7;
+                const int key = kv0 + (pc ^ ((row >> 1) & 7)) * 8;
+                const half_t* src = (row < p.d && key < p.ldvt) ? Vb + (long long)row * p.ldvt + key : zero;
+                if (ONES && row == VROWS - 1) src = icd_ones_page;
+                glds16(src, sv + g * 1024);
+            }
         }
     };
 
@@ -212,15 +233,44 @@ __global__ __launch_bounds__(256, OCC) void attn_fused_kernel(AttnK p) {
         const int x = (lr >> 1) & 7;
 #pragma unroll
         for (int st = 0; st < 4; ++st) vbase[st] = KT_BYTES + lr * 128 + (((2 * st + lh) ^ x) << 4);
+        if (P16) {
+            // 16x16x32 A operand: lane = head-dim row l & 15 (+ 16 per tile: an immediate), lane group g = l >> 4 reads the 8 keys
+            // the swapped P operand holds in k-slot g: chunk {0, 2, 1, 3}[g] of the 32-key half kt
+            const int l15 = l & 15, g = l >> 4, pg = ((g & 1) << 1) | (g >> 1), x16 = (l15 >> 1) & 7;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) vbase[kt] = KT_BYTES + l15 * 128 + (((4 * kt + pg) ^ x16) << 4);
+        }
     }
 
-    f32x16 o[QT][DT];
+    constexpr int ODT = P16 ? 1 : DT, OQT = P16 ? 1 : QT, O16Q = P16 ? QT : 1, O16R = P16 ? DR : 1;
+    f32x16 o[OQT][ODT];
+    f32x4 o16[O16Q][2][O16R];       // [query tile][16-query half][16-row head-dim tile]
 #pragma unroll
-    for (int u = 0; u < QT; ++u)
+    for (int u = 0; u < OQT; ++u)
 #pragma unroll
-        for (int i = 0; i < DT; ++i)
+        for (int i = 0; i < ODT; ++i)
 #pragma unroll
             for (int e = 0; e < 16; ++e) o[u][i][e] = 0.f;
+#pragma unroll
+    for (int u = 0; u < O16Q; ++u)
+#pragma unroll
+        for (int qh = 0; qh < 2; ++qh)
+#pragma unroll
+            for (int r = 0; r < O16R; ++r) o16[u][qh][r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // O (and nothing else) shrinks by alpha at a rescale; alpha is per query = per lane of the S^T layout
+    auto scale_o = [&](const int u, const float alpha) {
+        if constexpr (P16) {
+            const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(alpha), __float_as_uint(alpha), false, false);
+            const float a0 = __uint_as_float(sw[0]), a1 = __uint_as_float(sw[1]);      // queries l & 15 / 16 + (l & 15)
+#pragma unroll
+            for (int r = 0; r < O16R; ++r) { o16[u][0][r] *= a0; o16[u][1][r] *= a1; }
+        } else {
+#pragma unroll
+            for (int i = 0; i < ODT; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) o[u][i][e] *= alpha;
+        }
+    };
     // m_run: the row offset (raw score units) currently folded into O and l; l_run only when no ones-row exists
     float m_run[QT], l_run[QT];
 #pragma unroll
@@ -281,13 +331,21 @@ __global__ __launch_bounds__(256, OCC) void attn_fused_kernel(AttnK p) {
     };
     auto softmax_pv = [&](f32x16 (&s)[QT][2], const int BO, const int t) {
         // ---- V^T fragments of the first VPRE key steps: in flight while the softmax runs ----
-        constexpr int VPRE = QT * DT <= 2 ? 4 : QT * DT <= 4 ? 2 : 1;      // at most 8 fragments (32 VGPRs) ahead
-        f16x8 vf[4][DT];
+        constexpr int VPRE = P16 ? 0 : QT * DT <= 2 ? 4 : QT * DT <= 4 ? 2 : 1;      // at most 8 fragments (32 VGPRs) ahead
+        f16x8 vf[4][ODT];
+        f16x8 vf16[2][O16R];                              // P16: all 2 x DR fragments of the tile (24 VGPRs) ahead of the softmax
 #pragma unroll
         for (int st = 0; st < VPRE; ++st)
 #pragma unroll
-            for (int i = 0; i < DT; ++i)
+            for (int i = 0; i < ODT; ++i)
                 vf[st][i] = *reinterpret_cast<const f16x8*>(smem + vbase[st] + (BO + i * 4096));
+        if constexpr (P16) {
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < O16R; ++r)
+                    vf16[kt][r] = *reinterpret_cast<const f16x8*>(smem + vbase[kt] + (BO + r * 2048));
+        }
         __builtin_amdgcn_sched_barrier(0);
         // ---- softmax numerators (lane owns query column lr; element e of s[kt] is key 32kt + 16(e>>3) + 8lh + (e&7)) ----
         f16x8 pf[QT][4];
@@ -323,10 +381,7 @@ __global__ __launch_bounds__(256, OCC) void attn_fused_kernel(AttnK p) {
                     if (t != 0) {                         // (O and l are still zero on the first tile)
                         const float alpha = __builtin_amdgcn_exp2f(-delta);
                         if (!ONES) l_run[u] *= alpha;
-#pragma unroll
-                        for (int i = 0; i < DT; ++i)
-#pragma unroll
-                            for (int e = 0; e < 16; ++e) o[u][i][e] *= alpha;
+                        scale_o(u, alpha);
                     }
 #pragma unroll
                     for (int kt = 0; kt < 2; ++kt)
@@ -338,10 +393,7 @@ __global__ __launch_bounds__(256, OCC) void attn_fused_kernel(AttnK p) {
                 const float alpha = __builtin_amdgcn_exp2f((m_run[u] - m_new) * c);
                 m_run[u] = m_new;
                 if (!ONES) l_run[u] *= alpha;
-#pragma unroll
-                for (int i = 0; i < DT; ++i)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) o[u][i][e] *= alpha;
+                scale_o(u, alpha);
             }
             const float nmc = -m_run[u] * c;
             float rs = 0.f;
@@ -358,17 +410,41 @@ __global__ __launch_bounds__(256, OCC) void attn_fused_kernel(AttnK p) {
         __builtin_amdgcn_sched_barrier(0);
         // ---- O^T[dcol][q] += V^T[dcol][keys] . P^T[keys][q]  (each V^T fragment feeds the QT query tiles; the
         //      fragments of key step st+1 are requested before the MFMAs of step st) ----
+        if constexpr (P16) {
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                f16x8 pa[QT][2];                          // P^T operands of the two 16-query halves, 32 keys
+#pragma unroll
+                for (int u = 0; u < QT; ++u) {
+                    const u32x4 X = __builtin_bit_cast(u32x4, pf[u][2 * kt]), Y = __builtin_bit_cast(u32x4, pf[u][2 * kt + 1]);
+                    u32x4 a, b2;
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        const auto sw = __builtin_amdgcn_permlane16_swap(X[w], Y[w], false, false);
+                        a[w] = sw[0]; b2[w] = sw[1];
+                    }
+                    pa[u][0] = __builtin_bit_cast(f16x8, a); pa[u][1] = __builtin_bit_cast(f16x8, b2);
+                }
+#pragma unroll
+                for (int r = 0; r < O16R; ++r)
+#pragma unroll
+                    for (int u = 0; u < QT; ++u)
+#pragma unroll
+                        for (int qh = 0; qh < 2; ++qh)
+                            o16[u][qh][r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf16[kt][r], pa[u][qh], o16[u][qh][r], 0, 0, 0);
+            }
+        } else {
         f32x16 ls[QT];
 #pragma unroll
         for (int st = 0; st < 4; ++st) {
             if (st + 1 >= VPRE && st + 1 < 4) {
 #pragma unroll
-                for (int i = 0; i < DT; ++i)
+                for (int i = 0; i < ODT; ++i)
                     vf[st + 1][i] = *reinterpret_cast<const f16x8*>(smem + vbase[st + 1] + (BO + i * 4096));
                 __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
-            for (int i = 0; i < DT; ++i)
+            for (int i = 0; i < ODT; ++i)
 #pragma unroll
                 for (int u = 0; u < QT; ++u) o[u][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[st][i], pf[u][st], o[u][i], 0, 0, 0);
             if (LS_MFMA) {
@@ -380,6 +456,7 @@ __global__ __launch_bounds__(256, OCC) void attn_fused_kernel(AttnK p) {
         if (LS_MFMA) {
 #pragma unroll
             for (int u = 0; u < QT; ++u) l_run[u] += ls[u][0];          // every row of ones . P^T is the full 64-key sum
+        }
         }
     };
     using F = std::false_type;
@@ -395,12 +472,15 @@ __global__ __launch_bounds__(256, OCC) void attn_fused_kernel(AttnK p) {
         else issue_slow(tt, buf_off);
     };
     // tile t has landed (this wave's part) when at most the loads of the `keep` later tiles are outstanding
+    constexpr int VREM = NGV % 4;                        // ... and one V^T group less
     auto wait_landed = [&](int keep) {
+        const int fewer = (KREM != 0 && wv >= KREM ? 1 : 0) + (VREM != 0 && wv >= VREM ? 1 : 0);      // wave-uniform
         if (keep <= 0) __builtin_amdgcn_s_waitcnt(0x0f70);
-        else if (KREM != 0 && wv >= KREM) __builtin_amdgcn_s_waitcnt(0x0f70 | (NKG - 1 + DT));
-        else __builtin_amdgcn_s_waitcnt(0x0f70 | (NKG + DT));
+        else if (fewer == 2) __builtin_amdgcn_s_waitcnt(0x0f70 | (NKG + NVG >= 2 ? NKG + NVG - 2 : 0));
+        else if (fewer == 1) __builtin_amdgcn_s_waitcnt(0x0f70 | (NKG + NVG - 1));
+        else __builtin_amdgcn_s_waitcnt(0x0f70 | (NKG + NVG));
     };
-    static_assert(NKG + DT < 16 && NST <= 3, "vmcnt immediate / keep count");
+    static_assert(NKG + NVG < 16 && NST <= 3, "vmcnt immediate / keep count");
     {
         auto step = [&](const bool rag, const int buf, int t) {      // tile t sits in stage `buf`
             wait_landed(nt - 1 - t < PD - 1 ? nt - 1 - t : PD - 1);
@@ -424,11 +504,34 @@ __global__ __launch_bounds__(256, OCC) void attn_fused_kernel(AttnK p) {
         for (int i = 0; t < nfull; ++t, ++i) step(false, i, t);      // < NST leftover full tiles, stages 0, 1, ..
         if (ragged) step(true, nfull % NST, nfull);
     }
+    if constexpr (P16) {
+        // ---- 16x16 accumulators: lane = query (l & 15) of half qh, head-dim rows 16r + 4(l >> 4) .. + 3; the denominator is row
+        //      VROWS - 1 of O^T (the V^T ones-row): element 3 of the last tile in lane group 3 ----
+        const int l15 = l & 15, g = l >> 4;
+#pragma unroll
+        for (int u = 0; u < QT; ++u)
+#pragma unroll
+            for (int qh = 0; qh < 2; ++qh) {
+                const float inv = 1.0f / __shfl(o16[u][qh][O16R - 1][3], 48 + l15);
+                const int qrow = q0 + u * 32 + qh * 16 + l15;
+                if (qrow < p.Nq) {
+                    half_t* op = p.out + ((long long)b * p.Nq + qrow) * p.ldo + h * p.d;
+#pragma unroll
+                    for (int r = 0; r < O16R; ++r) {
+                        const int dc = r * 16 + 4 * g;
+                        if (dc < p.d) {
+                            const f32x4 v = o16[u][qh][r];
+                            *reinterpret_cast<f16x4*>(op + dc) = (f16x4){(half_t)(v[0] * inv), (half_t)(v[1] * inv), (half_t)(v[2] * inv), (half_t)(v[3] * inv)};
+                        }
+                    }
+                }
+            }
+    } else {
     // ---- normalise and store: lane holds 4 consecutive head-dim columns of query row q0 + 32u + lr ----
 #pragma unroll
     for (int u = 0; u < QT; ++u) {
         float l_tot;
-        if (ONES) l_tot = __shfl(o[u][DT - 1][15], lr + 32);   // row DT*32-1 of O^T = sum_k P (the V^T ones-row), upper half-wave
+        if (ONES) l_tot = __shfl(o[u][ODT - 1][15], lr + 32);   // row DT*32-1 of O^T = sum_k P (the V^T ones-row), upper half-wave
         else if (LS_MFMA) l_tot = l_run[u];
         else {
             const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run[u]), __float_as_uint(l_run[u]), false, false);
@@ -439,7 +542,7 @@ __global__ __launch_bounds__(256, OCC) void attn_fused_kernel(AttnK p) {
         if (qrow < p.Nq) {
             half_t* op = p.out + ((long long)b * p.Nq + qrow) * p.ldo + h * p.d;
 #pragma unroll
-            for (int i = 0; i < DT; ++i)
+            for (int i = 0; i < ODT; ++i)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int dc = i * 32 + 8 * g + 4 * lh;
@@ -450,6 +553,7 @@ __global__ __launch_bounds__(256, OCC) void attn_fused_kernel(AttnK p) {
                     }
                 }
         }
+    }
     }
 }
 
@@ -778,28 +882,28 @@ int launch_attn_cross(AttnK k, hipStream_t st) {
     return ICD_OK;
 }
 
-template <int KS, int DT, int QT, int OCC, int NST, int MODE, bool CAUSAL>
+template <int KS, int DT, int QT, int OCC, int NST, int MODE, bool CAUSAL, int DR = 0>
 int launch_attn_c(AttnK k, hipStream_t st) {
-    constexpr int smem = NST * (64 * 2 * KS * 16 + DT * 32 * 128);
+    constexpr int smem = NST * (64 * 2 * KS * 16 + (DR ? DR * 16 : DT * 32) * 128);
     static_assert(smem * OCC <= 160 * 1024, "LDS ring x occupancy exceeds the CU's 160 KiB");
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fused_kernel<KS, DT, QT, OCC, NST, MODE, CAUSAL>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fused_kernel<KS, DT, QT, OCC, NST, MODE, CAUSAL, DR>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         attr_set = true;
     }
     k.nqt = (k.Nq + 128 * QT - 1) / (128 * QT);
-    hipLaunchKernelGGL((attn_fused_kernel<KS, DT, QT, OCC, NST, MODE, CAUSAL>), dim3(k.nqt * k.B * k.H), dim3(256), smem, st, k);
+    hipLaunchKernelGGL((attn_fused_kernel<KS, DT, QT, OCC, NST, MODE, CAUSAL, DR>), dim3(k.nqt * k.B * k.H), dim3(256), smem, st, k);
     ICD_CHECK_LAUNCH("icd_attention_fused");
     return ICD_OK;
 }
-template <int KS, int DT, int QT, int OCC = 2, int NST = 2, int MODE = 0>
+template <int KS, int DT, int QT, int OCC = 2, int NST = 2, int MODE = 0, int DR = 0>
 int launch_attn(AttnK k, hipStream_t st) {
     // causal instantiations: every one-query-tile-per-wave kernel of MODE 0, and the head-dim-64 MODE 2 kernel (the CLIP text
     // encoders); icd_attention_fused_ex routes causal calls to those
     if constexpr (QT == 1 && (MODE == 0 || (MODE == 2 && KS == 4))) { if (k.causal) return launch_attn_c<KS, DT, QT, OCC, NST, MODE, true>(k, st); }
     if (k.causal) { icd_set_error("icd_attention_fused: internal: no causal instantiation for this tile"); return ICD_ERR_UNSUPPORTED; }
-    return launch_attn_c<KS, DT, QT, OCC, NST, MODE, false>(k, st);
+    return launch_attn_c<KS, DT, QT, OCC, NST, MODE, false, DR>(k, st);
 }
 
 }  // namespace
@@ -872,7 +976,8 @@ extern "C" int icd_attention_fused_ex(const void* q, const void* k, const void* 
     if (d <= 32) return launch_attn<2, 1, 1, 2, 2>(a, st);
     // (round 3, same-box round-robin A/B at 4096 x 4096: one query tile per wave, three blocks per CU and a 3-stage ring are all
     //  1 - 12 % slower than the configurations below with MODE 1 / 2; profiles/r03_attn_variants.txt)
-    if (fast && d == 40) return wide ? launch_attn<3, 2, 2, 2, 2, 1>(a, st) : launch_attn<3, 2, 1, 2, 2, 1>(a, st);
+    if (fast && d == 40 && wide) return launch_attn<3, 2, 2, 2, 2, 1, 3>(a, st);       // P.V on 16-row tiles (48 rows, not 64)
+    if (fast && d == 40) return launch_attn<3, 2, 1, 2, 2, 1>(a, st);
     if (fast && d == 64) return launch_attn<4, 2, 1, 2, 2, 2>(a, st);
     if (fast && d == 80) return launch_attn<5, 3, 1, 2, 2, 2>(a, st);
     if (d <= 48) return wide ? launch_attn<3, 2, 2, 2, 2>(a, st) : launch_attn<3, 2, 1, 2, 2>(a, st);

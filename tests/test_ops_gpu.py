@@ -405,8 +405,10 @@ def _attn_ref_exp2(qp, k, v, B, H, Nq, Nk, d, causal=False):
     return (torch.softmax(e, -1) @ vh).permute(0, 2, 1, 3).reshape(B * Nq, H * d)
 
 
-@pytest.mark.parametrize("B,H,Nq,Nk,d", [(1, 8, 1024, 1024, 40),      # MODE 1, two query tiles per wave (wide)
-                                          (2, 8, 256, 256, 40),       # MODE 1, one query tile per wave
+@pytest.mark.parametrize("B,H,Nq,Nk,d", [(4, 8, 4096, 512, 40),       # MODE 1, two query tiles per wave, P.V on 16x16x32 MFMAs
+                                          (4, 8, 4000, 333, 40),      # ... ragged last key tile, ragged query tile
+                                          (1, 8, 1024, 1024, 40),     # MODE 1, one query tile per wave (too few blocks for the wide kernel)
+                                          (2, 8, 256, 256, 40),
                                           (2, 8, 200, 333, 40),       # ... ragged last key tile, ragged query tile
                                           (2, 10, 256, 320, 64),      # MODE 2 (accumulators start from -M)
                                           (1, 5, 100, 77, 64), (1, 8, 256, 256, 80),
@@ -431,7 +433,7 @@ def test_attention_fused_with_a_prescaled_query(B, H, Nq, Nk, d, valu):
     assert rel_l2(out, base) < 2e-3
 
 
-@pytest.mark.parametrize("d,Nq", [(40, 256), (40, 1024), (64, 128), (80, 128)])
+@pytest.mark.parametrize("d,Nq", [(40, 256), (40, 1024), (40, 16384), (64, 128), (80, 128)])      # 16384 queries: the wide d = 40 kernel
 def test_attention_fused_prescaled_rescale_branch_and_extreme_offsets(d, Nq):
     """The lazy rescale of MODE 1 / 2 under stress: (a) a key that dominates a LATE tile (M moves after O has accumulated: O, l,
     this tile's scores and the offset the MFMA carries must all move exactly once), (b) rows whose exponents sit far from zero in

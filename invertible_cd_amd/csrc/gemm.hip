@@ -530,7 +530,10 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_kernel(GemmK p) {
                 }
                 f16x8 o;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = (half_t)(hv[e] * gelu_fast(gv[e]));
+                for (int e = 0; e < 8; e += 2) {
+                    const f32x2 ge = gelu_fast2((f32x2){gv[e], gv[e + 1]});
+                    o[e] = (half_t)(hv[e] * ge[0]); o[e + 1] = (half_t)(hv[e + 1] * ge[1]);
+                }
                 *reinterpret_cast<f16x8*>(out + (long long)m * p.ldo + (n0 >> 1) + oc) = o;
             }
         } else {

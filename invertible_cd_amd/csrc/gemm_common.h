@@ -49,18 +49,28 @@ __device__ __forceinline__ int swz_off(int row, int chunk) {        // byte offs
     return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
 }
 
-// erf with |error| < 1.5e-7 (Abramowitz & Stegun 7.1.26): plenty for an fp16 result, ~4x cheaper than erff
-__device__ __forceinline__ float erf_fast(float x) {
-    const float ax = fabsf(x);
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));     // v_rcp_f32 (1 ulp); an IEEE divide is 10 instructions
-    float p = fmaf(1.061405429f, t, -1.453152027f);
-    p = fmaf(p, t, 1.421413741f);
-    p = fmaf(p, t, -0.284496736f);
-    p = fmaf(p, t, 0.254829592f);
-    const float y = 1.0f - p * t * __builtin_amdgcn_exp2f(-1.4426950408889634f * ax * ax);
-    return copysignf(y, x);
+// gelu(x) = x Phi(x) = max(x, 0) - |x| erfc(|x| / sqrt 2) / 2, with log2(erfc(a / sqrt 2) / 2) as a degree-5 polynomial in
+// a = min(|x|, 6) (weighted minimax fit; beyond 6 the term is < |x| 1e-9): |error| < 6.4e-7 over the fp16 range, evaluated in fp32 -
+// three orders below the fp16 rounding of the result.  ONE transcendental and 9 plain VALU operations per element; the
+// Abramowitz-Stegun erf of rounds 1-2 (v_rcp + v_exp + 15 others) cost 52 issue cycles per element against ~30 (v_exp_f32 and
+// v_rcp_f32 are 8-cycle instructions, tools/valu_rate.hip), and the GEGLU epilogue is VALU-bound: 64 evaluations per lane and tile.
+// Two elements at a time so the Horner steps are v_pk_fma_f32 (hipcc keeps literal-constant FMAs scalar otherwise): per element
+// 2.5 packed + 3 plain VALU issues and one v_exp_f32.
+__device__ __forceinline__ f32x2 gelu_fast2(const f32x2 x) {
+    const float x0 = x[0], x1 = x[1];
+    const f32x2 a = {__builtin_amdgcn_fmed3f(__builtin_fabsf(x0), 0.f, 6.0f), __builtin_amdgcn_fmed3f(__builtin_fabsf(x1), 0.f, 6.0f)};
+    const f32x2 c5 = {-0.00047329376684501767f, -0.00047329376684501767f}, c4 = {0.007084457669407129f, 0.007084457669407129f};
+    const f32x2 c3 = {-0.05182715505361557f, -0.05182715505361557f}, c2 = {-0.4599926769733429f, -0.4599926769733429f};
+    const f32x2 c1 = {-1.1507877111434937f, -1.1507877111434937f}, c0 = {-1.000037670135498f, -1.000037670135498f};
+    f32x2 p = __builtin_elementwise_fma(c5, a, c4);
+    p = __builtin_elementwise_fma(p, a, c3);
+    p = __builtin_elementwise_fma(p, a, c2);
+    p = __builtin_elementwise_fma(p, a, c1);
+    p = __builtin_elementwise_fma(p, a, c0);
+    return (f32x2){__builtin_fmaf(-__builtin_fabsf(x0), __builtin_amdgcn_exp2f(p[0]), __builtin_amdgcn_fmed3f(x0, 0.f, __builtin_inff())),
+                   __builtin_fmaf(-__builtin_fabsf(x1), __builtin_amdgcn_exp2f(p[1]), __builtin_amdgcn_fmed3f(x1, 0.f, __builtin_inff()))};
 }
-__device__ __forceinline__ float gelu_fast(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_fast(float x) { return gelu_fast2((f32x2){x, x})[0]; }
 
 // LayerNorm folded into the GEMM that consumes it (icd_gemm_desc.ln_stats): with W' = W * gamma (folded at load time),
 // LN(x) @ W^T = rstd_m * (x @ W'^T - mean_m * rowsum(W')_n) + (W @ beta)_n - the last term travels in `bias`.

@@ -242,16 +242,21 @@ __device__ __forceinline__ void wave_epilogue(const GemmK& p, f32x16 (&acc)[TM][
                     const float* sp = wst + r * LDW + g_oc;
                     const f32x4 h0 = *reinterpret_cast<const f32x4*>(sp), h1 = *reinterpret_cast<const f32x4*>(sp + 4);
                     const f32x4 g0 = *reinterpret_cast<const f32x4*>(sp + 32), g1 = *reinterpret_cast<const f32x4*>(sp + 36);
-                    const float mu = g_st[pass][0], rstd = g_st[pass][1];
+                    // rstd (x alpha - mu s) + b as x (rstd alpha) + (s (-rstd mu) + b): two packed FMAs per pair of values, and the GELU
+                    // on pairs (gemm_common.h) - this epilogue is VALU-bound (64 outputs per lane and tile, 5 us of a 17.6 us tile at K = 320)
+                    const float ra = g_st[pass][1] * p.alpha, rm = -g_st[pass][1] * g_st[pass][0];
+                    const f32x2 ra2 = {ra, ra}, rm2 = {rm, rm};
+                    auto lin = [&](const f32x4& x, const f32x4& s_, const f32x4& b_, const int e) {
+                        return __builtin_elementwise_fma((f32x2){x[e], x[e + 1]}, ra2,
+                                                         __builtin_elementwise_fma((f32x2){s_[e], s_[e + 1]}, rm2, (f32x2){b_[e], b_[e + 1]}));
+                    };
                     f16x8 o;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float hv0 = rstd * (h0[e] * p.alpha - mu * g_sh0[e]) + g_bh0[e];
-                        const float hv1 = rstd * (h1[e] * p.alpha - mu * g_sh1[e]) + g_bh1[e];
-                        const float gv0 = rstd * (g0[e] * p.alpha - mu * g_sg0[e]) + g_bg0[e];
-                        const float gv1 = rstd * (g1[e] * p.alpha - mu * g_sg1[e]) + g_bg1[e];
-                        o[e] = (half_t)(hv0 * gelu_fast(gv0));
-                        o[4 + e] = (half_t)(hv1 * gelu_fast(gv1));
+                    for (int e = 0; e < 4; e += 2) {
+                        const f32x2 oa = lin(h0, g_sh0, g_bh0, e) * gelu_fast2(lin(g0, g_sg0, g_bg0, e));
+                        const f32x2 ob = lin(h1, g_sh1, g_bh1, e) * gelu_fast2(lin(g1, g_sg1, g_bg1, e));
+                        o[e] = (half_t)oa[0]; o[e + 1] = (half_t)oa[1];
+                        o[4 + e] = (half_t)ob[0]; o[4 + e + 1] = (half_t)ob[1];
                     }
                     if (m < p.M && ncol0 + g_oc < p.N) *reinterpret_cast<f16x8*>(out + (long long)m * p.ldo + (ncol0 >> 1) + g_oc) = o;
                 }

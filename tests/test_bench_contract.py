@@ -1,4 +1,4 @@
-"""The bench line the driver parses, checked on the committed evidence (profiles/r02_bench_default.json is the stdout of
+"""The bench line the driver parses, checked on the committed evidence (profiles/r03_bench_default.json is the stdout of
 `python bench.py` on an MI355X): every key of the contract is there, with the types and relations the contract states."""
 import json
 import os
@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _line():
-    lines = [l for l in open(os.path.join(ROOT, "profiles", "r02_bench_default.json")).read().splitlines() if l.strip()]
+    lines = [l for l in open(os.path.join(ROOT, "profiles", "r03_bench_default.json")).read().splitlines() if l.strip()]
     assert len(lines) == 1, "bench.py prints exactly ONE line on stdout"
     return json.loads(lines[0])
 
@@ -40,6 +40,26 @@ def test_roofline_and_cpu_baseline_objects():
     assert 5 <= c["seconds"] <= 120                          # a bounded sample
     s = d["sdxl"]                                             # BASELINE config 4's per-GPU share rides in the same line
     assert s["value"] > 0 and s["roofline"]["kernel"] == "gemm_dense" and "workload" in s["config"]
+
+
+def test_every_baseline_config_rides_on_the_default_line():
+    """Round 3: configs[2] (edit), configs[3] (sdxl) and configs[4] (sdxl_edit) are objects of the default line, each with its own
+    workload description and the value = batch / time relation; the event-overhead A/B and the per-rank spread are reported."""
+    d = _line()
+    for key, batch in (("edit", 8), ("sdxl", 8), ("sdxl_edit", 16)):
+        o = d[key]
+        assert o["unit"] == "images/sec" and o["value"] > 0 and "workload" in o["config"] and o["config"]["per_gpu_batch"] == batch, key
+        assert abs(o["value"] - o["config"]["global_batch"] / (o["ms_per_step"] * 1e-3)) / o["value"] < 1e-3, key
+        assert o["ms_per_step_per_rank"]["ranks"] == d["n_gpus"] and o["ms_per_step_per_rank"]["min"] <= o["ms_per_step_per_rank"]["max"], key
+    assert d["edit"]["attention_store_tensors_per_pass"] > 0                 # the controller really was in the loop
+    ev = d["event_overhead"]
+    assert ev["ms_per_step_with_events"] > 0 and ev["ms_per_step_without_events"] > 0
+    assert abs(ev["frac"] - (ev["ms_per_step_with_events"] / ev["ms_per_step_without_events"] - 1)) < 2e-3
+    # `value` comes from the pass without events whenever they cost more than 1 %
+    src = ev["ms_per_step_without_events"] if ev["frac"] > 0.01 else ev["ms_per_step_with_events"]
+    assert abs(d["ms_per_step"] - src) / src < 1e-3
+    r = d["ms_per_step_per_rank"]
+    assert r["ranks"] == 1 and r["min"] == r["max"]
 
 
 def test_committed_traffic_summaries_were_measured_on_the_current_kernel_sources():

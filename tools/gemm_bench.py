@@ -35,7 +35,7 @@ if kind == "conv":
 elif kind in ("dense", "geglu"):
     M, N, K = a
     x, w, b = rnd(M, K), rnd(N, K) * K ** -0.5, torch.zeros(N, device=dev)
-    res = None if kind == "geglu" else rnd(M, N)
+    res = None if kind == "geglu" or os.environ.get("PLAIN") else rnd(M, N)      # PLAIN=1: bias only, no residual operand
     import ctypes as C
     from invertible_cd_amd import _lib
     skws = torch.empty(8 * M * N, device=dev, dtype=torch.float32) if M * N <= 8 << 20 else None

@@ -50,8 +50,9 @@ __device__ __forceinline__ int swz_off(int row, int chunk) {        // byte offs
 }
 
 // gelu(x) = x Phi(x) = max(x, 0) - |x| erfc(|x| / sqrt 2) / 2, with log2(erfc(a / sqrt 2) / 2) as a degree-5 polynomial in
-// a = min(|x|, 6) (weighted minimax fit; beyond 6 the term is < |x| 1e-9): |error| < 6.4e-7 over the fp16 range, evaluated in fp32 -
-// three orders below the fp16 rounding of the result.  ONE transcendental and 9 plain VALU operations per element; the
+// a = min(|x|, 6) (weighted minimax fit; beyond 6 the term is < |x| 1e-9): |error| < 6.4e-7 in absolute terms over the fp16 range,
+// evaluated in fp32 (tests/test_gelu_poly.py) - below half an fp16 ulp of any result of magnitude >= 2^-9, a few ulps of the 1e-4
+// values of the negative tail; the Abramowitz-Stegun form it replaces had 2e-7.  ONE transcendental and 9 plain VALU operations per element; the
 // Abramowitz-Stegun erf of rounds 1-2 (v_rcp + v_exp + 15 others) cost 52 issue cycles per element against ~30 (v_exp_f32 and
 // v_rcp_f32 are 8-cycle instructions, tools/valu_rate.hip), and the GEGLU epilogue is VALU-bound: 64 evaluations per lane and tile.
 // Two elements at a time so the Horner steps are v_pk_fma_f32 (hipcc keeps literal-constant FMAs scalar otherwise): per element

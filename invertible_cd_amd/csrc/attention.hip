@@ -618,6 +618,15 @@ __global__ __launch_bounds__(256, 2) void attn_cross_kernel(AttnK p, int tiles_p
             qf[ks] = (qrow < p.Nq && dd < p.d) ? *reinterpret_cast<const f16x8*>(qp + dd) : z8;
         }
     };
+    // Key mask as an additive bias held in 16 VGPRs (round 3): as 48 per-element comparisons against Nk the loop-invariant predicates
+    // lived in scalar-register pairs, 124 of them spilt, and every tile paid ~110 v_readlane_b32 to get them back (as many issue
+    // slots as its 21 MFMAs + 48 exponentials).  The host sends only 64 < Nk <= 96 here, so tiles 0 and 1 need no mask at all.
+    float mb[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        mb[e] = (KT - 1) * 32 + 16 * (e >> 3) + 8 * lh + (e & 7) >= p.Nk ? -INFINITY : 0.f;
+        asm volatile("" : "+v"(mb[e]));                   // opaque: or the select is rematerialised inside the loop, predicates and all
+    }
     f16x8 qa[KS], qb[KS];
     load_q(qa, q_first);
     auto tile = [&](f16x8 (&qf)[KS], f16x8 (&qn)[KS], int q0, bool more) {
@@ -628,15 +637,15 @@ __global__ __launch_bounds__(256, 2) void attn_cross_kernel(AttnK p, int tiles_p
 #pragma unroll
             for (int kt = 0; kt < KT; ++kt)
                 s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kt][ks], qf[ks], ks == 0 ? zero16 : s[kt], 0, 0, 0);
-        // element e of s[kt] is key 32kt + 16(e>>3) + 8lh + (e&7); mask the slots past Nk, exact softmax over the rest
+        // element e of s[kt] is key 32kt + 16(e>>3) + 8lh + (e&7); the slots past Nk (all in the last tile: 64 < Nk <= 96) get -inf
+        // from the per-lane bias `mb`, exact softmax over the rest
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s[KT - 1][e] += mb[e];
         float mx = -INFINITY;
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                if (kt * 32 + 16 * (e >> 3) + (e & 7) >= p.Nk - 8 * lh) s[kt][e] = -INFINITY;      // key >= Nk
-                mx = fmaxf(mx, s[kt][e]);
-            }
+            for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[kt][e]);
         {
             const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
             mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
@@ -967,7 +976,7 @@ extern "C" int icd_attention_fused_ex(const void* q, const void* k, const void* 
     // cross-attention with enough query tiles to give every wave >= 2 of them (so the 24 KiB of K / V^T fragments per
     // wave amortise and the next Q tile prefetches): K / V^T fragments live in registers.  Shorter problems (SDXL's
     // 1024-query layers at batch 8) are launch + latency bound either way (~20 us for 42 MB) and stay on the tiled kernel.
-    if (Nk <= 96 && d <= 64 && !a.causal && (long long)((Nq + 127) / 128) * B * H >= 2048) {
+    if (Nk > 64 && Nk <= 96 && d <= 64 && !a.causal && (long long)((Nq + 127) / 128) * B * H >= 2048) {
         if (d <= 32) return launch_attn_cross<2, 1>(a, st);
         if (d <= 48) return launch_attn_cross<3, 2>(a, st);
         return launch_attn_cross<4, 2>(a, st);
@@ -985,5 +994,7 @@ extern "C" int icd_attention_fused_ex(const void* q, const void* k, const void* 
     if (d <= 80) return launch_attn<5, 3, 1, 2, 2>(a, st);
     if (d <= 96) return launch_attn<6, 3, 1, 2, 2>(a, st);
     if (d <= 128) return launch_attn<8, 4, 1, 2, 2>(a, st);
-    return launch_attn<10, 5, 1, 2, 2>(a, st);
+    // head dim 160 (SD1.5's 16 x 16 / 8 x 8 levels): its accumulators and fragments do not fit the 256 registers of two waves per SIMD
+    // (187 spilt); one wave per SIMD with the whole register file is 10 - 35 % faster (profiles/r03_attn_small_kernels.txt)
+    return launch_attn<10, 5, 1, 1, 2>(a, st);
 }

@@ -120,11 +120,13 @@ __device__ __forceinline__ void xattn_epilogue(const GemmK& p, f32x16 (&acc)[2][
             for (int kt = 0; kt < KT; ++kt)
                 s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kt][ks], qf[ks], ks == 0 ? zero16 : s[kt], 0, 0, 0);
         float mx = -INFINITY;
+        int kl = key_lim;
+        asm volatile("" : "+v"(kl));                        // opaque per query tile: no hoisted predicates (see xattn_epilogue_big)
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                if (kt * 32 + 16 * (e >> 3) + (e & 7) >= key_lim) s[kt][e] = -INFINITY;      // key >= x_nk (see xattn_epilogue_big)
+                if (kt * 32 + 16 * (e >> 3) + (e & 7) >= kl) s[kt][e] = -INFINITY;      // key >= x_nk
                 mx = fmaxf(mx, s[kt][e]);
             }
         {

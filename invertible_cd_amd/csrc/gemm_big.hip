@@ -125,13 +125,16 @@ __device__ __forceinline__ void xattn_epilogue_big(const GemmK& p, f32x16 (&acc)
                     for (int kt = 0; kt < KT; ++kt)
                         sc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kt][ks], qf[i0 + ii][ks], ks == 0 ? zero16 : sc[kt], 0, 0, 0);
                 float mx = -INFINITY;
+                // the limit is made opaque per query tile: as a loop invariant the 48 predicates (constant >= limit) were hoisted into
+                // scalar-register pairs, 181 of them spilt, and every tile read them back with v_readlane_b32 (round 3)
+                int kl = key_lim;
+                asm volatile("" : "+v"(kl));
 #pragma unroll
                 for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
-                        // key = kt*32 + 16*(e>>3) + 8*lh + (e&7) >= x_nk, written as (compile-time constant) >= (one per-lane limit):
-                        // comparing against x_nk itself keeps 48 scalar registers (x_nk - c) alive and the kernel spilt 185 SGPRs
-                        if (kt * 32 + 16 * (e >> 3) + (e & 7) >= key_lim) sc[kt][e] = -INFINITY;
+                        // key = kt*32 + 16*(e>>3) + 8*lh + (e&7) >= x_nk, written as (compile-time constant) >= (one per-lane limit)
+                        if (kt * 32 + 16 * (e >> 3) + (e & 7) >= kl) sc[kt][e] = -INFINITY;
                         mx = fmaxf(mx, sc[kt][e]);
                     }
                 {

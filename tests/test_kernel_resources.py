@@ -40,7 +40,8 @@ def test_gemm_big_tiles_keep_their_register_budget():
         mode, wm, wn, tm, tn, xattn = map(int, m.groups())
         assert v["vgpr_count"] <= 256
         if xattn:
-            assert v["vgpr_spill_count"] == 0, (n, v)                      # (its 181 SGPR spills all sit in the epilogue)
+            # (until round 3 the 48 loop-invariant key-mask predicates of its softmax epilogue sat in scalar registers: 181 spilt)
+            assert v["vgpr_spill_count"] == 0 and v["sgpr_spill_count"] == 0, (n, v)
         elif tm * tn <= 8:
             assert v["vgpr_spill_count"] == 0 and v["sgpr_spill_count"] == 0, (n, v)      # 256 x 256, 192 x 256, 128 x 320
         else:
@@ -59,5 +60,7 @@ def test_flash_attention_kernels_do_not_spill():
             assert v["sgpr_spill_count"] <= 16, (n, v)
     hot = [v for n, v in flash.items() if re.search(r"ILi3ELi2ELi2ELi2ELi2ELi1ELb0E|ILi4ELi2ELi1ELi2ELi2ELi2ELb0E|ILi5ELi3ELi1ELi2ELi2ELi2ELb0E", n)]
     assert len(hot) == 3 and all(v["sgpr_spill_count"] == 0 for v in hot)       # d = 40 (QT 2, 16-row P.V tiles) / 64 / 80 with the MFMA-carried offset
+    cross = {n: v for n, v in ks.items() if "attn_cross_kernel" in n}
+    assert len(cross) == 3 and all(v["sgpr_spill_count"] == 0 and v["vgpr_spill_count"] == 0 for v in cross.values()), cross
     pv16 = [v for n, v in flash.items() if "ILi3ELi2ELi2ELi2ELi2ELi1ELb0ELi3E" in n]
     assert len(pv16) == 1 and pv16[0]["vgpr_count"] <= 224        # two blocks per CU need <= 256; 218 today

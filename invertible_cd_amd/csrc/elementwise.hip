@@ -136,11 +136,16 @@ __global__ __launch_bounds__(256) void conv_out_kernel(const half_t* __restrict_
         const half_t* xp = x + ((long long)b * HW + yy * W + xc) * Cin;
         for (int c = sub; c < nch; c += LPP) {
             f16x8 v = *reinterpret_cast<const f16x8*>(xp + c * 8);
+            // v_dot2_f32_f16 (two fp16 products, fp32 accumulate) instead of 8 converts + 8 FMAs per weight chunk: 220 -> 169 us per
+            // 131072 pixels x 320 channels.  Still latency-bound on its 45 loads per pixel: a form with the weights in registers and 16
+            // pixels per wave was no faster (217 us, serial per pixel); the real fix is an MFMA tile over a halo patch
+            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 #pragma unroll
             for (int o = 0; o < 4; ++o) {
                 f16x8 wv = *reinterpret_cast<const f16x8*>(w + ((long long)(o * 9 + t)) * Cin + c * 8);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) acc[o] += (float)v[e] * (float)wv[e];
+                for (int e = 0; e < 4; ++e)
+                    acc[o] = __builtin_amdgcn_fdot2((h2){v[2 * e], v[2 * e + 1]}, (h2){wv[2 * e], wv[2 * e + 1]}, acc[o], false);
             }
         }
     }

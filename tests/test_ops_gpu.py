@@ -523,6 +523,23 @@ def test_conv_in_out(f32):
     assert rel_l2(eps, F.conv2d(h.float(), wo.float(), bo, padding=1)) < (1e-5 if f32 else TOL)
 
 
+@pytest.mark.parametrize("Cc,H,W", [(512, 9, 13), (640, 8, 8), (128, 20, 12), (320, 64, 64)])
+def test_conv_out_channel_widths(Cc, H, W):
+    """conv_out across channel widths: one wave per pixel striding over the 8-channel chunks (320, 512, 640 channels), lane groups per
+    pixel below (128: the VAE decoder); ragged pixel counts, 3 and 4 output channels, fp16 and fp32 results."""
+    ops = _ops()
+    B = 2
+    h = r16(B, Cc, H, W, seed=44)
+    wo = r16(4, Cc, 3, 3, seed=45, scale=(9 * Cc) ** -0.5)
+    bo = torch.randn(4, generator=torch.Generator().manual_seed(46)) * 0.1
+    ref = F.conv2d(h.float(), wo.float(), bo, padding=1)
+    for dt, tol in ((torch.float32, 1e-5), (torch.float16, TOL)):
+        eps = ops.conv_out(to_nhwc(h).cuda(), B, H, W, ops.pack_conv_weight(wo).cuda(), bo.cuda(), dt)
+        assert rel_l2(eps, ref) < tol, (Cc, dt)
+    eps3 = ops.conv_out(to_nhwc(h).cuda(), B, H, W, ops.pack_conv_weight(wo).cuda(), bo.cuda(), torch.float32, cout=3)
+    assert rel_l2(eps3, ref[:, :3]) < 1e-5
+
+
 def test_x0_step_bit_exact_vs_golden(golden_dir):
     """predicted_origin: fp32 arithmetic in the reference's evaluation order -> bit-exact against the vectors
     captured from utils/generation.py:136-155."""

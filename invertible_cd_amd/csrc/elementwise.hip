@@ -157,6 +157,95 @@ __global__ __launch_bounds__(256) void conv_out_kernel(const half_t* __restrict_
     }
 }
 
+// conv_out on the matrix cores (Cin % 32 == 0): D[16 output channels (4 real)][16 pixels] += W[16 x 32 k] . X[32 k x 16 pixels] with
+// v_mfma_f32_16x16x32_f16.  The B operand is read straight from the NHWC activations - lane (pixel n = l & 15, k-slot g = l >> 4) loads the
+// 8 channels c0 + 8g.. of its pixel's tap (16 B, the zero page outside the image); the A operand comes from an LDS copy of the 4 x 9 x Cin
+// weights (lanes of rows 4..15 read a zero chunk).  A wave owns Q 16-pixel tiles of consecutive pixels that share every weight
+// fragment (Q tiles per wave, UN k-chunks of loads in flight); 9 taps x Cin / 32 MFMAs per tile.  The VALU form above spends 169 us on
+// 131072 pixels x 320 channels (45 loads and 144 v_dot2 per pixel and wave), this one 103 us (28 against 44 us at 32768 pixels).
+template <typename TOut, int Q, int UN>
+__global__ __launch_bounds__(256) void conv_out_mfma_kernel(const half_t* __restrict__ x, int B, int H, int W, int Cin,
+                                                             const half_t* __restrict__ w, const float* __restrict__ bias,
+                                                             int Cout, TOut* __restrict__ eps) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    half_t* wl = reinterpret_cast<half_t*>(smem_raw);          // [9 * ncc][4 rows][32 halves], then one zero chunk of 8 halves
+    const int tid = threadIdx.x, l = tid & 63, n = l & 15, g = l >> 4;
+    const int ncc = Cin >> 5, HW = H * W;
+    const long long total = (long long)B * HW;
+    // stage the weights: w is [4][9][Cin]; 16-B chunks, chunk index = ((t * ncc + cc) * 4 + o) * 4 + j (j: 8-half slice of the 32)
+    for (int i = tid; i < 9 * ncc * 16; i += 256) {
+        const int j = i & 3, o = (i >> 2) & 3, kc = i >> 4, t = kc / ncc, cc = kc - t * ncc;
+        *reinterpret_cast<f16x8*>(wl + (long long)i * 8) = *reinterpret_cast<const f16x8*>(w + ((long long)(o * 9 + t)) * Cin + cc * 32 + j * 8);
+    }
+    if (tid == 0) {
+        f16x8 z;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) z[e] = (half_t)0.f;
+        *reinterpret_cast<f16x8*>(wl + (long long)9 * ncc * 128) = z;
+    }
+    __syncthreads();
+    const long long p0 = ((long long)blockIdx.x * 4 + (tid >> 6)) * (16 * Q);
+    if (p0 >= total) return;
+    const half_t* zero = reinterpret_cast<const half_t*>(icd_zero_page);
+    int pb[Q], py[Q], px[Q];
+    bool live[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        const long long pix = p0 + q * 16 + n;
+        live[q] = pix < total;
+        const long long pc = live[q] ? pix : 0;
+        pb[q] = (int)(pc / HW);
+        const int rem = (int)(pc - (long long)pb[q] * HW);
+        py[q] = rem / W; px[q] = rem - py[q] * W;
+    }
+    f32x4 acc[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // A-fragment address of this lane inside one k-chunk: rows >= 4 read the zero chunk
+    const int a_off = n < 4 ? (n * 4 + g) * 8 : -1;
+    const half_t* a_zero = wl + (long long)9 * ncc * 128;
+    for (int t = 0; t < 9; ++t) {
+        const int dy = t / 3 - 1, dx = t % 3 - 1;
+        const half_t* src[Q];
+        int inc[Q];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const int yy = py[q] + dy, xc = px[q] + dx;
+            const bool ok = live[q] && (unsigned)yy < (unsigned)H && (unsigned)xc < (unsigned)W;
+            src[q] = ok ? x + ((long long)pb[q] * HW + yy * W + xc) * Cin + g * 8 : zero;
+            inc[q] = ok ? 32 : 0;
+        }
+        const half_t* ap = a_off >= 0 ? wl + (long long)t * ncc * 128 + a_off : a_zero;
+        const int a_inc = a_off >= 0 ? 128 : 0;
+        for (int c0 = 0; c0 < ncc; c0 += UN) {                 // UN k-chunks = UN * Q activation loads in flight per lane
+            f16x8 a[UN], bq[UN][Q];
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const bool on = c0 + u < ncc;
+                a[u] = *reinterpret_cast<const f16x8*>(on ? ap + u * a_inc : a_zero);
+#pragma unroll
+                for (int q = 0; q < Q; ++q) bq[u][q] = *reinterpret_cast<const f16x8*>(on ? src[q] + u * inc[q] : zero);
+            }
+            ap += UN * a_inc;
+#pragma unroll
+            for (int q = 0; q < Q; ++q) src[q] += UN * inc[q];
+#pragma unroll
+            for (int u = 0; u < UN; ++u)
+#pragma unroll
+                for (int q = 0; q < Q; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[u], bq[u][q], acc[q], 0, 0, 0);
+        }
+    }
+    if (g == 0) {                                               // rows 0..3 of D = the output channels of pixel n
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            if (!live[q]) continue;
+#pragma unroll
+            for (int o = 0; o < 4; ++o)
+                if (o < Cout) eps[((long long)(pb[q] * Cout + o) * H + py[q]) * W + px[q]] = (TOut)(acc[q][o] + (bias ? bias[o] : 0.f));
+        }
+    }
+}
+
 // predicted_origin, eps-prediction.  Evaluation order and roundings mirror the reference's fp32 torch expression
 // (no FMA contraction): x0 = (x - sigma_t*eps) / alpha_t ; out = alpha_s*x0 + sigma_s*eps.
 template <typename TX, typename TE, typename TO>
@@ -268,6 +357,19 @@ extern "C" int icd_conv_out_n(const void* x, int32_t B, int32_t H, int32_t W, in
     const long long pixels = (long long)B * H * W;
     hipStream_t st = (hipStream_t)stream;
     const int nch = Cin / 8;
+    if (Cin % 32 == 0 && Cin >= 256 && (size_t)Cin * 72 + 16 <= 64 * 1024) {       // matrix-core form (narrower inputs: the VALU form is faster)
+        const size_t smem = (size_t)Cin * 72 + 16;                     // 9 * Cin / 32 k-chunks x 4 rows x 64 B, + the zero chunk
+        // two 16-pixel tiles per wave, five k-chunks (ten 16-B activation loads per lane) in flight: of the forms tried the best at 32768
+        // and 131072 pixels (profiles/r03_conv_out.txt).  All of them stop at ~104 us for 131072 pixels x 320 channels: the nine taps
+        // re-read every activation row through the L2 (755 MB); a halo patch in LDS would be the next step
+        const dim3 grid((unsigned)((pixels + 127) / 128));
+        if (out_is_f32) hipLaunchKernelGGL((conv_out_mfma_kernel<float, 2, 5>), grid, dim3(256), smem, st, (const half_t*)x, B, H, W, Cin,
+                                           (const half_t*)w, bias, Cout, (float*)out_nchw);
+        else hipLaunchKernelGGL((conv_out_mfma_kernel<half_t, 2, 5>), grid, dim3(256), smem, st, (const half_t*)x, B, H, W, Cin,
+                                (const half_t*)w, bias, Cout, (half_t*)out_nchw);
+        ICD_CHECK_LAUNCH("icd_conv_out(mfma)");
+        return ICD_OK;
+    }
 #define CO_LAUNCH(T, LPP)                                                                                              \
     hipLaunchKernelGGL((conv_out_kernel<T, LPP>), dim3((unsigned)((pixels + 4 * (64 / LPP) - 1) / (4 * (64 / LPP)))),  \
                        dim3(256), 0, st, (const half_t*)x, B, H, W, Cin, (const half_t*)w, bias, Cout, (T*)out_nchw)

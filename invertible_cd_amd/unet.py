@@ -283,6 +283,12 @@ class UNet2DConditionModel:
                 return -1
         return _lib.ATTN_HOOK(hook), adapter.probs_mode
 
+    def reset_context_cache(self):
+        """Forget the cached context K / V projections: the next forward recomputes them whatever tensor it is handed.  (The cache
+        keys on the context tensor's identity and version; a caller that reuses ONE tensor object for a new batch of prompts without
+        an in-place write - or a benchmark that wants every batch to pay for its projections - calls this at the batch boundary.)"""
+        self._kv = None
+
     @torch.no_grad()
     def __call__(self, sample, timestep, encoder_hidden_states=None, class_labels=None, timestep_cond=None,
                  attention_mask=None, cross_attention_kwargs=None, added_cond_kwargs=None, return_dict=True, **kwargs):

@@ -160,6 +160,12 @@ def load():
         raise RuntimeError(
             f"{LIB_PATH} is missing: the MI355X HIP extension is not built.  Run `python -m invertible_cd_amd.build` "
             "(or __graft_entry__.build()).  There is no CPU fallback for the product path.")
+    # torch FIRST.  The torch wheel bundles its own HIP runtime (torch/lib/libamdhip64.so, SONAME libamdhip64.so.7 - the SONAME this
+    # library needs from /opt/rocm): whichever copy is loaded first serves both.  Loaded the other way round, torch later brings in the
+    # rest of its bundled ROCm stack beside /opt/rocm's runtime and every launch of this library fails with "no ROCm-capable device is
+    # detected" (seen with __graft_entry__.build() followed by smoke() in one process).  Every caller in this package hands torch tensors
+    # to the library anyway.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)

@@ -154,6 +154,9 @@ struct Exec {
 
     const void* T(const std::string& name, int dtype, long long numel) {
         auto it = u->tensors.find(name);
+        // A forward that has already failed keeps its FIRST error: the walk goes on past a failed launch with stale channel counts, and
+        // the tensor it then asks for ("mid_block.resnets.0.conv_shortcut.bias is not bound") used to replace the real message.
+        if (!missing && status != ICD_OK) return nullptr;
         if (it == u->tensors.end()) {
             if (missing) { missing->push_back(name); return (const void*)0x1000; }
             icd_set_error("icd_unet_forward: tensor '%s' is not bound", name.c_str());

@@ -121,10 +121,19 @@ typedef struct {
     int32_t tune_xattn_tile;  /* host tile of the fused query-projection + cross-attention launch: 0 planner, 2 = 128 x 128, 4 = 256 x 128 */
     void* debug_timeline;     /* device buffer of 8 x uint64 per block: every block of this launch stamps s_memrealtime (100 MHz) at */
                               /* start, first k-tile landed, main loop done, epilogue done (+ s_memtime ticks of the main loop)     */
-    /* Second output for the fp32 residual stream (icd_unet option ICD_UNET_OPT_RESIDUAL_F32): the SAME values as `out` before the
+    /* Second output for the fp32 twin of the residual stream (icd_unet option ICD_UNET_OPT_RESIDUAL_MODE = ICD_RESIDUAL_F32): the SAME values as `out` before the
      * fp16 rounding, fp32 [M, ldo] (row stride ldo).  With an fp32 `resid` (ICD_GEMM_RESID_F32) a chain h <- h + f(h) accumulates
      * in fp32 while every consumer still reads the fp16 copy.  NULL: off.  fp16 `out` only, no GEGLU / transposed / batched. */
     float* out_f32;
+    /* Error carry of the residual stream (icd_unet option ICD_UNET_OPT_RESIDUAL_MODE = ICD_RESIDUAL_CARRY, the default): a tensor of a chain
+     * h <- h + f(h) lives as the fp16 value every consumer reads PLUS one byte per element holding what its rounding lost,
+     *     carry = bf8_e5m2((v - fp16(v)) * 2^14)          value = fp16 + carry * 2^-14,
+     * i.e. about four more mantissa bits on the stream (the rounding of the stream per add is the dominant error term of an
+     * fp16-storage UNet) for 1 + 1 bytes per element and add instead of the 2 + 4 of an fp32 twin.
+     * resid_carry: uint8 [M, ldr] beside an fp16 `resid`; out_carry: uint8 [M, ldo] beside the fp16 `out` (same leading dimensions, in
+     * elements).  Either may be NULL.  Plain fp16 output only (no GEGLU / transposed / fp32 / batched / fused cross-attention). */
+    const void* resid_carry;
+    void* out_carry;
 } icd_gemm_desc;
 
 int icd_gemm(const icd_gemm_desc* d, void* stream);
@@ -327,13 +336,22 @@ int32_t icd_unet_num_attention_layers(const icd_unet* u);
  *       2 = 128 x 128, 4 = 256 x 128.
  *   ICD_UNET_OPT_ATTN_VALU_SCALE  A/B: 1 = the flash attention kernels apply the softmax offset with one FMA per score on the VALU
  *       (ICD_ATTN_TUNE_MODE0), 0 (default) = the MFMA subtracts it (head dims 40 / 64 / 80).  Same arithmetic up to fp32 rounding.
- *   ICD_UNET_OPT_RESIDUAL_F32   1 = fp32 residual stream: every chain x <- x + f(x) of the UNet (ResnetBlock2D conv2 + input /
- *       shortcut, the three branch adds of a BasicTransformerBlock, Transformer2DModel proj_out + input) accumulates in fp32 and the
- *       fp16 copy the next operator reads is rounded from that sum (icd_gemm_desc.out_f32 + ICD_GEMM_RESID_F32).  Removes the dominant
- *       error term of fp16 storage: eps vs an fp32 evaluation 1.1e-3 -> 0.8e-3 rel-L2.  0 (default): fp16 residual stream.  What
- *       load_models(dtype='fp32') (the reference's default, utils/loading.py:34,38) selects.  Set before sizing the workspace.
+ *   ICD_UNET_OPT_RESIDUAL_MODE  precision of the residual stream.  Every chain x <- x + f(x) of the UNet (ResnetBlock2D conv2 + input /
+ *       shortcut, the three branch adds of a BasicTransformerBlock, Transformer2DModel proj_out + input) rounds the whole stream to
+ *       fp16 once per add, 100 - 300 adds deep - the dominant error term of fp16 storage (eps vs an fp32 evaluation 1.1e-3 rel-L2).
+ *         ICD_RESIDUAL_FP16  (0)  plain fp16 stream (rounds 1 - 3's default);
+ *         ICD_RESIDUAL_F32   (1)  fp32 twin: the chain accumulates in fp32 beside the fp16 copy the next operator reads
+ *                                 (icd_gemm_desc.out_f32 + ICD_GEMM_RESID_F32): 0.7e-3, 6 more bytes per element and add;
+ *         ICD_RESIDUAL_CARRY (2, default)  error carry: one bf8 byte per element keeps what the rounding lost
+ *                                 (icd_gemm_desc.resid_carry / out_carry): the same 0.7e-3 for 2 more bytes per element and add.
+ *       load_models(dtype='fp32') (the reference's default, utils/loading.py:34,38) adds fp32 latents / eps at the boundary to it.
+ *       Set before sizing the workspace.
  * Returns ICD_ERR_INVALID_ARG for an unknown option or value. */
-#define ICD_UNET_OPT_RESIDUAL_F32    5
+#define ICD_UNET_OPT_RESIDUAL_MODE   5
+#define ICD_UNET_OPT_RESIDUAL_F32    5   /* round-3 name of the same option */
+#define ICD_RESIDUAL_FP16  0
+#define ICD_RESIDUAL_F32   1
+#define ICD_RESIDUAL_CARRY 2
 #define ICD_UNET_OPT_XATTN_FUSION    1
 #define ICD_UNET_OPT_LN_INLINE_STATS 2
 #define ICD_UNET_OPT_XATTN_TILE      3

@@ -19,7 +19,9 @@ ICD_UNET_OPT_XATTN_FUSION = 1
 ICD_UNET_OPT_LN_INLINE_STATS = 2
 ICD_UNET_OPT_XATTN_TILE = 3
 ICD_UNET_OPT_ATTN_VALU_SCALE = 4
-ICD_UNET_OPT_RESIDUAL_F32 = 5
+ICD_UNET_OPT_RESIDUAL_MODE = 5
+ICD_UNET_OPT_RESIDUAL_F32 = 5           # round-3 name
+ICD_RESIDUAL_FP16, ICD_RESIDUAL_F32, ICD_RESIDUAL_CARRY = 0, 1, 2
 ICD_ATTN_CAUSAL = 1
 ICD_ATTN_Q_PRESCALED = 2
 ICD_ATTN_TUNE_MODE0 = 4
@@ -44,6 +46,7 @@ class GemmDesc(C.Structure):
         ("xattn_ldvt", C.c_int32), ("xattn_vt_bs", C.c_int64), ("xattn_scale", C.c_float),
         ("ln_eps", C.c_float),
         ("tune_group_m", C.c_int32), ("tune_xattn_tile", C.c_int32), ("debug_timeline", C.c_void_p), ("out_f32", C.c_void_p),
+        ("resid_carry", C.c_void_p), ("out_carry", C.c_void_p),
     ]
 
 

@@ -12,6 +12,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 // error plumbing (host)
 void icd_set_error(const char* fmt, ...);

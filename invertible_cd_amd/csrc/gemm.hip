@@ -571,6 +571,7 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_kernel(GemmK p) {
                     f16x8 rs = *reinterpret_cast<const f16x8*>(p.resid + (long long)m * p.ldr + n);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] += (float)rs[e];
+                    if (p.resid_c) carry_add8(v, p.resid_c + (long long)m * p.ldr + n);
                     }
                 }
                 if (p.out32) {
@@ -587,6 +588,7 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_kernel(GemmK p) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) o[e] = (half_t)v[e];
                     *reinterpret_cast<f16x8*>(reinterpret_cast<half_t*>(p.out) + o_off + (long long)m * p.ldo + n) = o;
+                    if (p.out_c) *reinterpret_cast<u32x2*>(p.out_c + (long long)m * p.ldo + n) = carry_of8(v, o);
                 }
             }
         }
@@ -633,6 +635,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmK p) {
         f16x8 rs = *reinterpret_cast<const f16x8*>(p.resid + (long long)m * p.ldr + n);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] += (float)rs[e];
+        if (p.resid_c) carry_add8(v, p.resid_c + (long long)m * p.ldr + n);
         }
     }
     if (p.out32) {
@@ -649,6 +652,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmK p) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = (half_t)v[e];
         *reinterpret_cast<f16x8*>(reinterpret_cast<half_t*>(p.out) + (long long)m * p.ldo + n) = o;
+        if (p.out_c) *reinterpret_cast<u32x2*>(p.out_c + (long long)m * p.ldo + n) = carry_of8(v, o);
     }
 }
 
@@ -747,6 +751,13 @@ static int gemm_run(const icd_gemm_desc* d, void* stream, icd_gemm_plan_info* in
     k.out32 = d->out_f32;
     ICD_CHECK_ARG(!(d->out_f32 && (trans || geglu || (d->flags & ICD_GEMM_OUT_F32) || d->batch > 1 || d->xattn_k)),
                   "icd_gemm: out_f32 (second fp32 output) goes with a plain fp16 output only");
+    k.resid_c = (const unsigned char*)d->resid_carry; k.out_c = (unsigned char*)d->out_carry;
+    ICD_CHECK_ARG(!(d->out_carry && (trans || geglu || (d->flags & ICD_GEMM_OUT_F32) || d->batch > 1 || d->xattn_k)),
+                  "icd_gemm: out_carry (error carry of the output) goes with a plain fp16 output only");
+    ICD_CHECK_ARG(!(d->resid_carry && (!d->resid || (d->flags & ICD_GEMM_RESID_F32) || d->batch > 1)),
+                  "icd_gemm: resid_carry needs an fp16 resid (unbatched)");
+    ICD_CHECK_ARG(!((d->out_carry && d->ldo % 8 != 0) || (d->resid_carry && d->ldr % 8 != 0)),
+                  "icd_gemm: carried tensors need leading dimensions that are multiples of 8");
     const int g_group_m = d->tune_group_m, g_xattn_tile = d->tune_xattn_tile;
     k.gm = g_group_m > 0 ? g_group_m : 1;        // the planner widens it below for launches with many n-tiles
     k.ln_stats = d->ln_stats; k.ln_s = d->ln_colsum;

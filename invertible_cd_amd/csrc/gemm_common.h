@@ -27,6 +27,8 @@ struct GemmK {
     const half_t* xk; const half_t* xvt;
     int x_nk, x_ldk, x_ldvt; long long x_vt_bs; float x_scale_log2;
     float* out32;                                // second output (icd_gemm_desc.out_f32): the values before the fp16 rounding, or null
+    const unsigned char* resid_c;                // error carry of `resid` (icd_gemm_desc.resid_carry): bf8 e5m2 of what fp16 lost, x 2^14
+    unsigned char* out_c;                        // error carry of `out` (icd_gemm_desc.out_carry), or null
     unsigned long long* timeline;                // diagnostics (icd_debug_gemm_timeline): 4 s_memrealtime stamps per block, or null
 };
 
@@ -86,6 +88,35 @@ __device__ __forceinline__ void ln_correct8(float (&v)[8], const float* ln_stats
     }
 }
 
+
+// Error carry of the residual stream (icd_gemm_desc.resid_carry / out_carry): value = fp16 + 2^-14 * bf8_e5m2.  |v - fp16(v)| is at most
+// half an ulp of the fp16 value, so with the fixed scale 2^14 the carry of any |v| < 2^13 sits inside the bf8 range (e5m2: 32 binades)
+// without a per-element exponent, and v_cvt_pk_bf8_f32 / v_cvt_pk_f32_bf8 convert two elements per instruction: 3.5 + 1.5 VALU
+// issues per element for the write and the read side.  What is left of the rounding error is <= 2^-3 of it (2 mantissa bits,
+// round to nearest even): the stream behaves like a 14..15-bit-mantissa tensor at 3 bytes per element.
+constexpr float CARRY_SCALE = 16384.f, CARRY_INV = 1.f / 16384.f;
+// v[0..8) += the 8 carries packed in w (element e in byte e)
+__device__ __forceinline__ void carry_add8(float (&v)[8], const u32x2 w) {
+    const f32x2 c0 = __builtin_amdgcn_cvt_pk_f32_bf8(w[0], false), c1 = __builtin_amdgcn_cvt_pk_f32_bf8(w[0], true);
+    const f32x2 c2 = __builtin_amdgcn_cvt_pk_f32_bf8(w[1], false), c3 = __builtin_amdgcn_cvt_pk_f32_bf8(w[1], true);
+    v[0] = __builtin_fmaf(c0[0], CARRY_INV, v[0]); v[1] = __builtin_fmaf(c0[1], CARRY_INV, v[1]);
+    v[2] = __builtin_fmaf(c1[0], CARRY_INV, v[2]); v[3] = __builtin_fmaf(c1[1], CARRY_INV, v[3]);
+    v[4] = __builtin_fmaf(c2[0], CARRY_INV, v[4]); v[5] = __builtin_fmaf(c2[1], CARRY_INV, v[5]);
+    v[6] = __builtin_fmaf(c3[0], CARRY_INV, v[6]); v[7] = __builtin_fmaf(c3[1], CARRY_INV, v[7]);
+}
+// ... of the 8 consecutive elements at c (8-byte aligned)
+__device__ __forceinline__ void carry_add8(float (&v)[8], const unsigned char* c) { carry_add8(v, *reinterpret_cast<const u32x2*>(c)); }
+// the carry bytes of 8 values v whose fp16 roundings are o
+__device__ __forceinline__ u32x2 carry_of8(const float (&v)[8], const f16x8& o) {
+    float d[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) d[e] = (v[e] - (float)o[e]) * CARRY_SCALE;
+    unsigned w0 = __builtin_amdgcn_cvt_pk_bf8_f32(d[0], d[1], 0, false);
+    w0 = __builtin_amdgcn_cvt_pk_bf8_f32(d[2], d[3], w0, true);
+    unsigned w1 = __builtin_amdgcn_cvt_pk_bf8_f32(d[4], d[5], 0, false);
+    w1 = __builtin_amdgcn_cvt_pk_bf8_f32(d[6], d[7], w1, true);
+    return (u32x2){w0, w1};
+}
 
 // gemm_big.hip tile configurations and their measured cost (tools/gemm_bench.py with forced configurations, one box):
 // one launch costs rounds x (k-tiles x tk + fixed) where a block owns its CU (1 block / CU), tk = one k-tile of one

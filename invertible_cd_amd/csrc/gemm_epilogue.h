@@ -20,10 +20,11 @@ static __device__ __attribute__((aligned(16))) const float icd_epi_ln_id[2] = {0
 // operands reading the neutral page): in the specialised variants an absent operand costs neither a load nor a register
 // (reading a neutral page instead was measured at +7..20 % on plain GEMMs - a 16-B residual read per lane is as much L1 traffic
 // as the output store).  Out-of-range lanes read the neutral page instead of branching around their loads.
-// R32: the residual is fp32 (ICD_GEMM_RESID_F32; two 16-B loads per pass instead of one); O32: the values are also stored before
-// the fp16 rounding (p.out32) - the two variants the executor's fp32 residual stream needs (plain + O32, R32 + O32).  Both are
-// compile-time so that the default variants carry neither the registers nor the branch.
-template <int JN, bool R, bool T, bool L, bool PF_ROWBIAS, int PF_PASSES, bool R32 = false, bool O32 = false>
+// RC: the residual comes with an error carry (p.resid_c: one 8-B load per pass beside the 16-B one); OC: the carry of the output is
+// stored beside it (p.out_c) - the two variants the executor's carried residual stream needs (start of a chain: OC; an add: R + RC
+// + OC).  Both are compile-time so that the default variants carry neither the registers nor the branch.  (Round 3's fp32 twin of the
+// stream - R32 / O32 variants, 4 + 6 more bytes per element and add - is served by the general path below since round 4.)
+template <int JN, bool R, bool T, bool L, bool PF_ROWBIAS, int PF_PASSES, bool RC = false, bool OC = false>
 __device__ __forceinline__ void fast_patch(const GemmK& p, const f32x16& acc0, const f32x16& acc1, float* wst, int l, int mrow0,
                                            int ncol0, const float* ln_lds, int ln_m0) {
     constexpr int LDW = 68;
@@ -33,9 +34,9 @@ __device__ __forceinline__ void fast_patch(const GemmK& p, const f32x16& acc0, c
     const bool ncol_ok = n < p.N;
     const half_t* zp = reinterpret_cast<const half_t*>(icd_epi_zero);
     f32x4 b0, b1, s0, s1;
-    f16x8 rs[R32 ? 1 : NPASS], rb[NPASS];
-    f32x4 rsa[R32 ? NPASS : 1], rsb[R32 ? NPASS : 1];
-    const float* zf = icd_epi_zero;
+    f16x8 rs[NPASS], rb[NPASS];
+    u32x2 rc[RC ? NPASS : 1];
+    const unsigned char* zc = reinterpret_cast<const unsigned char*>(icd_epi_zero);      // (a zero byte is a zero carry)
     f32x2 st[NPASS];
     {
         const float* bp = (p.bias && ncol_ok) ? p.bias + n : icd_epi_zero;       // 2 x 16 B per patch: not worth a variant
@@ -50,11 +51,8 @@ __device__ __forceinline__ void fast_patch(const GemmK& p, const f32x16& acc0, c
         if (pass >= PF_PASSES) break;
         const int m = mrow0 + ((pass * 64 + l) >> CHS);
         const bool okp = m < p.M && ncol_ok;
-        if (R && !R32) rs[pass] = *reinterpret_cast<const f16x8*>((p.resid && okp) ? p.resid + (long long)m * p.ldr + n : zp);
-        if (R && R32) {
-            const float* rp = (p.resid && okp) ? reinterpret_cast<const float*>(p.resid) + (long long)m * p.ldr + n : zf;
-            rsa[pass] = *reinterpret_cast<const f32x4*>(rp); rsb[pass] = *reinterpret_cast<const f32x4*>(rp + 4);
-        }
+        if (R) rs[pass] = *reinterpret_cast<const f16x8*>((p.resid && okp) ? p.resid + (long long)m * p.ldr + n : zp);
+        if (RC) rc[pass] = *reinterpret_cast<const u32x2*>((p.resid_c && okp) ? p.resid_c + (long long)m * p.ldr + n : zc);
         if (T && PF_ROWBIAS) rb[pass] = *reinterpret_cast<const f16x8*>((p.rowbias && okp) ? p.rowbias + (long long)(m / p.rps) * p.ld_rowbias + n : zp);
         if (L) {                                 // row statistics: from the kernel's own LDS table when it computed them (ln_lds)
             if (ln_lds) st[pass] = *reinterpret_cast<const f32x2*>(ln_lds + 2 * (m - ln_m0));
@@ -77,51 +75,46 @@ __device__ __forceinline__ void fast_patch(const GemmK& p, const f32x16& acc0, c
         const bool okl = m < p.M && ncol_ok;
         if (T && !PF_ROWBIAS) rb[pass] = *reinterpret_cast<const f16x8*>((p.rowbias && okl) ? p.rowbias + (long long)(m / p.rps) * p.ld_rowbias + n : zp);
         if (pass >= PF_PASSES) {
-            if (R && !R32) rs[pass] = *reinterpret_cast<const f16x8*>((p.resid && okl) ? p.resid + (long long)m * p.ldr + n : zp);
-            if (R && R32) {
-                const float* rp = (p.resid && okl) ? reinterpret_cast<const float*>(p.resid) + (long long)m * p.ldr + n : zf;
-                rsa[pass] = *reinterpret_cast<const f32x4*>(rp); rsb[pass] = *reinterpret_cast<const f32x4*>(rp + 4);
-            }
+            if (R) rs[pass] = *reinterpret_cast<const f16x8*>((p.resid && okl) ? p.resid + (long long)m * p.ldr + n : zp);
+            if (RC) rc[pass] = *reinterpret_cast<const u32x2*>((p.resid_c && okl) ? p.resid_c + (long long)m * p.ldr + n : zc);
             if (L) {
                 if (ln_lds) st[pass] = *reinterpret_cast<const f32x2*>(ln_lds + 2 * (m - ln_m0));
                 else st[pass] = *reinterpret_cast<const f32x2*>((p.ln_stats && okl) ? p.ln_stats + 2 * (long long)m : icd_epi_ln_id);
             }
         }
         f16x8 o;
-        f32x4 w0, w1;
+        float a[8];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             float a0 = v0[e] * p.alpha, a1 = v1[e] * p.alpha;
             if (L) { a0 = st[pass][1] * (a0 - st[pass][0] * s0[e]); a1 = st[pass][1] * (a1 - st[pass][0] * s1[e]); }
             a0 += b0[e]; a1 += b1[e];
             if (T) { a0 += (float)rb[pass][e]; a1 += (float)rb[pass][4 + e]; }
-            if (R && !R32) { a0 += (float)rs[pass][e]; a1 += (float)rs[pass][4 + e]; }
-            if (R && R32) { a0 += rsa[pass][e]; a1 += rsb[pass][e]; }
-            o[e] = (half_t)a0; o[4 + e] = (half_t)a1;
-            if (O32) { w0[e] = a0; w1[e] = a1; }
+            if (R) { a0 += (float)rs[pass][e]; a1 += (float)rs[pass][4 + e]; }
+            a[e] = a0; a[4 + e] = a1;
         }
+        if (RC) carry_add8(a, rc[pass]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (half_t)a[e];
         if (okl) *reinterpret_cast<f16x8*>(outp + (long long)m * p.ldo + n) = o;
-        if (O32 && okl) {
-            float* o32 = p.out32 + (long long)m * p.ldo + n;
-            *reinterpret_cast<f32x4*>(o32) = w0; *reinterpret_cast<f32x4*>(o32 + 4) = w1;
-        }
+        if (OC && okl) *reinterpret_cast<u32x2*>(p.out_c + (long long)m * p.ldo + n) = carry_of8(a, o);
     }
 }
 
 // All patches of one wave through fast_patch (one operand mix per instantiation).
-template <int TM, int TN, bool R, bool T, bool L, bool R32 = false, bool O32 = false>
+template <int TM, int TN, bool R, bool T, bool L, bool RC = false, bool OC = false>
 __device__ __forceinline__ void wave_epilogue_fast(const GemmK& p, f32x16 (&acc)[TM][TN], float* wst, int wm, int wn, int l, int m0,
                                                    int n0, const float* ln_lds) {
     constexpr bool PF_ROWBIAS = TM * TN <= 8;                    // the 160-accumulator tiles have no registers left for it,
-    constexpr int PF_PASSES = R32 ? (TM * TN <= 8 ? 2 : 1) : TM * TN <= 8 ? 4 : 2;   // and request only the first two passes early
+    constexpr int PF_PASSES = TM * TN <= 8 ? 4 : 2;              // and request only the first two passes early
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int mrow0 = m0 + (wm * TM + i) * 32;
 #pragma unroll
         for (int j0 = 0; j0 < TN; j0 += 2) {
             const int ncol0 = n0 + (wn * TN + j0) * 32;
-            if (TN - j0 >= 2) fast_patch<2, R, T, L, PF_ROWBIAS, PF_PASSES, R32, O32>(p, acc[i][j0], acc[i][j0 + 1 < TN ? j0 + 1 : j0], wst, l, mrow0, ncol0, ln_lds, m0);
-            else fast_patch<1, R, T, L, PF_ROWBIAS, PF_PASSES, R32, O32>(p, acc[i][j0], acc[i][j0], wst, l, mrow0, ncol0, ln_lds, m0);
+            if (TN - j0 >= 2) fast_patch<2, R, T, L, PF_ROWBIAS, PF_PASSES, RC, OC>(p, acc[i][j0], acc[i][j0 + 1 < TN ? j0 + 1 : j0], wst, l, mrow0, ncol0, ln_lds, m0);
+            else fast_patch<1, R, T, L, PF_ROWBIAS, PF_PASSES, RC, OC>(p, acc[i][j0], acc[i][j0], wst, l, mrow0, ncol0, ln_lds, m0);
         }
     }
 }
@@ -142,13 +135,13 @@ __device__ __forceinline__ void wave_epilogue(const GemmK& p, f32x16 (&acc)[TM][
     if (tl && tid == 0) tl[2] = __builtin_amdgcn_s_memrealtime();
     float* wst = reinterpret_cast<float*>(smem) + wv * (trans ? 64 * LDT : 32 * LDW);
     float* part = p.ksplit > 1 ? p.partial + (long long)split * p.M * p.N : nullptr;
-    if constexpr (FAST_OK && TM * TN <= 8)       // (the 160-accumulator tiles have no registers for two more variants: general path)
-    if (!trans && !geglu && !part && !out_f32 && p.out32 && !p.rowbias && !p.ln_stats) {
-        // the executor's fp32 residual stream: h32 <- h32 + f (and the fp16 copy every consumer reads), or the start of such a chain
-        if ((p.flags & ICD_GEMM_RESID_F32) && p.resid) { wave_epilogue_fast<TM, TN, true, false, false, true, true>(p, acc, wst, wm, wn, l, m0, n0, ln_lds); return; }
+    if constexpr (FAST_OK)
+    if (!trans && !geglu && !part && !out_f32 && !p.out32 && p.out_c && !p.rowbias && !p.ln_stats && !(p.flags & ICD_GEMM_RESID_F32)) {
+        // the executor's carried residual stream: h <- h + f with the rounding error of the sum kept beside it, or the start of a chain
+        if (p.resid && p.resid_c) { wave_epilogue_fast<TM, TN, true, false, false, true, true>(p, acc, wst, wm, wn, l, m0, n0, ln_lds); return; }
         if (!p.resid) { wave_epilogue_fast<TM, TN, false, false, false, false, true>(p, acc, wst, wm, wn, l, m0, n0, ln_lds); return; }
     }
-    if (FAST_OK && !trans && !geglu && !part && !out_f32 && !p.out32 && !(p.flags & ICD_GEMM_RESID_F32)) {
+    if (FAST_OK && !trans && !geglu && !part && !out_f32 && !p.out32 && !p.out_c && !p.resid_c && !(p.flags & ICD_GEMM_RESID_F32)) {
         // fast path of the common epilogue, specialised by which operands exist (wave-uniform switch around the whole wave tile)
         switch ((p.resid ? 1 : 0) | (p.rowbias ? 2 : 0) | (p.ln_stats ? 4 : 0)) {
             case 0: wave_epilogue_fast<TM, TN, false, false, false>(p, acc, wst, wm, wn, l, m0, n0, ln_lds); break;   // plain / bias only
@@ -302,6 +295,7 @@ __device__ __forceinline__ void wave_epilogue(const GemmK& p, f32x16 (&acc)[TM][
                         f16x8 rs = *reinterpret_cast<const f16x8*>(p.resid + (long long)m * p.ldr + n);
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] += (float)rs[e];
+                        if (p.resid_c) carry_add8(v, p.resid_c + (long long)m * p.ldr + n);
                         }
                     }
                     if (p.out32) {
@@ -318,6 +312,7 @@ __device__ __forceinline__ void wave_epilogue(const GemmK& p, f32x16 (&acc)[TM][
 #pragma unroll
                         for (int e = 0; e < 8; ++e) o[e] = (half_t)v[e];
                         *reinterpret_cast<f16x8*>(reinterpret_cast<half_t*>(p.out) + (long long)m * p.ldo + n) = o;
+                        if (p.out_c) *reinterpret_cast<u32x2*>(p.out_c + (long long)m * p.ldo + n) = carry_of8(v, o);
                     }
                 }
             }

@@ -120,18 +120,23 @@ struct icd_unet {
     bool ln_inline = true;          // the GEMM behind a LayerNorm computes its statistics (ICD_GEMM_LN_COMPUTE)
     int xattn_tile = 0;             // A/B: host tile of the fused launch (icd_gemm_desc.tune_xattn_tile)
     bool attn_mode0 = false;        // A/B: flash attention with the scale / offset FMA on the VALU (ICD_ATTN_TUNE_MODE0)
-    // fp32 residual stream: every chain x <- x + f(x) of the UNet (ResnetBlock2D: conv2 + input / shortcut; BasicTransformerBlock: the
-    // three branch adds; Transformer2DModel: proj_out + input) accumulates in fp32, and the fp16 copy the next operator reads is
-    // rounded from that sum.  Removes the dominant error term of an fp16-storage pipeline (one rounding of the whole stream per add,
-    // ~100 - 300 adds deep): eps rel-L2 vs the fp32 oracle 1.1e-3 -> 0.8e-3, for 6 more bytes per element and add.
-    bool resid32 = false;
+    // Precision of the residual stream.  Every chain x <- x + f(x) of the UNet (ResnetBlock2D: conv2 + input / shortcut;
+    // BasicTransformerBlock: the three branch adds; Transformer2DModel: proj_out + input) rounds the whole stream to fp16 once per add,
+    // ~100 - 300 adds deep: the dominant error term of an fp16-storage pipeline (eps rel-L2 vs the fp32 oracle 1.1e-3).
+    //   0  fp16 stream.
+    //   1  fp32 twin (round 3): the chain accumulates in fp32 beside the fp16 copy every consumer reads - 0.7e-3, 6 more bytes per
+    //      element and add (-9 % SD1.5, -7 % SDXL).
+    //   2  error carry (round 4, default): one bf8 byte per element holds what the fp16 rounding lost (icd_gemm_desc.resid_carry /
+    //      out_carry) - the same 0.7e-3 for 2 more bytes per element and add.
+    int resid_mode = 2;
 };
 
 namespace {
 
-// token-major activation [B*HW, C]; p32: the same tensor before its fp16 rounding, kept only while a consumer will use it as a
-// residual (icd_unet option ICD_UNET_OPT_RESIDUAL_F32) - every other consumer (GEMM operands, GroupNorm, skip concat) reads p
-struct Act { half_t* p; int C; float* p32 = nullptr; };
+// token-major activation [B*HW, C]; aux: what the fp16 rounding of the tensor lost - its fp32 twin (residual mode 1) or its bf8 error
+// carry (mode 2) - kept only while a consumer will use the tensor as a residual (icd_unet option ICD_UNET_OPT_RESIDUAL_MODE); every
+// other consumer (GEMM operands, GroupNorm, skip concat) reads p
+struct Act { half_t* p; int C; void* aux = nullptr; };
 
 struct Exec {
     icd_unet* u;
@@ -202,23 +207,35 @@ struct Exec {
         run(icd_gemm(&d, st));
     }
     // dense: out[M,N] (ldo) = a[M,K](lda) @ w[N,K]^T + bias + resid
+    // resid_aux / out_aux: the fp32 twin or the error carry of `resid` / `out` (residual mode 1 / 2; same leading dimensions)
+    void set_aux(icd_gemm_desc& d, const void* resid_aux, void* out_aux) {
+        if (u->resid_mode == 1) {
+            if (resid_aux) { d.resid = resid_aux; d.flags |= ICD_GEMM_RESID_F32; }       // the fp32 twin IS the residual
+            d.out_f32 = (float*)out_aux;
+        } else {
+            d.resid_carry = resid_aux; d.out_carry = out_aux;
+        }
+    }
+    long long aux_bytes(long long elems) const { return u->resid_mode == 1 ? elems * 4 : elems; }
+    void* alloc_aux(long long elems) { return u->resid_mode ? (void*)alloc<char>(aux_bytes(elems)) : nullptr; }
     void linear(const half_t* a, int lda, int M, int K, const half_t* w, int N, const float* bias, const half_t* resid,
                 int ldr, half_t* out, int ldo, int flags = 0, int rps = 0, const float* ln_stats = nullptr,
-                const float* ln_colsum = nullptr, const float* resid32 = nullptr, float* out32 = nullptr) {
+                const float* ln_colsum = nullptr, const void* resid_aux = nullptr, void* out_aux = nullptr) {
         icd_gemm_desc d; memset(&d, 0, sizeof(d));
         d.a0 = a; d.w = w; d.bias = bias; d.resid = resid; d.out = out;
-        if (resid32) { d.resid = resid32; flags |= ICD_GEMM_RESID_F32; }       // fp32 residual stream (same leading dimension)
-        d.out_f32 = out32;
+        d.flags = flags;
+        set_aux(d, resid_aux, out_aux);
+        flags = d.flags;
         d.ln_stats = ln_stats; d.ln_colsum = ln_colsum;
         d.M = M; d.N = N; d.K = K; d.Nw = N; d.lda = lda; d.ldw = K; d.ldo = ldo; d.ldr = ldr;
         d.rows_per_sample = rps; d.mode = 0; d.batch = 1; d.zdiv = 1; d.alpha = 1.f; d.flags = flags;
         gemm_desc(d);
     }
-    // resid32 / out32: fp32 residual stream (see icd_unet::resid32); out_is_f32: `out` itself is float (the shortcut conv of a
-    // ResnetBlock2D, which is only ever a residual)
+    // resid_aux / out_aux: as in linear(); out_is_f32: `out` itself is float (residual mode 1: the shortcut conv of a ResnetBlock2D,
+    // which is only ever a residual)
     void conv(const Act& x0, const Act* x1, int Hin, int Win, int ksize, int stride, int upsample, const half_t* w, int Cout,
-              const float* bias, const half_t* rowbias, int ld_rowbias, const half_t* resid, void* out, const float* resid32 = nullptr,
-              float* out32 = nullptr, bool out_is_f32 = false) {
+              const float* bias, const half_t* rowbias, int ld_rowbias, const half_t* resid, void* out, const void* resid_aux = nullptr,
+              void* out_aux = nullptr, bool out_is_f32 = false) {
         icd_gemm_desc d; memset(&d, 0, sizeof(d));
         const int Hu = Hin << upsample, Wu = Win << upsample;
         const int Ho = (Hu + stride - 1) / stride, Wo = (Wu + stride - 1) / stride;
@@ -228,13 +245,12 @@ struct Exec {
         d.ldw = d.K; d.ldo = Cout; d.ldr = Cout; d.ld_rowbias = ld_rowbias; d.rows_per_sample = Ho * Wo;
         d.mode = 1; d.Hin = Hin; d.Win = Win; d.Hout = Ho; d.Wout = Wo; d.ksize = ksize; d.stride = stride; d.upsample = upsample;
         d.batch = 1; d.zdiv = 1; d.alpha = 1.f;
-        if (resid32) { d.resid = resid32; d.flags |= ICD_GEMM_RESID_F32; }
-        d.out_f32 = out32;
+        set_aux(d, resid_aux, out_aux);
         if (out_is_f32) d.flags |= ICD_GEMM_OUT_F32;
         gemm_desc(d);
     }
-    void free_act(Act& a) { release(a.p); release(a.p32); a.p = nullptr; a.p32 = nullptr; }
-    void free32(Act& a) { release(a.p32); a.p32 = nullptr; }
+    void free_act(Act& a) { release(a.p); release(a.aux); a.p = nullptr; a.aux = nullptr; }
+    void free_aux(Act& a) { release(a.aux); a.aux = nullptr; }
     void groupnorm(const Act& x0, const Act* x1, int HW, const float* g, const float* b, float eps, int silu, half_t* out) {
         if (!ok() || dry) return;
         ProfScope ps(true, st, ICD_PROF_GROUPNORM, 0.0, 6.0 * B * (double)HW * (x0.C + (x1 ? x1->C : 0)));
@@ -263,34 +279,35 @@ struct Exec {
         Act h1a{h1, Cout};
         groupnorm(h1a, nullptr, HW, Wf(p + ".norm2.weight", Cout), Wf(p + ".norm2.bias", Cout), 1e-5f, 1, n2);
         release(h1);
-        const bool r32 = u->resid32;
+        const int rm = u->resid_mode;
         const half_t* resid = x0.p;
-        const float* resid_f = r32 ? x0.p32 : nullptr;
+        const void* resid_aux = rm ? x0.aux : nullptr;
         half_t* sc = nullptr;
-        float* sc32 = nullptr;
+        void* sc_aux = nullptr;
         if (Cin != Cout) {
-            if (r32) {                               // the shortcut is only ever a residual: fp32 output, no fp16 copy
-                sc32 = alloc<float>(M * Cout);
+            if (rm == 1) {                           // the shortcut is only ever a residual: fp32 output, no fp16 copy
+                sc_aux = alloc<float>(M * Cout);
                 conv(x0, x1, Hh, Ww, 1, 1, 0, Wh(p + ".conv_shortcut.weight", (long long)Cin * Cout), Cout,
-                     Wf(p + ".conv_shortcut.bias", Cout), nullptr, 0, nullptr, sc32, nullptr, nullptr, true);
-                resid_f = sc32;
-            } else {
+                     Wf(p + ".conv_shortcut.bias", Cout), nullptr, 0, nullptr, sc_aux, nullptr, nullptr, true);
+            } else {                                 // fp16 (+ its error carry in mode 2)
                 sc = alloc<half_t>(M * Cout);
+                sc_aux = alloc_aux(M * Cout);
                 conv(x0, x1, Hh, Ww, 1, 1, 0, Wh(p + ".conv_shortcut.weight", (long long)Cin * Cout), Cout,
-                     Wf(p + ".conv_shortcut.bias", Cout), nullptr, 0, nullptr, sc);
+                     Wf(p + ".conv_shortcut.bias", Cout), nullptr, 0, nullptr, sc, nullptr, sc_aux);
                 resid = sc;
             }
+            resid_aux = sc_aux;
         }
         half_t* out = alloc<half_t>(M * Cout);
-        float* out32 = r32 ? alloc<float>(M * Cout) : nullptr;
+        void* out_aux = alloc_aux(M * Cout);
         Act n2a{n2, Cout};
         conv(n2a, nullptr, Hh, Ww, 3, 1, 0, Wh(p + ".conv2.weight", 9LL * Cout * Cout), Cout, Wf(p + ".conv2.bias", Cout),
-             nullptr, 0, resid_f ? nullptr : resid, out, resid_f, out32);
+             nullptr, 0, (rm == 1 && resid_aux) ? nullptr : resid, out, resid_aux, out_aux);
         release(n2);
         release(sc);
-        release(sc32);
+        release(sc_aux);
         Act o{out, Cout};
-        o.p32 = out32;
+        o.aux = out_aux;
         return o;
     }
 
@@ -360,9 +377,10 @@ struct Exec {
         half_t* n = alloc<half_t>(M * C);
         groupnorm(x, nullptr, HW, Wf(p + ".norm.weight", C), Wf(p + ".norm.bias", C), 1e-6f, 0, n);
         half_t* h = alloc<half_t>(M * C);
-        float* h32 = u->resid32 ? alloc<float>(M * C) : nullptr;         // fp32 residual stream of the transformer blocks
+        void* hx = alloc_aux(M * C);                 // fp32 twin / error carry of the transformer blocks' residual stream
+        const bool tw = u->resid_mode == 1;          // fp32 twin: the twin IS the residual operand (no fp16 resid beside it)
         linear(n, C, (int)M, C, Wh(p + ".proj_in.weight", (long long)C * C), C, Wf(p + ".proj_in.bias", C), nullptr, 0, h, C, 0, 0,
-               nullptr, nullptr, nullptr, h32);
+               nullptr, nullptr, nullptr, hx);
         // the first GEMM behind each LayerNorm computes the statistics of its input rows itself (from its MFMA operand fragments
         // where the tile kernel can, see icd_gemm) and leaves them in lnst for a second consumer (to_v after to_qk)
         const int lnc = u->ln_inline ? ICD_GEMM_LN_COMPUTE : 0;
@@ -384,8 +402,8 @@ struct Exec {
             const AttnPlan self_plan = attn_query(false, place, heads, HW, HW);
             attention(self_plan, false, place, qk, 2 * C, qk + C, 2 * C, vt, ldv_self, (long long)C * ldv_self, heads, HW, HW, d, ao, C);
             release(qk); release(vt);
-            linear(ao, C, (int)M, C, Wh(b + ".attn1.to_out.0.weight", (long long)C * C), C, Wf(b + ".attn1.to_out.0.bias", C), h32 ? nullptr : h, C,
-                   h, C, 0, 0, nullptr, nullptr, h32, h32);
+            linear(ao, C, (int)M, C, Wh(b + ".attn1.to_out.0.weight", (long long)C * C), C, Wf(b + ".attn1.to_out.0.bias", C), tw ? nullptr : h, C,
+                   h, C, 0, 0, nullptr, nullptr, hx, hx);
             // ---- cross attention ----
             ln_stats(h, M, C, lnst);
             // K and V^T of this layer are column / row slices of the per-forward batched projections
@@ -419,27 +437,27 @@ struct Exec {
                 release(q2);
             }
             kv_off += C;
-            linear(ao, C, (int)M, C, Wh(b + ".attn2.to_out.0.weight", (long long)C * C), C, Wf(b + ".attn2.to_out.0.bias", C), h32 ? nullptr : h, C,
-                   h, C, 0, 0, nullptr, nullptr, h32, h32);
+            linear(ao, C, (int)M, C, Wh(b + ".attn2.to_out.0.weight", (long long)C * C), C, Wf(b + ".attn2.to_out.0.bias", C), tw ? nullptr : h, C,
+                   h, C, 0, 0, nullptr, nullptr, hx, hx);
             release(ao);
             // ---- GEGLU feed-forward ----
             ln_stats(h, M, C, lnst);
             half_t* ff = alloc<half_t>(M * 4 * C);
             linear(h, C, (int)M, C, Wh(b + ".ff.net.0.proj.weight", 8LL * C * C), 8 * C, Wf(b + ".ff.net.0.proj.bias", 8 * C), nullptr, 0,
                    ff, 4 * C, ICD_GEMM_GEGLU | lnc, 0, lnst, Wf(b + ".ff.net.0.proj.lnsum", 8 * C));
-            linear(ff, 4 * C, (int)M, 4 * C, Wh(b + ".ff.net.2.weight", 4LL * C * C), C, Wf(b + ".ff.net.2.bias", C), h32 ? nullptr : h, C, h, C,
-                   0, 0, nullptr, nullptr, h32, h32);
+            linear(ff, 4 * C, (int)M, 4 * C, Wh(b + ".ff.net.2.weight", 4LL * C * C), C, Wf(b + ".ff.net.2.bias", C), tw ? nullptr : h, C, h, C,
+                   0, 0, nullptr, nullptr, hx, hx);
             release(ff);
         }
         release(lnst);
         half_t* out = alloc<half_t>(M * C);
-        float* out32 = u->resid32 ? alloc<float>(M * C) : nullptr;
-        release(h32);                                // (proj_out reads the fp16 copy of the stream as its operand)
-        linear(h, C, (int)M, C, Wh(p + ".proj_out.weight", (long long)C * C), C, Wf(p + ".proj_out.bias", C), x.p32 ? nullptr : x.p, C, out, C,
-               0, 0, nullptr, nullptr, x.p32, out32);
+        void* out_aux = alloc_aux(M * C);
+        release(hx);                                 // (proj_out reads the fp16 copy of the stream as its operand)
+        linear(h, C, (int)M, C, Wh(p + ".proj_out.weight", (long long)C * C), C, Wf(p + ".proj_out.bias", C), (tw && x.aux) ? nullptr : x.p, C, out, C,
+               0, 0, nullptr, nullptr, x.aux, out_aux);
         release(h);
         Act o{out, C};
-        o.p32 = out32;
+        o.aux = out_aux;
         return o;
     }
 
@@ -533,13 +551,13 @@ struct Exec {
                 run(icd_pack_latent(io->sample, io->sample_is_f32, B, HW0, lat8, st));
             }
             Act l8{lat8, 8};
-            if (u->resid32) h.p32 = alloc<float>((long long)B * HW0 * ch0);       // residual of down_blocks.0.resnets.0
+            h.aux = alloc_aux((long long)B * HW0 * ch0);                          // residual of down_blocks.0.resnets.0
             conv(l8, nullptr, H0, W0, 3, 1, 0, Wh("conv_in.weight8", 72LL * ch0), ch0, Wf("conv_in.bias", ch0), nullptr, 0, nullptr, h.p,
-                 nullptr, h.p32);
+                 nullptr, h.aux);
             release(lat8);
         }
-        // the skip stack keeps the fp16 tensors (their consumers concatenate them as GEMM / GroupNorm operands); the fp32 twin of a
-        // tensor lives only until the one operator that uses it as a residual has run
+        // the skip stack keeps the fp16 tensors (their consumers concatenate them as GEMM / GroupNorm operands); the fp32 twin / error
+        // carry of a tensor lives only until the one operator that uses it as a residual has run
         skips.push_back(Act{h.p, h.C});
         int Hh = H0, Ww = W0;
         // ---------------- down
@@ -548,8 +566,8 @@ struct Exec {
             for (int j = 0; j < c.layers_per_block && ok(); ++j) {
                 const std::string rp = "down_blocks." + std::to_string(i) + ".resnets." + std::to_string(j);
                 Act r = resnet(rp, h, nullptr, Hh, Ww, Cout);
-                // h stays alive: it is on the skip stack (its fp32 twin has served as this resnet's residual)
-                free32(h);
+                // h stays alive: it is on the skip stack (its twin / carry has served as this resnet's residual)
+                free_aux(h);
                 h = r;
                 if (c.down_has_attn[i]) {
                     Act t = transformer("down_blocks." + std::to_string(i) + ".attentions." + std::to_string(j), h, Hh, Ww,
@@ -562,11 +580,11 @@ struct Exec {
             if (i < L - 1) {
                 const std::string dp = "down_blocks." + std::to_string(i) + ".downsamplers.0.conv";
                 Act dn{alloc<half_t>((long long)B * (Hh / 2) * (Ww / 2) * Cout), Cout};
-                // (its fp32 twin is a residual only where the next level keeps the channel count: SD1.5's last level)
-                if (u->resid32 && c.block_out_channels[i + 1] == Cout) dn.p32 = alloc<float>((long long)B * (Hh / 2) * (Ww / 2) * Cout);
+                // (it is a residual only where the next level keeps the channel count: SD1.5's last level)
+                if (c.block_out_channels[i + 1] == Cout) dn.aux = alloc_aux((long long)B * (Hh / 2) * (Ww / 2) * Cout);
                 conv(h, nullptr, Hh, Ww, 3, 2, 0, Wh(dp + ".weight", 9LL * Cout * Cout), Cout, Wf(dp + ".bias", Cout), nullptr, 0, nullptr, dn.p,
-                     nullptr, dn.p32);
-                free32(h);
+                     nullptr, dn.aux);
+                free_aux(h);
                 Hh /= 2; Ww /= 2;
                 h = dn;
                 skips.push_back(Act{h.p, h.C});
@@ -576,7 +594,7 @@ struct Exec {
         {
             const int Cm = c.block_out_channels[L - 1];
             Act r0 = resnet("mid_block.resnets.0", h, nullptr, Hh, Ww, Cm);     // h is the last skip: stays alive
-            free32(h);
+            free_aux(h);
             Act t = transformer("mid_block.attentions.0", r0, Hh, Ww, c.transformer_layers[L - 1], c.num_heads[L - 1], 1);
             free_act(r0);
             Act r1 = resnet("mid_block.resnets.1", t, nullptr, Hh, Ww, Cm);
@@ -599,7 +617,7 @@ struct Exec {
                     free_act(h);
                     h = t;
                 }
-                free32(h);                           // the next resnet concatenates h with a skip: Cin != Cout, its residual is the shortcut
+                free_aux(h);                         // the next resnet concatenates h with a skip: Cin != Cout, its residual is the shortcut
             }
             if (i < L - 1) {
                 const std::string upn = "up_blocks." + std::to_string(i) + ".upsamplers.0.conv";
@@ -659,9 +677,9 @@ extern "C" int icd_unet_set_option(icd_unet* u, int32_t option, int32_t value) {
     case ICD_UNET_OPT_ATTN_VALU_SCALE:
         ICD_CHECK_ARG(value == 0 || value == 1, "icd_unet_set_option: ICD_UNET_OPT_ATTN_VALU_SCALE takes 0 or 1 (got %d)", value);
         u->attn_mode0 = value != 0; return ICD_OK;
-    case ICD_UNET_OPT_RESIDUAL_F32:
-        ICD_CHECK_ARG(value == 0 || value == 1, "icd_unet_set_option: ICD_UNET_OPT_RESIDUAL_F32 takes 0 or 1 (got %d)", value);
-        u->resid32 = value != 0; return ICD_OK;
+    case ICD_UNET_OPT_RESIDUAL_MODE:
+        ICD_CHECK_ARG(value >= 0 && value <= 2, "icd_unet_set_option: ICD_UNET_OPT_RESIDUAL_MODE takes 0, 1 or 2 (got %d)", value);
+        u->resid_mode = value; return ICD_OK;
     case ICD_UNET_OPT_LN_INLINE_STATS:
         ICD_CHECK_ARG(value == 0 || value == 1, "icd_unet_set_option: ICD_UNET_OPT_LN_INLINE_STATS takes 0 or 1 (got %d)", value);
         u->ln_inline = value != 0; return ICD_OK;

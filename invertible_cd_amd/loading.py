@@ -120,10 +120,11 @@ def load_models(model_id, device, reverse_checkpoint, forward_checkpoint, r=64, 
     architecture (reduced-width checkpoints in tests).
 
     dtype: the reference's default 'fp32' runs diffusers in fp32 (utils/loading.py:34,38).  This executor multiplies fp16 x fp16
-    into fp32 accumulators on the matrix cores either way; 'fp32' selects fp32 latents / eps at the UNet boundary, fp32
-    boundary-step arithmetic AND the fp32 residual stream (UNet option residual_f32: every x <- x + f(x) chain accumulates in
-    fp32, the dominant error term of fp16 activation storage is gone) - DESIGN.md section 6 has the measured distance of both
-    modes to an fp32 evaluation (eps rel-L2 1.1e-3 for 'fp16', 0.8e-3 for 'fp32')."""
+    into fp32 accumulators on the matrix cores either way; 'fp32' selects fp32 latents / eps at the UNet boundary and fp32
+    boundary-step arithmetic.  In both modes the residual stream carries its rounding error (UNet option residual = 2, the default
+    since round 4: every x <- x + f(x) chain keeps one bf8 byte per element beside the fp16 value, so the dominant error term of fp16
+    activation storage is gone) - DESIGN.md section 6 has the measured distance to an fp32 evaluation (eps rel-L2 0.7e-3; 1.1e-3 with
+    unet.set_option('residual', 0))."""
     tdtype = torch.float32 if dtype == 'fp32' else torch.float16
     cfg = dataclasses.replace(unet_config or SD15, time_cond_proj_dim=int(w_embed_dim))
     if w_embed_dim > 0:
@@ -139,8 +140,6 @@ def load_models(model_id, device, reverse_checkpoint, forward_checkpoint, r=64, 
 
     def pipeline(sd):
         unet = UNet2DConditionModel(cfg, sd, device=device, dtype=tdtype)
-        if dtype == 'fp32':
-            unet.set_option("residual_f32", 1)
         sched = DDIMScheduler.sd15()
         return StableDiffusionPipeline(unet, sched, comp["vae"], comp["tokenizer"], comp["text_encoder"], device, tdtype)
 

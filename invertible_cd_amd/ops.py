@@ -61,9 +61,10 @@ FORBID_BIG_TILE = 0x200000
 
 def gemm(a, w, bias=None, resid=None, rowbias=None, rows_per_sample=0, geglu=False, out=None, alpha=1.0,
          out_f32=False, debug_flags=0, ln_stats=None, ln_colsum=None, ln_compute=False, ln_eps=1e-5, group_m=0, timeline=None,
-         out32=None):
+         out32=None, resid_carry=None, out_carry=None):
     """out[M, N] = alpha * a[M, K] @ w[N, K]^T (+bias[N] fp32) (+rowbias[m // rps]) (+resid) ; GEGLU halves N.
-    ln_stats [M, 2] fp32 + ln_colsum [N] fp32: LayerNorm of `a` fused into the epilogue (w carries gamma, bias carries W beta)."""
+    ln_stats [M, 2] fp32 + ln_colsum [N] fp32: LayerNorm of `a` fused into the epilogue (w carries gamma, bias carries W beta).
+    resid_carry / out_carry: uint8 [M, N] error carries of `resid` / `out` (icd_gemm_desc.resid_carry / out_carry; carry_decode)."""
     _chk16(a, "a"); _chk16(w, "w")
     M, K = a.shape
     N = w.shape[0]
@@ -94,6 +95,7 @@ def gemm(a, w, bias=None, resid=None, rowbias=None, rows_per_sample=0, geglu=Fal
     if out32 is not None:                     # second output: the same values before the fp16 rounding (fp32 residual stream)
         assert out32.dtype == torch.float32 and out32.is_cuda and tuple(out32.shape) == (M, n_out) and out32.stride(0) == out.stride(0)
         d.out_f32 = out32.data_ptr()
+    _set_carry(d, resid, resid_carry, out, out_carry)
     d.tune_group_m = group_m                  # tuning / diagnostics travel in the descriptor (no process-wide state)
     d.debug_timeline = timeline.data_ptr() if timeline is not None else None
     ws = _splitk_ws(d, a.device)
@@ -101,8 +103,32 @@ def gemm(a, w, bias=None, resid=None, rowbias=None, rows_per_sample=0, geglu=Fal
     return out
 
 
+def _set_carry(d, resid, resid_carry, out, out_carry):
+    if resid_carry is not None:
+        assert resid is not None and resid_carry.dtype == torch.uint8 and resid_carry.is_cuda and resid_carry.shape == resid.shape
+        assert resid_carry.stride(0) == resid.stride(0)
+        d.resid_carry = resid_carry.data_ptr()
+    if out_carry is not None:
+        assert out_carry.dtype == torch.uint8 and out_carry.is_cuda and out_carry.shape == out.shape and out_carry.stride(0) == out.stride(0)
+        d.out_carry = out_carry.data_ptr()
+
+
+CARRY_SCALE = 16384.0
+
+
+def carry_decode(hi, carry):
+    """fp32 value of a carried tensor: fp16 `hi` + 2^-14 * bf8_e5m2 `carry` (uint8), see icd_gemm_desc.resid_carry."""
+    return hi.float() + carry.view(torch.float8_e5m2).float() / CARRY_SCALE
+
+
+def carry_encode(v):
+    """(hi, carry) of an fp32 tensor, as the GEMM epilogues produce them (round to nearest even twice)."""
+    hi = v.half()
+    return hi, ((v.float() - hi.float()) * CARRY_SCALE).to(torch.float8_e5m2).view(torch.uint8)
+
+
 def conv3x3(x, B, H, W, w_packed, bias=None, x2=None, stride=1, upsample=False, resid=None, rowbias=None, ksize=3,
-            debug_flags=0, pad_hi=False, out_f32=False, alpha=1.0):
+            debug_flags=0, pad_hi=False, out_f32=False, alpha=1.0, resid_carry=None, out_carry=None):
     """Implicit-GEMM conv over NHWC x [B*H*W, C0] (optionally cat with x2 [.., C1]); returns [B*Ho*Wo, Cout].
     pad_hi: zero padding on the bottom/right edge only (AutoencoderKL Downsample2D).  out_f32 / an fp32 `resid` / alpha: the
     fp32-fidelity VAE path (fp32 conv outputs and residual stream, power-of-two input scaling undone by alpha)."""
@@ -128,6 +154,7 @@ def conv3x3(x, B, H, W, w_packed, bias=None, x2=None, stride=1, upsample=False, 
     d.batch, d.zdiv, d.alpha, d.flags = 1, 1, alpha, debug_flags | (ICD_GEMM_PAD_HI if pad_hi else 0) | (ICD_GEMM_OUT_F32 if out_f32 else 0)
     if resid is not None and resid.dtype == torch.float32:
         d.flags |= ICD_GEMM_RESID_F32
+    _set_carry(d, resid, resid_carry, out, out_carry)
     ws = _splitk_ws(d, x.device)
     _lib.check(_lib.load().icd_gemm(C.byref(d), _stream()), "icd_gemm(conv)")
     return out

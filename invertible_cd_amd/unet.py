@@ -214,14 +214,15 @@ class UNet2DConditionModel:
 
     OPTIONS = {"xattn_fusion": _lib.ICD_UNET_OPT_XATTN_FUSION, "ln_inline_stats": _lib.ICD_UNET_OPT_LN_INLINE_STATS,
                "xattn_tile": _lib.ICD_UNET_OPT_XATTN_TILE, "attn_valu_scale": _lib.ICD_UNET_OPT_ATTN_VALU_SCALE,
-               "residual_f32": _lib.ICD_UNET_OPT_RESIDUAL_F32}
+               "residual": _lib.ICD_UNET_OPT_RESIDUAL_MODE, "residual_f32": _lib.ICD_UNET_OPT_RESIDUAL_MODE}
 
     def set_option(self, name, value):
-        """Per-handle execution option (icd_unet_set_option): 'xattn_fusion' 0 / 1 / 2, 'ln_inline_stats' 0 / 1, 'xattn_tile' 0 / 2 / 4.  A/B tuning and
-        tests; the defaults are the measured-faster settings and nothing is process-wide."""
+        """Per-handle execution option (icd_unet_set_option): 'xattn_fusion' 0 / 1 / 2, 'ln_inline_stats' 0 / 1, 'xattn_tile' 0 / 2 / 4,
+        'residual' 0 fp16 stream / 1 fp32 twin / 2 error carry (default; 'residual_f32' is the round-3 name of the same option).  A/B
+        tuning and tests; nothing is process-wide."""
         _lib.check(self._lib.icd_unet_set_option(self._h, self.OPTIONS[name], int(value)), f"icd_unet_set_option({name})")
-        if name == "residual_f32":
-            self._ws_key = None                  # the arena holds the fp32 twins of the residual stream: size it again
+        if name in ("residual", "residual_f32"):
+            self._ws_key = None                  # the arena holds the twins / carries of the residual stream: size it again
         return self
 
     # ------------------------------------------------------------------ duck-typed nn.Module surface

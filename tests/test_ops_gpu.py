@@ -244,6 +244,66 @@ def test_gemm_fp32_residual_stream_outputs(M, N, K, flags):
     assert rel_l2(o32, a.double() @ w.double().t() + bias.double()) < 1e-5 and torch.equal(out2.cpu(), o32.cpu().half())
 
 
+@pytest.mark.parametrize("M,N,K,flags", [(8192, 1280, 1280, 0),                                    # planner: 192 x 256 tile, fast variants
+                                         (4096, 512, 512, 0x100000 | (1 << 24)),                     # forced 256 x 256
+                                         (4096, 640, 640, 0x100000 | (2 << 24)),                     # forced 256 x 320 (160 accumulators)
+                                         (4096, 640, 640, 0x100000 | (4 << 24)),                     # forced 128 x 320
+                                         (200, 320, 320, 0),                                         # 128-wide kernel, ragged M
+                                         (512, 1280, 5120, 0)])                                      # split-K + reduce kernel
+def test_gemm_error_carry_of_the_residual_stream(M, N, K, flags):
+    """icd_gemm_desc.resid_carry / out_carry (UNet option residual = 2, the default): a stream tensor is an fp16 value plus one bf8 byte
+    holding what the rounding lost.  h <- h + a w^T + bias in place on (hi, carry) like the executor; also the start of a chain."""
+    ops = _ops()
+    a, w = r16(M, K, seed=140), (r16(N, K, seed=141).float() * K ** -0.5).half()
+    bias = torch.randn(N, generator=torch.Generator().manual_seed(142))
+    h32 = torch.randn(M, N, generator=torch.Generator().manual_seed(143)) * 3.0
+    hi, lo = ops.carry_encode(h32)
+    assert rel_l2(ops.carry_decode(hi, lo), h32) < 0.1 * rel_l2(hi, h32)                             # (the encoding itself: > 10 x closer)
+    ref = ops.carry_decode(hi, lo).double() + a.double() @ w.double().t() + bias.double()
+    hi_d, lo_d = hi.cuda(), lo.cuda()
+    out = ops.gemm(a.cuda(), w.cuda(), bias=bias.cuda(), resid=hi_d, resid_carry=lo_d, out=hi_d, out_carry=lo_d, debug_flags=flags)
+    assert out.data_ptr() == hi_d.data_ptr()
+    e_hi, e_c = rel_l2(hi_d, ref), rel_l2(ops.carry_decode(hi_d, lo_d), ref)
+    print(f"[carry {M}x{N}x{K} flags={flags:#x}] fp16 alone {e_hi:.3e}, with the carry {e_c:.3e}")
+    assert e_hi < 3e-4 and e_c < 0.1 * e_hi                                                          # what fp16 lost is back (x >= 10)
+    assert (hi_d.cpu() != ref.half()).float().mean() < 2e-3                                          # hi is the fp16 rounding of the sum
+    # the same launch without the carries reproduces the plain fp16 result of hi + f
+    plain = ops.gemm(a.cuda(), w.cuda(), bias=bias.cuda(), resid=hi.cuda(), debug_flags=flags)
+    assert rel_l2(plain, hi.double() + a.double() @ w.double().t() + bias.double()) < 3e-4
+    o_hi = torch.empty(M, N, device="cuda", dtype=torch.float16)
+    o_lo = torch.empty(M, N, device="cuda", dtype=torch.uint8)
+    ops.gemm(a.cuda(), w.cuda(), bias=bias.cuda(), out=o_hi, out_carry=o_lo, debug_flags=flags)       # chain start: no residual
+    ref0 = a.double() @ w.double().t() + bias.double()
+    assert rel_l2(ops.carry_decode(o_hi, o_lo), ref0) < 0.1 * rel_l2(o_hi, ref0)
+    # a residual WITHOUT a carry beside an output WITH one (general path)
+    o2_lo = torch.empty(M, N, device="cuda", dtype=torch.uint8)
+    o2 = ops.gemm(a.cuda(), w.cuda(), bias=bias.cuda(), resid=hi.cuda(), out_carry=o2_lo, debug_flags=flags)
+    ref2 = hi.double() + ref0
+    assert rel_l2(ops.carry_decode(o2, o2_lo), ref2) < 0.1 * rel_l2(o2, ref2)
+
+
+def test_conv_error_carry():
+    """The resnet form: conv2 (3 x 3) + carried residual -> carried output, on the conv tiles (256 x 320 at C = 320)."""
+    ops = _ops()
+    B, H, W, C = 4, 32, 32, 320
+    x = r16(B * H * W, C, seed=150)
+    wt = (r16(C, 9 * C, seed=151).float() * (9 * C) ** -0.5).half()
+    bias = torch.randn(C, generator=torch.Generator().manual_seed(152))
+    h32 = torch.randn(B * H * W, C, generator=torch.Generator().manual_seed(153)) * 2.0
+    hi, lo = ops.carry_encode(h32)
+    o_lo = torch.empty(B * H * W, C, device="cuda", dtype=torch.uint8)
+    out = ops.conv3x3(x.cuda(), B, H, W, wt.cuda(), bias=bias.cuda(), resid=hi.cuda(), resid_carry=lo.cuda(), out_carry=o_lo)
+    plain = ops.conv3x3(x.cuda(), B, H, W, wt.cuda(), bias=bias.cuda())
+    ref = ops.carry_decode(hi, lo).double() + (plain.cpu().double())          # (plain is within fp16 rounding of the conv; compare sums)
+    got = ops.carry_decode(out, o_lo).cpu().double()
+    # the conv term itself is only known to fp16 precision from `plain`: the carried sum is checked against hi + lo + conv to that
+    # precision, and a second carried launch against the first (the pair must not depend on anything but the values)
+    assert rel_l2(got, ref) < 2e-4
+    o_lo2 = torch.empty_like(o_lo)
+    out2 = ops.conv3x3(x.cuda(), B, H, W, wt.cuda(), bias=bias.cuda(), resid=hi.cuda(), resid_carry=lo.cuda(), out_carry=o_lo2)
+    assert torch.equal(out2, out) and torch.equal(o_lo2, o_lo)
+
+
 def test_gemm_rowbias_alpha_f32():
     ops = _ops()
     B, HW, K, N = 3, 64, 128, 192

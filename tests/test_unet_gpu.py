@@ -35,7 +35,7 @@ def _oracle_cfg(unet_ref, cfg):
     return o
 
 
-def _run_case(cfg, B, H, W, t, seed, tol, with_cond=True, n_ctx=77, f32_io=False, variants=None, check_plans=None):
+def _run_case(cfg, B, H, W, t, seed, tol, with_cond=True, n_ctx=77, f32_io=False, variants=None, check_plans=None, variant_tol=None):
     """Product vs fp32 oracle vs the fp16-torch floor.  `variants`: {name: {option: value}} - further runs of the SAME handle under
     other per-handle options (UNet2DConditionModel.set_option), each compared with the oracle too; `check_plans(name, plans)` gets
     the planner records of every run (name None = defaults) so a case can assert the code path it claims to pin.  Returns
@@ -93,7 +93,7 @@ def _run_case(cfg, B, H, W, t, seed, tol, with_cond=True, n_ctx=77, f32_io=False
         ev = rel_l2(e2, ref)
         print(f"[{cfg.name} B={B} {H}x{W} t={t}] variant {name} {opts}: rel-L2(eps) = {ev:.3e}  ratio to the floor = {ev / floor:.2f}  "
               f"distance to the default run = {rel_l2(e2, eps):.3e}")
-        assert torch.isfinite(e2).all() and ev < tol and ev <= 1.5 * floor + 1e-4
+        assert torch.isfinite(e2).all() and ev < (variant_tol or tol) and ev <= 1.5 * floor + 1e-4
         results[name] = (ev, e2)
     return results
 
@@ -123,12 +123,13 @@ def test_unet_full_sd15_small_latent():
 
 
 @pytest.mark.parametrize("which", ["sd15_tiny", "sdxl_tiny", "sd15_full_32"])
-def test_fp32_residual_stream_meets_the_north_star_tolerance(which):
-    """UNet option residual_f32 (what load_models(dtype='fp32') selects): every x <- x + f(x) chain of the UNet accumulates in fp32
-    (icd_gemm_desc.out_f32 + ICD_GEMM_RESID_F32), the fp16 copy the next operator reads is rounded from that sum.  The north
-    star's bar is 1e-3 rel-L2; with fp16 activation storage the residual stream's own roundings (one per add, 100-300 adds deep)
-    put a single forward at 1.1e-3 - this option removes that term.  Asserted: eps rel-L2 < 1e-3 against the fp32 oracle, clearly
-    better than the default mode of the SAME handle, and switching the option off restores the default result bit for bit."""
+def test_carried_residual_stream_meets_the_north_star_tolerance(which):
+    """UNet option residual (icd_unet_set_option ICD_UNET_OPT_RESIDUAL_MODE).  With fp16 activation storage the residual stream's own
+    roundings (one per x <- x + f(x), 100-300 adds deep) put a single forward at 1.0 - 1.2e-3 from an fp32 evaluation; the north star's
+    bar is 1e-3.  Mode 2 (default since round 4) keeps what each rounding lost in one bf8 byte per element (icd_gemm_desc.resid_carry /
+    out_carry), mode 1 (round 3) accumulated the chain in an fp32 twin.  Asserted: the default is < 1e-3 against the fp32 oracle and
+    clearly better than the plain fp16 stream of the SAME handle; the carry is as good as the fp32 twin (within 5 %); switching back
+    restores the default result bit for bit."""
     _, _, uc, _ = _mods()
     if which == "sd15_tiny":
         cfg, B, H = uc.SD15.scaled((64, 128, 256, 256), cross_dim=64), 2, 32
@@ -136,10 +137,11 @@ def test_fp32_residual_stream_meets_the_north_star_tolerance(which):
         cfg, B, H = uc.SDXL.scaled((64, 128, 256), cross_dim=128, heads=(2, 4, 8)), 2, 32
     else:
         cfg, B, H = uc.SD15, 2, 32
-    r = _run_case(cfg, B=B, H=H, W=H, t=779, seed=31, tol=2e-3, variants={"resid32": {"residual_f32": 1}, "back": {"residual_f32": 0}})
-    e16, e32 = r[None][0], r["resid32"][0]
-    print(f"[{which}] fp16 residual stream {e16:.3e} -> fp32 residual stream {e32:.3e}")
-    assert e32 < 1.0e-3 and e32 < 0.85 * e16
+    r = _run_case(cfg, B=B, H=H, W=H, t=779, seed=31, tol=1e-3,
+                  variants={"fp16": {"residual": 0}, "twin": {"residual": 1}, "back": {"residual": 2}}, variant_tol=2e-3)
+    e_c, e16, e32 = r[None][0], r["fp16"][0], r["twin"][0]
+    print(f"[{which}] fp16 residual stream {e16:.3e} -> error carry {e_c:.3e} (fp32 twin {e32:.3e})")
+    assert e_c < 1.0e-3 and e_c < 0.85 * e16 and e_c < 1.05 * e32
     assert torch.equal(r["back"][1], r[None][1])
 
 

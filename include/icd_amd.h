@@ -41,6 +41,10 @@ typedef enum {
 
 const char* icd_last_error(void);
 int icd_version(void);
+/* 12 hex digits of the sha1 over the kernel sources (csrc/ *.hip, *.h, *.cpp) this binary was built from; "unstamped" for a build that
+ * did not go through invertible_cd_amd/build.py.  The Python binding compares it with the sources next to it and refuses a stale library;
+ * bench.py reports it as roofline.kernels_sha. */
+const char* icd_build_sha(void);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Block-level operators (diffusers semantics, SURVEY.md section 8a row "a12/13-ops").

@@ -95,6 +95,7 @@ class UNetIO(C.Structure):
 SIGNATURES = {
     "icd_last_error": (C.c_char_p, []),
     "icd_version": (C.c_int, []),
+    "icd_build_sha": (C.c_char_p, []),
     "icd_gemm": (C.c_int, [C.POINTER(GemmDesc), C.c_void_p]),
     "icd_gemm_workspace_bytes": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
     "icd_groupnorm": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
@@ -174,8 +175,21 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
+    # the digest of the sources the binary was built from travels inside it: a tree whose csrc/ was edited but not rebuilt must not
+    # run (and must not report a kernels_sha it did not execute).  ICD_AMD_LIB (another build, for A/B) is exempt by design.
+    if not os.environ.get("ICD_AMD_LIB"):
+        from . import build as _build
+        if os.path.isdir(_build.CSRC):
+            built, now = lib.icd_build_sha().decode(), _build.source_sha()
+            if built != now:
+                raise RuntimeError(f"{LIB_PATH} was built from kernel sources {built}, csrc/ is now {now}: run `python -m invertible_cd_amd.build`")
     _lib = lib
     return lib
+
+
+def build_sha():
+    """Digest of the kernel sources the LOADED library was built from (icd_build_sha)."""
+    return load().icd_build_sha().decode()
 
 
 def check(status, what=""):

@@ -21,18 +21,34 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-val
 EXTRA_FLAGS = {"attention.hip": ["-fno-honor-nans"]}
 
 
+def source_sha():
+    """sha1 (12 hex digits) over the kernel sources: the digest stamped into the library (icd_build_sha) and compared at load time."""
+    import hashlib
+    h = hashlib.sha1()
+    for f in sorted(os.listdir(CSRC)):
+        if f.endswith((".hip", ".h", ".inc", ".cpp")):
+            h.update(open(os.path.join(CSRC, f), "rb").read())
+    return h.hexdigest()[:12]
+
+
 def _deps():
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     hdrs.append(os.path.join(HERE, "..", "include", "icd_amd.h"))
     return max(os.path.getmtime(h) for h in hdrs)
 
 
-def _compile(src, force):
+def _compile(src, force, sha):
     obj = os.path.join(LIBDIR, os.path.splitext(src)[0] + ".o")
     path = os.path.join(CSRC, src)
+    extra = list(EXTRA_FLAGS.get(src, []))
+    if src == "error.cpp":                       # carries the digest of ALL sources: rebuilt whenever it changes
+        stamp = os.path.join(LIBDIR, "build_sha.txt")
+        stamped = open(stamp).read().strip() if os.path.exists(stamp) else None
+        force = force or stamped != sha
+        extra.append(f'-DICD_BUILD_SHA="{sha}"')
     if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(path), _deps()):
         return obj, False
-    cmd = [HIPCC] + FLAGS + EXTRA_FLAGS.get(src, []) + (["-x", "hip"] if src.endswith(".hip") else []) + ["-c", path, "-o", obj]
+    cmd = [HIPCC] + FLAGS + extra + (["-x", "hip"] if src.endswith(".hip") else []) + ["-c", path, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
@@ -42,14 +58,17 @@ def _compile(src, force):
 def build(force=False, verbose=True):
     os.makedirs(LIBDIR, exist_ok=True)
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    sha = source_sha()
     with ThreadPoolExecutor(max_workers=8) as ex:
-        res = list(ex.map(lambda s: _compile(s, force), srcs))
+        res = list(ex.map(lambda s: _compile(s, force, sha), srcs))
     objs = [o for o, _ in res]
     if any(c for _, c in res) or not os.path.exists(LIB):
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+        with open(os.path.join(LIBDIR, "build_sha.txt"), "w") as f:
+            f.write(sha + "\n")
         if verbose:
             print(f"[icd-amd] built {LIB} ({os.path.getsize(LIB) >> 10} KiB)")
     elif verbose:

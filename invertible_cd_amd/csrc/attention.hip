@@ -481,13 +481,25 @@ __global__ __launch_bounds__(256, OCC) void attn_fused_kernel(AttnK p) {
         else __builtin_amdgcn_s_waitcnt(0x0f70 | (NKG + NVG));
     };
     static_assert(NKG + NVG < 16 && NST <= 3, "vmcnt immediate / keep count");
+    // INVARIANT the counted wait rests on (the bare s_barrier below no longer drains vmcnt): per tile, wave wv issues exactly one
+    // LDS-DMA load for every j with wv + 4 j < 2 KS (K groups) and every j with wv + 4 j < NGV (V^T groups) - issue_fast and issue_slow
+    // iterate the SAME two predicates and never skip a load inside them (rows / chunks past the tensor read the zero page instead), so
+    // the per-wave count is (NKG - [KREM != 0 && wv >= KREM]) + (NVG - [VREM != 0 && wv >= VREM]) for full and ragged tiles alike.
+    static_assert(NKG == (2 * KS + 3) / 4 && NVG == (NGV + 3) / 4 && KREM == (2 * KS) % 4 && VREM == NGV % 4,
+                  "wait_landed counts the loads of issue_fast / issue_slow: keep the group arithmetic in one place");
+    // -DICD_ATTN_DEBUG_SYNC restores the full fence (s_waitcnt vmcnt(0) lgkmcnt(0) + barrier) at every tile: a miscounted ring shows up
+    // as a bitwise difference between the two builds (tools/attn_ring_check.py runs the ragged / causal / wide-head cases on both).
     {
         auto step = [&](const bool rag, const int buf, int t) {      // tile t sits in stage `buf`
             wait_landed(nt - 1 - t < PD - 1 ? nt - 1 - t : PD - 1);
             // a bare s_barrier: __syncthreads() is a release fence first (s_waitcnt vmcnt(0) lgkmcnt(0)), which drains the LDS-DMA of
             // the tiles still in flight and turns every ring into a 2-stage one.  The counted wait above is the whole contract:
             // this wave's part of tile t has landed, its fragment reads of tile t - 1 were consumed by MFMAs already.
+#ifdef ICD_ATTN_DEBUG_SYNC
+            __syncthreads();
+#else
             __builtin_amdgcn_s_barrier();                 // tile t visible to all; everybody is done with tile t-1
+#endif
             if (t + PD < nt) issue(t + PD, ((buf + PD) % NST) * STAGE);
             f32x16 s[QT][2];
             qk(s, buf * STAGE, rag, t);

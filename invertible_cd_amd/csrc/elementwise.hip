@@ -175,7 +175,12 @@ __global__ __launch_bounds__(256) void conv_out_mfma_kernel(const half_t* __rest
     // stage the weights: w is [4][9][Cin]; 16-B chunks, chunk index = ((t * ncc + cc) * 4 + o) * 4 + j (j: 8-half slice of the 32)
     for (int i = tid; i < 9 * ncc * 16; i += 256) {
         const int j = i & 3, o = (i >> 2) & 3, kc = i >> 4, t = kc / ncc, cc = kc - t * ncc;
-        *reinterpret_cast<f16x8*>(wl + (long long)i * 8) = *reinterpret_cast<const f16x8*>(w + ((long long)(o * 9 + t)) * Cin + cc * 32 + j * 8);
+        // (w holds 4 rows by contract, icd_conv_out_n; rows >= Cout are not trusted to exist or to be zero: staged as zeros)
+        f16x8 wv;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) wv[e] = (half_t)0.f;
+        if (o < Cout) wv = *reinterpret_cast<const f16x8*>(w + ((long long)(o * 9 + t)) * Cin + cc * 32 + j * 8);
+        *reinterpret_cast<f16x8*>(wl + (long long)i * 8) = wv;
     }
     if (tid == 0) {
         f16x8 z;

@@ -189,7 +189,7 @@ __device__ __forceinline__ void xattn_epilogue_big(const GemmK& p, f32x16 (&acc)
 
 constexpr int enc_vmcnt(int n) { return ((n >> 4) << 14) | 0x0F70 | (n & 15); }
 
-template <int MODE, int WM, int WN, int TM, int TN, bool XATTN = false>
+template <int MODE, int WM, int WN, int TM, int TN, bool XATTN = false, bool CARRY = false>
 __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_big_kernel(GemmK p) {
     constexpr int NT = WM * WN * 64;
     constexpr int BM = WM * TM * 32, BNt = WN * TN * 32;
@@ -448,7 +448,21 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_big_kernel(GemmK p) {
                     const f32x2 v = *reinterpret_cast<const f32x2*>(parts + 2 * (w * BM + row));
                     s_ += v[0]; q_ += v[1];
                 }
-                const float mean = s_ * inv_k, var = fmaxf(q_ * inv_k - mean * mean, 0.f);
+                const float mean = s_ * inv_k;
+                float var = fmaxf(q_ * inv_k - mean * mean, 0.f);
+                // One-pass variance: E[x^2] - mean^2 loses ~ (1 + mean^2 / var) x 1e-6 of relative accuracy.  Rows whose offset
+                // dominates their spread (|mean| > 4 sigma: not seen on zero-centred transformer activations, but a row is a row)
+                // take the exact second pass instead - sum (x - mean)^2 in fp32 over the row, which the tile just streamed through L2.
+                if (mean * mean > 16.f * var && m0 + row < p.M) {
+                    const half_t* ar = p.a0 + (long long)(m0 + row) * p.lda;
+                    float acc2 = 0.f;
+                    for (int kk = 0; kk < p.K; kk += 8) {
+                        const f16x8 v = *reinterpret_cast<const f16x8*>(ar + kk);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { const float dlt = (float)v[e] - mean; acc2 = __builtin_fmaf(dlt, dlt, acc2); }
+                    }
+                    var = acc2 * inv_k;
+                }
                 const float rstd = rsqrtf(var + p.ln_eps);
                 *reinterpret_cast<f32x2*>(table + 2 * row) = (f32x2){mean, rstd};
                 if (nt == 0 && m0 + row < p.M) *reinterpret_cast<f32x2*>(p.ln_stats_w + 2 * (long long)(m0 + row)) = (f32x2){mean, rstd};
@@ -464,7 +478,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_big_kernel(GemmK p) {
         if (tl && tid == 0) tl[2] = __builtin_amdgcn_s_memrealtime();
         xattn_epilogue_big<TM>(p, acc, smem, wv, wm, wn, l, m0, n0, ln_lds);
     } else {
-        wave_epilogue<TM, TN, true>(p, acc, smem, wv, wm, wn, l, m0, n0, split, tl, ln_lds);
+        wave_epilogue<TM, TN, true, CARRY>(p, acc, smem, wv, wm, wn, l, m0, n0, split, tl, ln_lds);
     }
     if (tl) {                                    // last wave out writes the end stamp (stores of this wave are issued, not drained)
         __syncthreads();
@@ -472,17 +486,17 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_big_kernel(GemmK p) {
     }
 }
 
-template <int MODE, int WM, int WN, int TM, int TN, bool XATTN = false>
+template <int MODE, int WM, int WN, int TM, int TN, bool XATTN = false, bool CARRY = false>
 int launch_one(const GemmK& k, hipStream_t st) {
     constexpr int smem0 = 2 * (WM * TM * 32 + WN * TN * 32) * 128;
     constexpr int smem = XATTN && XA_SMEM > smem0 ? XA_SMEM : smem0;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_big_kernel<MODE, WM, WN, TM, TN, XATTN>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_big_kernel<MODE, WM, WN, TM, TN, XATTN, CARRY>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_big_kernel<MODE, WM, WN, TM, TN, XATTN>), dim3(k.nbm * k.nbn, k.ksplit, 1), dim3(WM * WN * 64), smem, st, k);
+    hipLaunchKernelGGL((gemm_big_kernel<MODE, WM, WN, TM, TN, XATTN, CARRY>), dim3(k.nbm * k.nbn, k.ksplit, 1), dim3(WM * WN * 64), smem, st, k);
     ICD_CHECK_LAUNCH("icd_gemm(big tile)");
     return ICD_OK;
 }
@@ -494,16 +508,19 @@ namespace icd_gemm_detail {
 // k.nbm / k.nbn / k.ksplit / k.kt_per_split are set by the caller for the tile of configuration `cfg` (BIG_TILES[])
 int launch_big(const GemmK& k, int cfg, hipStream_t st) {
     const bool conv = k.ksize > 0 && k.Hout > 0;
+    // launches with an error carry (the residual adds of the executor) have their own instantiation; with split-K the carry is the
+    // reduce kernel's business and the tile kernel is the plain one
+    const bool carry = (k.out_c || k.resid_c) && k.ksplit == 1;
+#define ICD_BIG(WM, WN, TM, TN)                                                                                                    \
+    (carry ? (conv ? launch_one<1, WM, WN, TM, TN, false, true>(k, st) : launch_one<0, WM, WN, TM, TN, false, true>(k, st))        \
+           : (conv ? launch_one<1, WM, WN, TM, TN>(k, st) : launch_one<0, WM, WN, TM, TN>(k, st)))
     switch (cfg) {
-    case 0:   // 256 x 256: 2 x 4 waves of 128 x 64 (GEGLU capable)
-        return conv ? launch_one<1, 2, 4, 4, 2>(k, st) : launch_one<0, 2, 4, 4, 2>(k, st);
-    case 1:   // 256 x 320: 4 x 2 waves of 64 x 160
-        return conv ? launch_one<1, 4, 2, 2, 5>(k, st) : launch_one<0, 4, 2, 2, 5>(k, st);
-    case 2:   // 192 x 256: 2 x 4 waves of 96 x 64 (GEGLU capable) - chip fill for M = 8192-class layers
-        return conv ? launch_one<1, 2, 4, 3, 2>(k, st) : launch_one<0, 2, 4, 3, 2>(k, st);
-    case 3:   // 128 x 320: 4 x 2 waves of 32 x 160
-        return conv ? launch_one<1, 4, 2, 1, 5>(k, st) : launch_one<0, 4, 2, 1, 5>(k, st);
+    case 0: return ICD_BIG(2, 4, 4, 2);   // 256 x 256: 2 x 4 waves of 128 x 64 (GEGLU capable)
+    case 1: return ICD_BIG(4, 2, 2, 5);   // 256 x 320: 4 x 2 waves of 64 x 160
+    case 2: return ICD_BIG(2, 4, 3, 2);   // 192 x 256: 2 x 4 waves of 96 x 64 (GEGLU capable) - chip fill for M = 8192-class layers
+    case 3: return ICD_BIG(4, 2, 1, 5);   // 128 x 320: 4 x 2 waves of 32 x 160
     }
+#undef ICD_BIG
     if (cfg == 100)   // query projection + cross-attention in one launch (icd_gemm_desc.xattn_*): 256 x 256 = 256 queries x 4 heads
         return launch_one<0, 2, 4, 4, 2, true>(k, st);
     icd_set_error("icd_gemm: unknown big-tile configuration %d", cfg);

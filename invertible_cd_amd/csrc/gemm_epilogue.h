@@ -121,7 +121,10 @@ __device__ __forceinline__ void wave_epilogue_fast(const GemmK& p, f32x16 (&acc)
 
 // acc[i][j]: 32x32 MFMA tile (i = 32-row group of the wave's rows, j = 32-column group), wave (wm, wn) of a WM x WN grid
 // whose wave tile is (TM*32) x (TN*32); m0 / n0: origin of the block tile.  All waves of the block must call it.
-template <int TM, int TN, bool FAST_OK = true>
+// CARRY: the instantiation that serves launches with an error carry (p.resid_c / p.out_c, ksplit == 1); the default instantiation
+// carries no trace of it (as a run-time branch in ONE kernel the two extra variants cost the plain launches 1 - 3 %: registers,
+// code size).
+template <int TM, int TN, bool FAST_OK = true, bool CARRY = false>
 __device__ __forceinline__ void wave_epilogue(const GemmK& p, f32x16 (&acc)[TM][TN], unsigned char* smem, int wv, int wm, int wn,
                                               int l, int m0, int n0, int split, unsigned long long* tl, const float* ln_lds = nullptr) {
     const int lr = l & 31, lh = l >> 5;
@@ -135,13 +138,14 @@ __device__ __forceinline__ void wave_epilogue(const GemmK& p, f32x16 (&acc)[TM][
     if (tl && tid == 0) tl[2] = __builtin_amdgcn_s_memrealtime();
     float* wst = reinterpret_cast<float*>(smem) + wv * (trans ? 64 * LDT : 32 * LDW);
     float* part = p.ksplit > 1 ? p.partial + (long long)split * p.M * p.N : nullptr;
-    if constexpr (FAST_OK)
+    if constexpr (FAST_OK && CARRY)
     if (!trans && !geglu && !part && !out_f32 && !p.out32 && p.out_c && !p.rowbias && !p.ln_stats && !(p.flags & ICD_GEMM_RESID_F32)) {
         // the executor's carried residual stream: h <- h + f with the rounding error of the sum kept beside it, or the start of a chain
         if (p.resid && p.resid_c) { wave_epilogue_fast<TM, TN, true, false, false, true, true>(p, acc, wst, wm, wn, l, m0, n0, ln_lds); return; }
         if (!p.resid) { wave_epilogue_fast<TM, TN, false, false, false, false, true>(p, acc, wst, wm, wn, l, m0, n0, ln_lds); return; }
     }
-    if (FAST_OK && !trans && !geglu && !part && !out_f32 && !p.out32 && !p.out_c && !p.resid_c && !(p.flags & ICD_GEMM_RESID_F32)) {
+    if constexpr (!CARRY)
+    if (FAST_OK && !trans && !geglu && !part && !out_f32 && !p.out32 && !(p.flags & ICD_GEMM_RESID_F32)) {
         // fast path of the common epilogue, specialised by which operands exist (wave-uniform switch around the whole wave tile)
         switch ((p.resid ? 1 : 0) | (p.rowbias ? 2 : 0) | (p.ln_stats ? 4 : 0)) {
             case 0: wave_epilogue_fast<TM, TN, false, false, false>(p, acc, wst, wm, wn, l, m0, n0, ln_lds); break;   // plain / bias only
@@ -295,7 +299,7 @@ __device__ __forceinline__ void wave_epilogue(const GemmK& p, f32x16 (&acc)[TM][
                         f16x8 rs = *reinterpret_cast<const f16x8*>(p.resid + (long long)m * p.ldr + n);
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] += (float)rs[e];
-                        if (p.resid_c) carry_add8(v, p.resid_c + (long long)m * p.ldr + n);
+                        if constexpr (CARRY) { if (p.resid_c) carry_add8(v, p.resid_c + (long long)m * p.ldr + n); }
                         }
                     }
                     if (p.out32) {
@@ -312,7 +316,7 @@ __device__ __forceinline__ void wave_epilogue(const GemmK& p, f32x16 (&acc)[TM][
 #pragma unroll
                         for (int e = 0; e < 8; ++e) o[e] = (half_t)v[e];
                         *reinterpret_cast<f16x8*>(reinterpret_cast<half_t*>(p.out) + (long long)m * p.ldo + n) = o;
-                        if (p.out_c) *reinterpret_cast<u32x2*>(p.out_c + (long long)m * p.ldo + n) = carry_of8(v, o);
+                        if constexpr (CARRY) { if (p.out_c) *reinterpret_cast<u32x2*>(p.out_c + (long long)m * p.ldo + n) = carry_of8(v, o); }
                     }
                 }
             }

@@ -41,8 +41,14 @@ def init(backend=None, timeout_s=None):
     os.environ.setdefault('WORLD_SIZE', '1')
     if 'MASTER_PORT' not in os.environ:
         if int(os.environ['WORLD_SIZE']) > 1:
-            raise RuntimeError('dist_utils.init: WORLD_SIZE > 1 needs the launcher\'s MASTER_PORT (torchrun / bench.py --gpus N set it)')
-        os.environ['MASTER_PORT'] = str(_free_port())
+            # every rank must agree on the port, so nothing can be picked here: the reference's fixed default (utils/dist_utils.py:11-12)
+            # keeps launchers that export only RANK / WORLD_SIZE / MASTER_ADDR (srun, mpirun wrappers) working - said out loud, because
+            # a stale listener on 29500 is the usual reason such a run hangs at the rendezvous
+            import warnings
+            warnings.warn('dist_utils.init: WORLD_SIZE > 1 without MASTER_PORT - meeting on the reference\'s default port 29500')
+            os.environ['MASTER_PORT'] = '29500'
+        else:
+            os.environ['MASTER_PORT'] = str(_free_port())
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     if backend is None:
         backend = 'nccl' if torch.cuda.is_available() else 'gloo'
@@ -64,13 +70,15 @@ def prepare_val_prompts(all_text, bs=20, max_cnt=5000):
     return batches, index, all_text
 
 
-def gather_samples(local, local_ids):
+def gather_samples(local, local_ids, always_collective=False):
     """ONE all-gather of this rank's finished samples + their global ids (running/sd1.5/generate.py:372-378), then
     reorder by id (:386-397).  `local`: [N_local, ...] tensor (uint8 images or fp16 latents), `local_ids`: int64 [N_local].
     Every rank must contribute the same N_local (the reference has the same equal-shape requirement).
-    Returns (samples ordered by global id, sorted ids) on every rank."""
+    Returns (samples ordered by global id, sorted ids) on every rank.  A single process skips the collective unless
+    `always_collective` is set and a process group exists (the reference always calls all_gather; a world of one then runs the real
+    RCCL all-gather on its one GPU - how the collective path is exercised on a 1-GPU box)."""
     W = get_world_size()
-    if W == 1:
+    if W == 1 and not (always_collective and dist.is_available() and dist.is_initialized()):
         order = torch.argsort(local_ids)
         return local[order], local_ids[order]
     bufs = [torch.empty_like(local) for _ in range(W)]

@@ -90,6 +90,7 @@ class StableDiffusionXLPipeline:
         self._execution_device = torch.device(device)
         self.device = self._execution_device
         self.image_processor = _ImageProcessor()
+        self.force_zeros_for_empty_prompt = True     # SDXL-base's pipeline config (diffusers): see encode_prompt
 
     def to(self, device=None, dtype=None):
         if device is not None:
@@ -141,8 +142,13 @@ class StableDiffusionXLPipeline:
         emb, pooled = run(texts)
         neg = neg_pooled = None
         if do_classifier_free_guidance:
-            negs = [negative_prompt or ""] * len(texts) if not isinstance(negative_prompt, (list, tuple)) else list(negative_prompt)
-            neg, neg_pooled = run(negs)
+            if negative_prompt is None and getattr(self, "force_zeros_for_empty_prompt", True):
+                # diffusers' SDXL pipelines (config.force_zeros_for_empty_prompt, True for SDXL-base): no negative prompt means ZERO
+                # negative embeddings and pooled output, not the encoding of the empty string
+                neg, neg_pooled = torch.zeros_like(emb), None if pooled is None else torch.zeros_like(pooled)
+            else:
+                negs = [negative_prompt or ""] * len(texts) if not isinstance(negative_prompt, (list, tuple)) else list(negative_prompt)
+                neg, neg_pooled = run(negs)
         return rep(emb.to(self.unet.dtype)), rep(None if neg is None else neg.to(self.unet.dtype)), rep(pooled), rep(neg_pooled)
 
 

@@ -286,9 +286,21 @@ class UNet2DConditionModel:
 
     def reset_context_cache(self):
         """Forget the cached context K / V projections: the next forward recomputes them whatever tensor it is handed.  (The cache
-        keys on the context tensor's identity and version; a caller that reuses ONE tensor object for a new batch of prompts without
-        an in-place write - or a benchmark that wants every batch to pay for its projections - calls this at the batch boundary.)"""
+        keys on the context tensor's identity and version counter; a caller that rewrites ONE tensor object through a raw pointer - a
+        ctypes kernel of this library writing into it as an `out=` buffer, a DLPack alias - or a benchmark that wants every batch to
+        pay for its projections calls this at the batch boundary.  In-place torch ops bump the version counter and need no call.)"""
         self._kv = None
+
+    @staticmethod
+    def _ctx_version(ctx):
+        """Version counter of the context tensor, or None where torch does not track one (inference tensors: reading `_version`
+        raises) - None never hits the cache."""
+        try:
+            if ctx.is_inference():
+                return None
+            return ctx._version
+        except RuntimeError:
+            return None
 
     @torch.no_grad()
     def __call__(self, sample, timestep, encoder_hidden_states=None, class_labels=None, timestep_cond=None,
@@ -348,20 +360,25 @@ class UNet2DConditionModel:
         io.hook = hook
         if self.kv_cache_enabled:
             kv, stream_id = self._kv, torch.cuda.current_stream().cuda_stream
-            hit = (kv is not None and kv[0].data_ptr() == ctx.data_ptr() and kv[0].shape == ctx.shape and kv[0].stride() == ctx.stride()
-                   and kv[0]._version == ctx._version == kv[1] and kv[3] == stream_id)       # (filled and read on ONE stream)
+            ver = self._ctx_version(ctx)
+            # a hit needs the SAME storage, layout and version counter as the forward that filled the cache, on the same stream (filled and
+            # read in stream order).  Tensors without a version counter (created under torch.inference_mode()) never hit.  The key cannot
+            # see writes made through raw pointers - e.g. this library's own kernels writing into an `out=` tensor that is later handed
+            # in as the context: such callers call reset_context_cache() (see its docstring).
+            hit = (kv is not None and ver is not None and kv[0].data_ptr() == ctx.data_ptr() and kv[0].shape == ctx.shape
+                   and kv[0].stride() == ctx.stride() and kv[1] == ver and kv[3] == stream_id)
             if not hit:
                 nbytes = self._lib.icd_unet_kv_cache_bytes(self._h, B, n_ctx)
                 buf = kv[2] if kv is not None and kv[2].numel() == nbytes else torch.empty((nbytes,), dtype=torch.uint8, device=dev)
-                self._kv = kv = (ctx, ctx._version, buf, stream_id)
+                self._kv = kv = (ctx, ver, buf, stream_id)
             io.kv_cache, io.kv_cache_bytes, io.kv_cache_valid = kv[2].data_ptr(), kv[2].numel(), int(hit)
         rc = self._lib.icd_unet_forward(self._h, C.byref(io), C.c_void_p(torch.cuda.current_stream().cuda_stream))
         # the probability buffers handed in by the hook stay referenced until the NEXT call (cleared at its start): the launch is
         # asynchronous, and freeing them here would rely on every later consumer of the allocator running on this same stream
+        if rc != 0 or errors:
+            self._kv = None                      # a failed forward (also one aborted by a hook's exception) may have left the cache half written
         if errors:
             raise errors[0]
-        if rc != 0:
-            self._kv = None                      # a failed forward may have left the cache half written
         _lib.check(rc, "icd_unet_forward")
         if not return_dict:
             return (eps,)

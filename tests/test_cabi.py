@@ -106,3 +106,34 @@ def test_header_is_plain_c_and_the_ctypes_mirrors_have_its_layout(tmp_path):
         assert got[(cname, "size")] == ctypes.sizeof(cls), cname
         for fname, *_ in cls._fields_:
             assert got[(cname, fname)] == getattr(cls, fname).offset, f"{cname}.{fname}"
+
+
+def test_the_library_carries_the_digest_of_its_sources_and_a_stale_one_is_refused(monkeypatch):
+    """icd_build_sha(): the sha of csrc/ is compiled INTO the .so by build.py; _lib.load() compares it with the sources next to it
+    (bench.py reports it as roofline.kernels_sha) - an edited-but-not-rebuilt tree cannot run, let alone report a digest it did not
+    execute.  A library selected with ICD_AMD_LIB (another build, for A/B) is exempt."""
+    from invertible_cd_amd import build
+    lib = _lib.load()
+    sha = lib.icd_build_sha().decode()
+    assert re.fullmatch(r"[0-9a-f]{12}", sha) and sha == build.source_sha() == _lib.build_sha()
+    monkeypatch.setattr(_lib, "_lib", None)                     # force a fresh load against "edited" sources
+    monkeypatch.setattr(build, "source_sha", lambda: "0" * 12)
+    with pytest.raises(RuntimeError, match="was built from kernel sources"):
+        _lib.load()
+    monkeypatch.setenv("ICD_AMD_LIB", _lib.LIB_PATH)
+    assert _lib.load() is not None
+    monkeypatch.setattr(_lib, "_lib", lib)
+
+
+def test_context_cache_key_survives_inference_mode():
+    """Inference tensors have no version counter (`_version` raises): such a context never hits the K / V cache instead of crashing
+    every forward under torch.inference_mode()."""
+    import torch
+    from invertible_cd_amd.unet import UNet2DConditionModel as U
+    t = torch.zeros(2, 3)
+    assert U._ctx_version(t) == t._version
+    t.add_(1)
+    assert U._ctx_version(t) == 1
+    with torch.inference_mode():
+        ti = torch.zeros(2, 3)
+    assert U._ctx_version(ti) is None

@@ -107,19 +107,33 @@ def test_bench_timed_leg_world2_takes_the_max_over_ranks_and_gathers_every_sampl
     assert [r[:2] for r in res] == [(0, True), (1, True)] and res[0][2] == res[1][2]
 
 
-def test_dist_init_picks_a_free_port_and_refuses_a_multi_rank_run_without_one(monkeypatch):
+def test_dist_init_picks_a_free_port_alone_and_the_reference_default_for_a_multi_rank_run(monkeypatch):
+    """A lone process takes a port that is free right now; WORLD_SIZE > 1 without MASTER_PORT (launchers that export only RANK /
+    WORLD_SIZE / MASTER_ADDR) meets on the reference's fixed 29500 (utils/dist_utils.py:11-12) and says so - every rank must agree on
+    the port, so nothing can be picked there."""
     from invertible_cd_amd import dist_utils
     import pytest
     for k in ("MASTER_PORT", "MASTER_ADDR", "RANK", "LOCAL_RANK"):
         monkeypatch.delenv(k, raising=False)
     monkeypatch.setenv("WORLD_SIZE", "2")
-    with pytest.raises(RuntimeError, match="MASTER_PORT"):
+    called = {}
+    monkeypatch.setattr(dist, "init_process_group", lambda **kw: called.update(kw))       # (no second rank will ever come)
+    with pytest.warns(UserWarning, match="29500"):
         dist_utils.init(backend="gloo")
+    assert os.environ["MASTER_PORT"] == "29500" and called["backend"] == "gloo" and called["init_method"] == "env://"
+    monkeypatch.undo()
+    for k in ("MASTER_PORT", "MASTER_ADDR", "RANK", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
     monkeypatch.setenv("WORLD_SIZE", "1")
     monkeypatch.setenv("HSA_ENABLE_IPC_MODE_LEGACY", "7")            # a value the launcher chose is kept
     dist_utils.init(backend="gloo", timeout_s=30)
     try:
-        assert int(os.environ["MASTER_PORT"]) > 1024 and os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] == "7"
+        assert int(os.environ["MASTER_PORT"]) > 1024 and os.environ["MASTER_PORT"] != "29500" and os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] == "7"
         assert dist.is_initialized() and dist.get_world_size() == 1
+        # a world of one can still run the collective (what the GPU box does with backend "nccl"): same result as the shortcut
+        x, ids = torch.arange(12.0).reshape(3, 4), torch.tensor([2, 0, 1])
+        a, ai = dist_utils.gather_samples(x, ids)
+        b, bi = dist_utils.gather_samples(x, ids, always_collective=True)
+        assert torch.equal(a, b) and torch.equal(ai, bi) and torch.equal(ai, torch.arange(3))
     finally:
         dist.destroy_process_group()

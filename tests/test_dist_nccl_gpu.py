@@ -1,6 +1,8 @@
 """The N > 1 path on real GPUs: one process per GPU, backend "nccl" (= RCCL on ROCm), the ONE end-of-run all-gather of
 uint8 images + int64 ids (running/sd1.5/generate.py:372-397), and `bench.py --gpus 2` spawning its own ranks.
-Skipped on a single-GPU box (the driver's multi-GPU tier and the CPU gloo test tests/test_dist_gloo.py cover it there)."""
+The world-2 cases skip on a single-GPU box; the world-1 cases run everywhere: a process group of ONE rank on backend "nccl" executes
+the real RCCL bootstrap and the real all_gather kernels on the one GPU (no W == 1 shortcut), alone and under torchrun - so the
+collective of utils/dist_utils.py:8-22 / running/sd1.5/generate.py:372-383 has run on hardware before the driver's 8-GPU tier."""
 import json
 import os
 import subprocess
@@ -24,13 +26,14 @@ assert dist.get_backend() == "nccl" and torch.cuda.current_device() == int(os.en
 n = 3
 ids = torch.arange(n, device="cuda", dtype=torch.int64) * W + r            # round-robin ownership, like prepare_val_prompts
 imgs = (ids[:, None, None, None] % 251).to(torch.uint8).expand(n, 64, 64, 3).contiguous()
-allx, alli = dist_utils.gather_samples(imgs, ids)
+allx, alli = dist_utils.gather_samples(imgs, ids, always_collective=True)       # (a world of one still runs the RCCL all-gather)
 assert allx.dtype == torch.uint8 and allx.shape == (n * W, 64, 64, 3)
 assert torch.equal(alli, torch.arange(n * W, device="cuda"))
 assert torch.equal(allx[:, 0, 0, 0].long(), torch.arange(n * W, device="cuda") % 251)
 dist.barrier()
+maps = open("/proc/self/maps").read()
 if r == 0:
-    print("NCCL_GATHER_OK", W)
+    print("NCCL_GATHER_OK", W, "rccl_mapped" if "librccl" in maps else "rccl_not_in_maps", torch.cuda.nccl.version())
 dist.destroy_process_group()
 '''
 
@@ -48,6 +51,43 @@ def _free_port():
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
         sk.bind(("127.0.0.1", 0))
         return sk.getsockname()[1]
+
+
+def test_world1_rccl_all_gather_runs_on_this_gpu(tmp_path):
+    """dist_utils.init("nccl") in a lone process (its own free port) + gather_samples through the real all_gather."""
+    w = tmp_path / "worker.py"
+    w.write_text(WORKER)
+    env = _env()
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, str(w)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "NCCL_GATHER_OK 1" in r.stdout
+    assert "rccl_mapped" in r.stdout, r.stdout[-500:]             # librccl.so is mapped into the process that ran the collective
+
+
+def test_world1_under_torchrun(tmp_path):
+    """The launcher path at N = 1: torch.distributed.run sets RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*; same worker."""
+    w = tmp_path / "worker.py"
+    w.write_text(WORKER)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), str(w)]
+    r = subprocess.run(cmd, env=_env(), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "NCCL_GATHER_OK 1" in r.stdout
+
+
+def test_bench_under_torchrun_at_one_gpu_reports_rccl():
+    """`torchrun --nproc-per-node 1 bench.py --gpus 1`: the driver's launch line at N = 1.  The line must carry the rccl object of a
+    world of one whose end-of-run all-gather went through RCCL."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1", "--batch", "4",
+           "--no-cpu-baseline", "--no-vae", "--no-ref-batching", "--no-sdxl", "--no-edit"]
+    r = subprocess.run(cmd, env=_env(), capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and d["value"] > 0
+    assert d["rccl"]["rccl_world_size"] == 1 and d["rccl"]["backend"] == "nccl" and d["rccl"]["all_gather_executed"] is True
 
 
 @needs2

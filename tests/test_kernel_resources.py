@@ -17,10 +17,30 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 pytestmark = pytest.mark.skipif(not os.path.exists(HIPCC) and shutil.which("hipcc") is None, reason="no hipcc on this box")
 
 
-def _descriptors(src, extra=()):
+def _main_loop_scratch(asm, kernel):
+    """Scratch (spill) instructions inside the loops of `kernel` that issue MFMAs - the main loop; spills elsewhere (one epilogue
+    variant of many) cost nothing unless that variant runs."""
+    lines = asm.split("\n")
+    i0 = next(i for i, l in enumerate(lines) if l.startswith(kernel + ":"))
+    i1 = next(i for i in range(i0, len(lines)) if lines[i].startswith("\ts_endpgm"))
+    body = lines[i0:i1]
+    labels = {m.group(1): i for i, l in enumerate(body) for m in [re.match(r"^(\.LBB\d+_\d+):", l)] if m}
+    worst = 0
+    for i, l in enumerate(body):
+        m = re.search(r"s_c?branch\w* (\.LBB\d+_\d+)", l)
+        if m and m.group(1) in labels and labels[m.group(1)] < i:
+            loop = body[labels[m.group(1)]:i]
+            if sum("v_mfma" in x for x in loop) >= 16:
+                worst = max(worst, sum("scratch_" in x for x in loop))
+    return worst
+
+
+def _descriptors(src, extra=(), main_loops=False):
     out = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-x", "hip", "-S", "--cuda-device-only", "-o", "-",
                           *extra, os.path.join(ROOT, "invertible_cd_amd", "csrc", src)], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
+    if main_loops:
+        return out.stdout
     meta = out.stdout[out.stdout.index("amdhsa.kernels:"):]
     kernels = {}
     for blk in re.split(r"\n  - ", meta)[1:]:
@@ -33,11 +53,15 @@ def _descriptors(src, extra=()):
 
 def test_gemm_big_tiles_keep_their_register_budget():
     ks = _descriptors("gemm_big.hip")
+    asm = _descriptors("gemm_big.hip", main_loops=True)
     tiles = {n: v for n, v in ks.items() if "gemm_big_kernel" in n}
-    assert len(tiles) == 9
+    assert len(tiles) == 17                                     # 4 tiles x {dense, conv} x {plain, error carry} + the fused cross-attention host
     for n, v in tiles.items():
-        m = re.search(r"gemm_big_kernelILi(\d)ELi(\d)ELi(\d)ELi(\d)ELi(\d)ELb(\d)E", n)
-        mode, wm, wn, tm, tn, xattn = map(int, m.groups())
+        # whatever the epilogue variants spill, the MFMA loop touches no scratch - except the 256 x 320 conv tile (160 accumulators + the
+        # im2col loader state), which reloads two loop invariants per k-tile (one in round 3)
+        assert _main_loop_scratch(asm, n) <= (4 if "ILi1ELi4ELi2ELi2ELi5E" in n else 0), n
+        m = re.search(r"gemm_big_kernelILi(\d)ELi(\d)ELi(\d)ELi(\d)ELi(\d)ELb(\d)ELb(\d)E", n)
+        mode, wm, wn, tm, tn, xattn, carry = map(int, m.groups())
         assert v["vgpr_count"] <= 256
         if xattn:
             # (until round 3 the 48 loop-invariant key-mask predicates of its softmax epilogue sat in scalar registers: 181 spilt)
@@ -45,7 +69,9 @@ def test_gemm_big_tiles_keep_their_register_budget():
         elif tm * tn <= 8:
             assert v["vgpr_spill_count"] == 0 and v["sgpr_spill_count"] == 0, (n, v)      # 256 x 256, 192 x 256, 128 x 320
         else:
-            # 256 x 320 (160 accumulators): a few spills in the general epilogue only; the main loop carries one reload per 2 k-tiles
+            # 256 x 320 (160 accumulators): a few spills in the epilogue variants (14 dense / 31 conv; the error-carry instantiations
+            # 22 / 32) - the carry variants live in their own instantiation because as two more branches of ONE kernel they took the
+            # dense tile to 76 spilt registers and the plain launches 1 - 3 % (round 4)
             assert v["vgpr_spill_count"] <= 40 and v["sgpr_spill_count"] == 0, (n, v)
 
 

@@ -73,7 +73,7 @@ def test_load_models_from_disk_matches_oracle_fused_weights(tmp_path):
         errs[name + "_vs_unfused"] = _check(pipe.unet, cfg, full, 2, False)
     print("[loader sd15] (error, fp16-torch floor):", {k: f"{e:.3e}/{f:.3e}" for k, (e, f) in errs.items()})
     for k in ("teacher", "reverse", "forward"):
-        assert errs[k][0] <= 1.5 * errs[k][1] + 1e-4 and errs[k][0] < 4e-3, (k, errs[k])
+        assert errs[k][0] <= 1.5 * errs[k][1] + 1e-4 and errs[k][0] < 1.2e-3, (k, errs[k])     # measured 0.73 - 0.83e-3
     assert errs["reverse_vs_unfused"][0] > 1e-2 and errs["forward_vs_unfused"][0] > 1e-2     # the LoRA really changed the function
 
 
@@ -92,7 +92,7 @@ def test_load_models_xl_from_disk_matches_oracle_fused_weights(tmp_path):
            "forward": _check(forw.unet, cfg, fused_f, 4, True), "reverse_vs_unfused": _check(pipe.unet, cfg, full, 4, True)}
     print("[loader sdxl] (error, fp16-torch floor):", {k: f"{e:.3e}/{f:.3e}" for k, (e, f) in res.items()})
     for k in ("teacher", "reverse", "forward"):
-        assert res[k][0] <= 1.5 * res[k][1] + 1e-4 and res[k][0] < 4e-3, (k, res[k])
+        assert res[k][0] <= 1.5 * res[k][1] + 1e-4 and res[k][0] < 1.2e-3, (k, res[k])       # measured 0.80 - 0.99e-3 (the fused LoRA widens the activations)
     assert res["reverse_vs_unfused"][0] > 1e-2
 
 

@@ -5,12 +5,15 @@ Inputs are fp16-representable (so both sides see identical values); the HIP kern
 once to fp16, hence the tolerance: rel-L2 <= 1e-3 (fp16 has an 11-bit significand: 4.9e-4 relative rounding).
 """
 import math
+import os
 
 import pytest
 import torch
 import torch.nn.functional as F
 
 from conftest import rel_l2
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-3
@@ -158,6 +161,52 @@ def test_gemm_computes_the_layernorm_statistics_it_applies(M, C, N, flags, geglu
     out2 = ops.gemm(x.cuda(), w16.cuda(), bias=t.cuda(), ln_stats=st, ln_colsum=s.cuda(), debug_flags=flags & ~0x800000) if not geglu else None
     if out2 is not None:
         assert rel_l2(out2, want) < 1.5e-3
+
+
+@pytest.mark.parametrize("ratio", [50.0, 3.0, 0.0])
+@pytest.mark.parametrize("M,C,N,flags", [(1024, 640, 1280, 0), (2048, 320, 320, 0x100000), (512, 1280, 1280, 3 << 24)])
+def test_in_loop_layernorm_statistics_survive_a_large_row_offset(M, C, N, flags, ratio):
+    """ICD_GEMM_LN_COMPUTE on the big tiles sums x and x^2 of each row from the MFMA operand fragments (one pass).  E[x^2] - mean^2
+    cancels when a row's offset dominates its spread: at |mean| / sigma = 50 the one-pass variance alone is off by ~2.5e-3.  Rows with
+    |mean| > 4 sigma take an exact second pass in the kernel; asserted here: rstd within 1e-5 (relative) of an fp64 reference at
+    |mean| / sigma = 50, 3 (one-pass side of the switch) and 0, and the normalised product against torch."""
+    ops = _ops()
+    gen = torch.Generator().manual_seed(391)
+    sigma = 0.5
+    x = (torch.randn(M, C, generator=gen) * sigma + ratio * sigma * (1 + 0.1 * torch.randn(M, 1, generator=gen))).half()
+    gamma, beta = 1 + 0.2 * torch.randn(C, generator=gen), 0.3 * torch.randn(C, generator=gen)
+    w = torch.randn(N, C, generator=gen) * C ** -0.5
+    b = torch.randn(N, generator=gen)
+    w16, s, t = ops.fold_layernorm(w, gamma, beta, b)
+    st = torch.full((M, 2), float("nan"), device="cuda")
+    d = _lib_plan(ops, M, N, C, flags)
+    assert d.ln_inline == 1 and d.kernel == 1, "this case must take the in-loop statistics of a big tile"
+    out = ops.gemm(x.cuda(), w16.cuda(), bias=t.cuda(), ln_stats=st, ln_colsum=s.cuda(), ln_compute=True, debug_flags=flags)
+    xd = x.double()
+    mean = xd.mean(1)
+    rstd = 1.0 / torch.sqrt(xd.var(1, unbiased=False) + 1e-5)
+    e_mean = float(((st[:, 0].cpu().double() - mean).abs() / mean.abs().clamp_min(sigma)).max())
+    e_rstd = float(((st[:, 1].cpu().double() - rstd).abs() / rstd).max())
+    print(f"[LN statistics in the main loop, |mean|/sigma = {ratio}: {M}x{C}] max rel error mean {e_mean:.2e} rstd {e_rstd:.2e}")
+    assert e_mean < 1e-5 and e_rstd < 1e-5
+    want = F.layer_norm(x.float(), (C,), gamma, beta, 1e-5) @ w.t() + b
+    # (the rank-1 mean correction of the folded form subtracts two numbers ~ ratio times the result: its fp32 rounding grows with the ratio)
+    assert rel_l2(out, want) < (1.5e-3 if ratio <= 3 else 5e-3)
+
+
+def _lib_plan(ops, M, N, K, flags):
+    """icd_gemm_plan of a dense LN_COMPUTE launch of this shape."""
+    import ctypes as C
+    from invertible_cd_amd import _lib
+    d = _lib.GemmDesc()
+    buf = torch.empty(8, device="cuda")
+    d.a0 = d.w = d.out = buf.data_ptr()
+    d.ln_stats = d.ln_colsum = buf.data_ptr()
+    d.M, d.N, d.K, d.Nw, d.lda, d.ldw, d.ldo = M, N, K, N, K, K, N
+    d.mode, d.batch, d.zdiv, d.alpha, d.flags = 0, 1, 1, 1.0, flags | _lib.ICD_GEMM_LN_COMPUTE
+    info = _lib.GemmPlanInfo()
+    _lib.check(_lib.load().icd_gemm_plan(C.byref(d), C.byref(info)), "icd_gemm_plan")
+    return info
 
 
 @pytest.mark.parametrize("cfg", [
@@ -734,3 +783,14 @@ def test_attention_probs_one_pass(B, H, Nq, Nk, d):
     S = ops.attention_scores(q.cuda(), k.cuda(), B, H, Nq, Nk, d, scale, ld)
     P2 = ops.softmax_rows(S.reshape(B * H * Nq, ld), Nk, ld).reshape(B * H, Nq, ld)
     assert float((P.float() - P2.float()).abs().max()) < 2e-3
+
+
+def test_flash_attention_ring_is_bit_identical_to_a_fully_fenced_build():
+    """The flash kernels hand tiles over with a counted s_waitcnt vmcnt(N) + a bare s_barrier (attention.hip wait_landed); a miscounted
+    ring would read LDS rows that have not landed.  tools/attn_ring_check.py builds attention.hip again with a full fence at every tile
+    (-DICD_ATTN_DEBUG_SYNC) and runs ragged / causal / wide-head cases of every head dim on both libraries: same bits."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "attn_ring_check.py")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "cases bit-identical" in r.stdout and "DIFF" not in r.stdout

@@ -6,8 +6,14 @@ BASELINE configs covered here (reduced widths for the oracle-checked cases, full
   cfg 3  iCD-SD1.5 4-step forward inversion + 4-step reverse edit with p2p controllers (AttentionStore / AttentionReplace)
   cfg 4  iCD-SDXL 4-step reverse
   cfg 5  iCD-SDXL 3-step forward + 3-step reverse with dynamic guidance (tau < 1)
-Tolerances: rel-L2 <= 5e-3 on latents after 4-8 chained UNet evaluations (each evaluation is ~1.1e-3 from fp32, the
-boundary step at t=999 amplifies eps errors by sigma_t/alpha_t ~ 15), <= 2e-3 on attention-store tensors.
+Tolerances (round 4, residual stream with error carry - the default and the benchmarked mode): the north star's 1e-3 rel-L2 is
+asserted where the arithmetic can meet it - final latents of the reverse loops and EVERY attention-store tensor of a reverse pass,
+reduced width and full width (64x64 latents).  One evaluation is 0.70 - 0.85e-3 from the fp32 oracle (the floor of fp16 MFMA
+operands); the reverse loop contracts that (x0-prediction: 3e-4 after 4 steps), the FORWARD loops amplify it - every
+step adds its own eps error times (sigma_s - alpha_s sigma_t / alpha_t) ~ 0.7 on top of the propagated one - and land at 1.0 - 1.5e-3
+after 3 - 4 steps, the edit (8 evaluations, probabilities rewritten by the controller) at 1.2e-3 / 1.5e-3 on its store.  Those bars are
+stated next to each assert with the measured value; an fp16 diffusers-style pipeline (the oracle graph in fp16 torch) sits at 2 - 2.6e-3
+per evaluation on the same weights.
 """
 import numpy as np
 import pytest
@@ -43,8 +49,8 @@ def _tables(sched_ref):
     return np.sqrt(ac), np.sqrt(1 - ac)
 
 
-def _sd15_setup(E, B, H, W, seed):
-    cfg = E["SD15"].scaled((64, 128, 256, 256), cross_dim=64)
+def _sd15_setup(E, B, H, W, seed, full=False):
+    cfg = E["SD15"] if full else E["SD15"].scaled((64, 128, 256, 256), cross_dim=64)
     sd = {k: v.half().float() for k, v in E["synthetic"].synthetic_state_dict(cfg, seed=seed).items()}
     inp = E["synthetic"].synthetic_inputs(cfg, B, H, W, seed=seed)
     lat, ctx = inp["latents"].half().float(), inp["context"].half().float()
@@ -93,7 +99,7 @@ def test_sd15_reverse_with_attention_store(eliminate):
     ref = _oracle_loop(E, sd, cfg, lat.clone(), ctx, list(zip(REV_T, REV_S)), [[gs] * B] * 4, controller=ref_store)
     err = rel_l2(outs[-1], ref)
     print(f"[sd15 reverse, eliminate={eliminate}] rel-L2(latents) = {err:.3e}")
-    assert err < 1e-3                                # measured 4.1e-4 (profiles/r02_parity.txt); bar <= 2.5x for box-to-box plan changes
+    assert err < 1e-3                                # measured 2.9e-4 (4.1e-4 on the plain fp16 stream of rounds 1-3)
     assert store.cur_step == ref_store.cur_step == 4
     n_checked, worst = 0, 0.0
     for key, refs in ref_store.attention_store.items():
@@ -104,11 +110,53 @@ def test_sd15_reverse_with_attention_store(eliminate):
             assert tuple(gc.shape) == tuple(r.shape), (key, gc.shape, r.shape)
             e = rel_l2(gc, r)
             worst = max(worst, e)
-            assert e < 2e-3, (key, e)
+            assert e < 1e-3, (key, e)              # the north star's bar on every stored tensor (worst measured: 8.3e-4)
             n_checked += 1
     print(f"[sd15 reverse, eliminate={eliminate}] worst attention-store tensor rel-L2 = {worst:.3e}")
     # latent 32x32 -> query counts 1024,1024,256,256,64,64 down; 16 mid; up 64x3,256x3,1024x3: all <= 32^2 -> all 32 stored
     assert n_checked == 32
+
+
+@pytest.mark.slow
+def test_full_width_sd15_64x64_reverse_store_and_inversion_meet_1e3():
+    """SURVEY 8c(3) at full width: the 859.7 M-parameter SD1.5 UNet on 64 x 64 latents (512 x 512 images), B = 2, the benchmarked
+    residual mode.  (a) 4-step reverse with an AttentionStore: final latents and EVERY stored tensor (22 per pass at this size: the 32^2,
+    16^2 and 8^2 layers) within 1e-3 of the fp32 oracle loop; (b) the 4-step forward inversion: reported, bar 1.3e-3 (see the header).
+    2 x 6.4 TFLOP of CPU oracle."""
+    E = _env()
+    p2p = E["p2p"]
+    B, H, W, gs = 2, 64, 64, 7.0
+    cfg, sd, lat, ctx, model, solver = _sd15_setup(E, B, H, W, seed=15, full=True)
+    store = p2p.AttentionStore()
+    p2p.register_attention_control(model, store)
+    outs = solver.cons_generation(lat.cuda(), guidance_scale=gs, w_embed_dim=512, dynamic_guidance=False, tau1=1.0, tau2=1.0,
+                                  controller=store)
+    ref_store = p2p.AttentionStore()
+    ref_store.num_att_layers = 32
+    # B == 2 -> the CFG-doubled batch of 4 takes the [0, 0, 0, gs] branch of the w vector (utils/generation.py:232-233): cond rows [0, gs]
+    ref = _oracle_loop(E, sd, cfg, lat.clone(), ctx, list(zip(REV_T, REV_S)), [[0.0, gs]] * 4, controller=ref_store)
+    err = rel_l2(outs[-1], ref)
+    worst, n = 0.0, 0
+    for key, refs in ref_store.attention_store.items():
+        got = store.attention_store[key]
+        assert len(got) == len(refs), key
+        for g, r in zip(got, refs):
+            e = rel_l2(g, r)
+            worst, n = max(worst, e), n + 1
+            assert e < 1e-3, (key, tuple(r.shape), e)
+    print(f"[sd15 full width 64x64 reverse] rel-L2(latents) = {err:.3e}, worst of {n} attention-store tensors = {worst:.3e}")
+    assert err < 1e-3 and n == 22
+    p2p.register_attention_control(model, None)
+    del store, ref_store
+    solver.latent2image = lambda z, return_type="np": np.zeros((1,))
+    _, inv = solver.cons_inversion(lat.cuda(), guidance_scale=0.0, w_embed_dim=512, seed=5)
+    alpha, sigma = _tables(E["sched_ref"])
+    noise = torch.randn(lat.shape, generator=torch.Generator().manual_seed(5))
+    x0 = float(alpha[19]) * lat + float(sigma[19]) * noise
+    ref_inv = _oracle_loop(E, sd, cfg, x0.clone(), ctx, list(zip(FWD_T, FWD_S)), [[0.0, 0.0]] * 4)
+    e_inv = rel_l2(inv[0], ref_inv)
+    print(f"[sd15 full width 64x64 inversion] rel-L2 = {e_inv:.3e}")
+    assert e_inv < 1.3e-3
 
 
 def test_sd15_inversion_then_replace_edit():
@@ -129,7 +177,7 @@ def test_sd15_inversion_then_replace_edit():
     ref_inv = _oracle_loop(E, sd, cfg, x0.clone(), ctx, list(zip(FWD_T, FWD_S)), [[0.0, 0.0]] * 4)
     e_inv = rel_l2(inv[0], ref_inv)
     print(f"[sd15 inversion] rel-L2 = {e_inv:.3e}")
-    assert e_inv < 2.5e-3                            # measured 1.36e-3
+    assert e_inv < 1.3e-3                            # measured 1.03e-3 (1.37e-3 on the plain fp16 stream): forward steps amplify, see the header
     # ---- edit: replace controller (cross 0.5 / self 0.5), dynamic guidance tau = 0.8, gs = 19
     p2p.tokenizer = E["synthetic"].SyntheticTokenizer()
     p2p.NUM_DDIM_STEPS = 4
@@ -148,13 +196,13 @@ def test_sd15_inversion_then_replace_edit():
     ref = _oracle_loop(E, sd, cfg, start.clone(), ctx, list(zip(REV_T, REV_S)), ws, controller=ref_ctrl)
     e = rel_l2(outs[-1], ref)
     print(f"[sd15 replace edit] rel-L2 = {e:.3e}")
-    assert e < 3e-3                                  # measured 1.68e-3 (8 UNet evaluations deep, edited probabilities)
+    assert e < 1.6e-3                                # measured 1.20e-3 (1.73e-3 before the carry; gs = 19, edited probabilities)
     assert ctrl.cur_step == 4
     worst = 0.0
     for key, refs in ref_ctrl.attention_store.items():
         for g, r in zip(ctrl.attention_store[key], refs):
             worst = max(worst, rel_l2(g, r))
-            assert rel_l2(g, r) < 3e-3, key
+            assert rel_l2(g, r) < 2e-3, key          # worst measured 1.51e-3 (2.10e-3 before the carry)
     print(f"[sd15 replace edit] worst attention-store tensor rel-L2 = {worst:.3e}")
 
 
@@ -181,7 +229,7 @@ def test_sdxl_reverse_and_dynamic_edit_pipeline():
     ref = _oracle_loop_xl(E, sd, cfg, lat.clone(), ctx, pairs, [[7.0] * B] * 4, added)
     e4 = rel_l2(out, ref)
     print(f"[sdxl reverse] rel-L2 = {e4:.3e}")
-    assert e4 < 1.2e-3                               # measured 6.1e-4
+    assert e4 < 1e-3                                 # measured 4.9e-4 (6.1e-4 before the carry)
     # cfg 5: forward 3 steps (w = 0) from noised latents at t = 19, then reverse 3 steps with tau = 0.7, gs = 19
     fwd, start = X.inverse_sample_deterministic(fpipe, lat.cuda().half(), ["x"] * B, num_inference_steps=3, timesteps=[19, 339, 699],
                                                 guidance_scale=0.0, is_sdxl=True, compute_embeddings_fn=emb, seed=3,
@@ -194,7 +242,7 @@ def test_sdxl_reverse_and_dynamic_edit_pipeline():
     ref_f = _oracle_loop_xl(E, sd, cfg, x0, ctx, list(zip([19, 339, 699], [339, 699, 999])), [[0.0] * B] * 3, added)
     e5f = rel_l2(fwd, ref_f)
     print(f"[sdxl forward] rel-L2 = {e5f:.3e}")
-    assert e5f < 3.5e-3                              # measured 2.03e-3 (forward model from t = 19: small eps, noise dominated)
+    assert e5f < 1.9e-3                              # measured 1.45e-3 (1.98e-3 before the carry): three forward steps amplify
     _, rev = X.sample_deterministic(pipe, ["x"] * B, latents=ref_f.cuda().half(), num_inference_steps=3, guidance_scale=19.0,
                                     is_sdxl=True, timesteps=[339, 699, 999], compute_embeddings_fn=emb, return_latent=True,
                                     use_dynamic_guidance=True, tau1=0.7, tau2=0.7)
@@ -203,7 +251,7 @@ def test_sdxl_reverse_and_dynamic_edit_pipeline():
     ref_r = _oracle_loop_xl(E, sd, cfg, ref_f.half().float(), ctx, list(zip([999, 699, 339], [699, 339, 0])), ws, added)
     e5r = rel_l2(rev, ref_r)
     print(f"[sdxl dynamic reverse] rel-L2 = {e5r:.3e}")
-    assert e5r < 3e-3                                # measured 1.85e-3
+    assert e5r < 1.7e-3                              # measured 1.31e-3 (1.89e-3 before the carry; gs = 19 from t = 999)
 
 
 def _oracle_loop_xl(E, sd, cfg, x, ctx, pairs, w_vals, added):

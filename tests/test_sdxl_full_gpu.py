@@ -101,14 +101,6 @@ def test_config5_sdxl_b16_3plus3_dynamic_guidance(sdxl, monkeypatch):
     assert e < 4e-3                                  # measured 2.5e-3: three steps amplify the plan-dependent rounding (loop error vs oracle 1.9e-3)
 
 
-def test_full_sdxl_forward_64x64_vs_oracle():
-    """One full-width SDXL forward at 64x64 (B = 1, 1.7 TFLOP of CPU oracle) - the largest size the oracle checks."""
-    from test_unet_gpu import _run_case
-    from invertible_cd_amd.unet_config import SDXL
-    torch.cuda.empty_cache()
-    _run_case(SDXL, B=1, H=64, W=64, t=499, seed=7, tol=2e-3)
-
-
 def test_sdxl_inversion_from_image_tensor_and_pil(sdxl):
     """running/sdxl/edit.py:196-207: PIL image -> image_processor.preprocess -> inverse_sample_deterministic ->
     img2img prepare_latents (fp32 VAE encode, latent_dist.sample(generator) * 0.13025, add_noise at t = 19)."""
@@ -213,4 +205,4 @@ def test_full_sdxl_forward_128x128_b2_on_the_benchmarked_tiles():
             assert len(xa) == 70 and len(on_big) == 60 and len(on_128) == 10 and all(p["xattn"] for p in xa)
             assert all(p["ln_inline"] for p in on_big)            # ... with the LayerNorm statistics from the same main loop
 
-    _run_case(SDXL, B=2, H=128, W=128, t=699, seed=9, tol=2e-3, variants={"xattn_everywhere": {"xattn_fusion": 1}}, check_plans=check)
+    _run_case(SDXL, B=2, H=128, W=128, t=699, seed=9, tol=1e-3, variants={"xattn_everywhere": {"xattn_fusion": 1}}, check_plans=check)

@@ -3,12 +3,14 @@ and inputs.
 
 Tolerance: the product stores activations in fp16 (fp32 accumulate); the oracle is fp32 end to end.  Weights and inputs
 are rounded to fp16 on both sides so the comparison measures the kernels, not the weight quantisation.  The north star's
-bar is 1e-3 rel-L2 "of the reference", whose configs 2-5 run diffusers in fp16: every case therefore also runs the oracle's
-own graph in fp16 with stock torch ops on the GPU (the "fp16-torch noise floor": how far ANY fp16-storage pipeline sits
-from fp32 on these weights) and prints it next to the product's error.  Bars:
-  * product error <= 1.5 x the measured fp16-torch floor of the same case (the product may not be worse than fp16 torch), and
-  * absolute: reduced-width <= 2e-3, full-width SD1.5 / SDXL <= 2e-3 (measured 1.1e-3: ~100-300 fp16-rounded layers deep).
-`pytest -s` output of this file is kept as profiles/r02_parity.txt.
+bar is 1e-3 rel-L2 "of the reference".  Bars (round 4):
+  * absolute: EVERY case, reduced width and full width, on the benchmarked tiles too, < 1e-3 against the fp32 oracle in the default
+    (and benchmarked) mode - the residual stream with its error carry (measured 0.70 - 0.85e-3; the plain fp16 stream of rounds 1 - 3
+    sat at 1.0 - 1.2e-3 and is kept as option residual = 0, asserted < 2e-3 where a test switches to it);
+  * relative: every case also runs the oracle's own graph in fp16 with stock torch ops on the GPU (the "fp16-torch noise floor":
+    how far an fp16 diffusers-style pipeline - what the reference's configs 2 - 5 run - sits from fp32 on these weights, 1.9 - 2.6e-3)
+    and the product must be <= 1.5 x that floor (it is at 0.3 - 0.4 x).
+`pytest -s` output of the GPU suite is kept as profiles/r04_parity.txt.
 """
 import pytest
 import torch
@@ -101,25 +103,25 @@ def _run_case(cfg, B, H, W, t, seed, tol, with_cond=True, n_ctx=77, f32_io=False
 def test_unet_tiny_sd15_topology():
     _, _, uc, _ = _mods()
     cfg = uc.SD15.scaled((64, 128, 256, 256), cross_dim=64)
-    _run_case(cfg, B=2, H=32, W=32, t=779, seed=1, tol=2e-3)
+    _run_case(cfg, B=2, H=32, W=32, t=779, seed=1, tol=1e-3)
 
 
 def test_unet_tiny_sd15_ragged_and_f32_io():
     _, _, uc, _ = _mods()
     cfg = uc.SD15.scaled((32, 64, 64, 128), cross_dim=40, heads=(4, 4, 4, 4))
-    _run_case(cfg, B=3, H=16, W=24, t=19, seed=2, tol=2e-3, with_cond=False, n_ctx=13, f32_io=True)
+    _run_case(cfg, B=3, H=16, W=24, t=19, seed=2, tol=1e-3, with_cond=False, n_ctx=13, f32_io=True)
 
 
 def test_unet_tiny_sdxl_topology():
     _, _, uc, _ = _mods()
     cfg = uc.SDXL.scaled((64, 128, 256), cross_dim=128, heads=(2, 4, 8))
-    _run_case(cfg, B=2, H=32, W=32, t=999, seed=3, tol=2e-3)
+    _run_case(cfg, B=2, H=32, W=32, t=999, seed=3, tol=1e-3)
 
 
 def test_unet_full_sd15_small_latent():
     """Full-width SD1.5 UNet (859.7 M parameters) on a 32x32 latent."""
     _, _, uc, _ = _mods()
-    _run_case(uc.SD15, B=2, H=32, W=32, t=519, seed=4, tol=2e-3)
+    _run_case(uc.SD15, B=2, H=32, W=32, t=519, seed=4, tol=1e-3)
 
 
 @pytest.mark.parametrize("which", ["sd15_tiny", "sdxl_tiny", "sd15_full_32"])
@@ -149,14 +151,14 @@ def test_carried_residual_stream_meets_the_north_star_tolerance(which):
 def test_unet_full_sd15_64x64():
     """BASELINE config-1 shape: full SD1.5, 64x64 latent (512x512 image), CFG-doubled batch of 2."""
     _, _, uc, _ = _mods()
-    _run_case(uc.SD15, B=2, H=64, W=64, t=999, seed=5, tol=2e-3)
+    _run_case(uc.SD15, B=2, H=64, W=64, t=999, seed=5, tol=1e-3)
 
 
 @pytest.mark.slow
 def test_unet_full_sdxl_small_latent():
     """Full-width SDXL UNet (2.57 G parameters) on a 32x32 latent (oracle: ~0.4 TFLOP)."""
     _, _, uc, _ = _mods()
-    _run_case(uc.SDXL, B=1, H=32, W=32, t=699, seed=6, tol=2e-3)
+    _run_case(uc.SDXL, B=1, H=32, W=32, t=699, seed=6, tol=1e-3)
 
 
 @pytest.mark.slow
@@ -188,7 +190,7 @@ def test_unet_full_sd15_b8_64x64_on_the_benchmarked_tiles_and_layernorm_statisti
         else:
             assert len(inline) == 0
 
-    r = _run_case(uc.SD15, B=8, H=64, W=64, t=779, seed=8, tol=2e-3, variants={"ln_pass": {"ln_inline_stats": 0}}, check_plans=check)
+    r = _run_case(uc.SD15, B=8, H=64, W=64, t=779, seed=8, tol=1e-3, variants={"ln_pass": {"ln_inline_stats": 0}}, check_plans=check)
     d = rel_l2(r["ln_pass"][1], r[None][1])
     print(f"[LN statistics in the consuming GEMM vs a pass over the stream] vs oracle {r[None][0]:.3e} / {r['ln_pass'][0]:.3e}; "
           f"the two differ by {d:.3e}")
@@ -244,3 +246,34 @@ def test_context_projection_cache_is_exact_and_notices_a_changed_context():
         model.kv_cache_enabled = True
         assert torch.equal(got, want)
         del c
+
+
+def test_forward_under_inference_mode_and_after_a_failing_hook():
+    """(a) torch.inference_mode(): context tensors created there have no version counter - the K / V cache treats them as a miss instead
+    of raising, results equal the no_grad ones bit for bit.  (b) a controller that raises aborts the forward: the exception surfaces and
+    the context cache is dropped (a half-written cache must not be trusted by the next forward)."""
+    synthetic, unet, uc, _ = _mods()
+    cfg = uc.SD15.scaled((64, 128, 256, 256), cross_dim=64)
+    model = unet.UNet2DConditionModel(cfg, synthetic.synthetic_state_dict(cfg, seed=23))
+    inp = synthetic.synthetic_inputs(cfg, 2, 16, 16, seed=23)
+    x, ctx = inp["latents"].half().cuda(), inp["context"].half().cuda()
+    ref = model(x, 519, encoder_hidden_states=ctx).sample.clone()
+    with torch.inference_mode():
+        xi, ci = x.clone(), ctx.clone()
+        a = model(xi, 519, encoder_hidden_states=ci).sample.clone()
+        b = model(xi, 519, encoder_hidden_states=ci).sample.clone()
+    assert torch.equal(a, ref) and torch.equal(b, ref)
+
+    class Boom:
+        num_att_layers = 0
+
+        def __call__(self, *a, **k):
+            raise ValueError("controller failed")
+    model(x, 519, encoder_hidden_states=ctx)
+    assert model._kv is not None
+    model.attn_controller = Boom()
+    with pytest.raises(Exception):
+        model(x, 519, encoder_hidden_states=ctx)
+    assert model._kv is None
+    model.attn_controller = None
+    assert torch.equal(model(x, 519, encoder_hidden_states=ctx).sample, ref)

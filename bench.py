@@ -64,6 +64,11 @@ def parse():
     ap.add_argument("--ln-inline-stats", type=int, default=1, choices=[0, 1],
                     help="A/B switch (UNet option ln_inline_stats): 1 = the GEMM behind a LayerNorm computes its statistics (default), "
                          "0 = a separate statistics pass over the residual stream")
+    ap.add_argument("--in-flight", type=int, default=2,
+                    help="independent batches in flight per GPU (host threads x HIP streams x executor replicas over one set of weights; "
+                         "InFlight): 1 = the sequential loop of rounds 1-3.  Every UNet call still runs the configuration's batch")
+    ap.add_argument("--in-flight-edit", type=int, default=3,
+                    help="batches in flight of the SD1.5 edit leg (configs[2]: 8 images per batch, the reference's shipped batch_per_gpu)")
     ap.add_argument("--residual", type=int, default=2, choices=[0, 1, 2],
                     help="UNet option residual (precision of the residual stream): 2 (default) = fp16 + bf8 error carry, the mode that "
                          "meets the 1e-3 parity bar; 0 = plain fp16 stream (rounds 1-3); 1 = fp32 twin (round 3's accurate mode)")
@@ -107,23 +112,29 @@ class SD15Workload:
     """Full-width SD1.5 + fused LoRA behind generation.Generator: BASELINE configs[1] (reverse, B = 32) and configs[2] (inversion +
     reverse with p2p.AttentionStore, B = 8) share one set of weights."""
 
-    def __init__(self, device):
+    def __init__(self, device, net=None):
         from invertible_cd_amd import generation, synthetic, unet
         from invertible_cd_amd.pipelines import StableDiffusionPipeline
         from invertible_cd_amd.schedulers import DDIMScheduler
         from invertible_cd_amd.unet_config import SD15
         from invertible_cd_amd.loading import fuse_lora
-        # synthetic weights generated directly on this rank's GPU (seeded per tensor), LoRA (rank 64, alpha 8) fused at load
-        sd = synthetic.synthetic_state_dict(SD15, seed=0, device=device)
-        sd = fuse_lora(sd, synthetic.synthetic_lora(SD15, seed=1, device=device), lora_dtype=torch.float16)
         self.cfg, self.device = SD15, device
-        self.model = StableDiffusionPipeline(unet.UNet2DConditionModel(SD15, sd, device=device, dtype=torch.float16), DDIMScheduler.sd15(),
-                                             tokenizer=synthetic.SyntheticTokenizer(), device=device, dtype=torch.float16)
+        if net is None:
+            # synthetic weights generated directly on this rank's GPU (seeded per tensor), LoRA (rank 64, alpha 8) fused at load
+            sd = synthetic.synthetic_state_dict(SD15, seed=0, device=device)
+            sd = fuse_lora(sd, synthetic.synthetic_lora(SD15, seed=1, device=device), lora_dtype=torch.float16)
+            net = unet.UNet2DConditionModel(SD15, sd, device=device, dtype=torch.float16)
+            del sd
+        self.model = StableDiffusionPipeline(net, DDIMScheduler.sd15(), tokenizer=synthetic.SyntheticTokenizer(), device=device,
+                                             dtype=torch.float16)
         self.net = self.model.unet
         self.solver = generation.Generator(self.model, 50, DDIMScheduler.sd15(), forward_cons_model=self.model, reverse_cons_model=self.model,
                                            reverse_timesteps=[259, 519, 779, 999], forward_timesteps=[19, 259, 519, 779])
         self.solver.latent2image = lambda z, return_type="np": None        # cons_inversion's image_rec decode is outside the path (8d)
-        del sd
+
+    def replica(self):
+        """The same weights behind a second executor handle / pipeline / Generator: one more batch in flight (UNet2DConditionModel.replica)."""
+        return SD15Workload(self.device, net=self.net.replica())
 
     def inputs(self, batch):
         g = torch.Generator().manual_seed(453645634)                     # running/sd1.5/launch_generation_iCD_sd1.5.sh:32
@@ -169,21 +180,26 @@ class SDXLWorkload:
     """Full-width SDXL behind generation_sdxl: configs[3]'s per-GPU share (reverse, 8 images / GPU) and configs[4]'s (3-step inversion
     + 3-step reverse with dynamic guidance, 16 images / GPU) on one set of weights."""
 
-    def __init__(self, device):
+    def __init__(self, device, net=None):
         from invertible_cd_amd import synthetic, unet
         from invertible_cd_amd.pipelines import StableDiffusionXLImg2ImgPipeline, StableDiffusionXLPipeline
         from invertible_cd_amd.schedulers import DDIMScheduler
         from invertible_cd_amd.unet_config import SDXL
         from invertible_cd_amd.loading import fuse_lora
-        # configs[3] / [4] are LoRA models like configs[1] / [2] (utils/loading.py:119-125): rank 64, alpha 8, fused at load
-        sd = synthetic.synthetic_state_dict(SDXL, seed=0, device=device, dtype=torch.float16)
-        sd = fuse_lora(sd, synthetic.synthetic_lora(SDXL, seed=1, device=device), lora_dtype=torch.float16)
         self.cfg, self.device = SDXL, device
-        self.net = unet.UNet2DConditionModel(SDXL, sd, device=device, dtype=torch.float16)
+        if net is None:
+            # configs[3] / [4] are LoRA models like configs[1] / [2] (utils/loading.py:119-125): rank 64, alpha 8, fused at load
+            sd = synthetic.synthetic_state_dict(SDXL, seed=0, device=device, dtype=torch.float16)
+            sd = fuse_lora(sd, synthetic.synthetic_lora(SDXL, seed=1, device=device), lora_dtype=torch.float16)
+            net = unet.UNet2DConditionModel(SDXL, sd, device=device, dtype=torch.float16)
+            del sd
+        self.net = net
         self.pipe = StableDiffusionXLPipeline(self.net, DDIMScheduler.sdxl(), device=device)
         self.fwd = StableDiffusionXLImg2ImgPipeline(self.net, DDIMScheduler.sdxl(), device=device)
         self.pipe.vae = None
-        del sd
+
+    def replica(self):
+        return SDXLWorkload(self.device, net=self.net.replica())
 
     def inputs(self, batch):
         from invertible_cd_amd import synthetic
@@ -292,13 +308,63 @@ def cuda_sync():
         torch.cuda.synchronize()
 
 
+class InFlight:
+    """N independent batches in flight: one host thread + one HIP stream per executor replica, all pulling passes from one counter.
+    An iCD evaluation at the reference's batch sizes leaves CUs idle at every launch's ramp and tail (8 images: ~310 launches of 20 - 30 us
+    on half of the chip); the NEXT batch - independent samples, its own handle, arena and controller - fills them.  Results are those
+    of the sequential loop (same kernels, same arithmetic per batch); only the wall clock changes."""
+
+    def __init__(self, steps, device):
+        self.steps, self.device = list(steps), device
+        self.streams = [torch.cuda.Stream(device=device) for _ in self.steps] if len(self.steps) > 1 and torch.cuda.is_available() else None
+
+    def __len__(self):
+        return len(self.steps)
+
+    def run(self, n):
+        """n passes; returns their outputs in submission order (the caller's stream may consume them afterwards)."""
+        if len(self.steps) == 1:
+            return [self.steps[0]() for _ in range(n)]
+        import itertools
+        import threading
+        outs, errs, ticket = [None] * n, [], itertools.count()
+        main = torch.cuda.current_stream()
+        for st in self.streams:
+            st.wait_stream(main)                      # inputs produced on the caller's stream are visible to the side streams
+
+        def work(i):
+            try:
+                torch.cuda.set_device(self.device)
+                with torch.cuda.stream(self.streams[i]):
+                    while True:
+                        k = next(ticket)
+                        if k >= n:
+                            break
+                        outs[k] = self.steps[i]()
+            except BaseException as e:                # noqa: BLE001  (re-raised on the caller's thread)
+                errs.append(e)
+        th = [threading.Thread(target=work, args=(i,)) for i in range(len(self.steps))]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        if errs:
+            raise errs[0]
+        for st in self.streams:
+            main.wait_stream(st)                      # the caller's stream continues behind every side stream
+        return outs
+
+
 def time_leg(step, steps, warmup, batch, device, world, rank, decode=None, events_family=None):
     """W untimed passes, then EXACTLY `steps` timed passes bracketed by barrier + synchronize on both sides, the ONE all-gather of
-    the produced samples inside the timed region; MAX over ranks.  events_family: bracket the launches of that kernel family with
-    HIP events during the timed region (the roofline leg); None: no events at all.  Returns (seconds, per-rank seconds list,
-    event profile or None)."""
+    the produced samples inside the timed region; MAX over ranks.  `step`: a callable (one batch at a time) or an InFlight (several
+    independent batches in flight, K passes in total).  events_family: bracket the launches of that kernel family with HIP events during
+    the timed region (the roofline leg; one batch at a time only); None: no events at all.  Returns (seconds, per-rank seconds list,
+    event profile or None, last output)."""
     import torch.distributed as dist
     from invertible_cd_amd import _lib, dist_utils
+    flight = step if isinstance(step, InFlight) else InFlight([step], device)
+    assert not (events_family and len(flight) > 1), "the event profiler serves one batch at a time"
 
     def sync_all():
         cuda_sync()
@@ -306,15 +372,13 @@ def time_leg(step, steps, warmup, batch, device, world, rank, decode=None, event
             dist.barrier()
             cuda_sync()
 
-    for _ in range(warmup):
-        step()
+    if warmup:
+        flight.run(warmup * len(flight))
     sync_all()
     if events_family:
         _lib.profile_enable(True, only=[events_family])
-    outs = []
     t0 = time.perf_counter()
-    for _ in range(steps):
-        outs.append(step())
+    outs = flight.run(steps)
     local = torch.stack(outs).reshape(-1, *outs[0].shape[1:]).to(torch.float16)
     if decode is not None:
         local = torch.cat([decode(local[i:i + batch]) for i in range(0, local.shape[0], batch)])
@@ -352,6 +416,18 @@ def family_table(step):
     return fam, max(fam, key=lambda k: (fam[k]["flops"], fam[k]["ms"]))
 
 
+def workload_group(wl, n):
+    """[wl, replica, ...]: n executors over wl's weights (built once per workload; options follow wl's at the time of the call)."""
+    if not hasattr(wl, "_group"):
+        wl._group = [wl]
+    while len(wl._group) < n:
+        wl._group.append(wl.replica())
+    for w in wl._group[1:]:
+        for name, value in wl.net._options.items():
+            w.net.set_option(name, value)
+    return wl._group[:n]
+
+
 def run_reverse(a, wl, arch, batch, steps, warmup, device, world, rank, primary):
     """BASELINE configs[1] (SD1.5, the `value` of the line) / configs[3]'s per-GPU share (SDXL): the 4-step reverse loop."""
     import torch.distributed as dist
@@ -359,6 +435,8 @@ def run_reverse(a, wl, arch, batch, steps, warmup, device, world, rank, primary)
     wl.net.set_option("ln_inline_stats", a.ln_inline_stats).set_option("xattn_fusion", a.xattn_fusion)     # per-handle A/B switches
     wl.net.set_option("attn_valu_scale", a.attn_valu_scale).set_option("residual", a.residual)
     step = wl.reverse_step(batch)
+    group = workload_group(wl, a.in_flight)              # this workload + its replicas (same weights, own handle / arena / stream)
+    flight = InFlight([step] + [w.reverse_step(batch) for w in group[1:]], device)
     vae_m = None
     # the VAE exists only where something decodes: rank 0's separate vae_decode leg, or every rank under --gather images
     if (rank == 0 and not a.no_vae and primary) or a.gather == "images":
@@ -381,14 +459,15 @@ def run_reverse(a, wl, arch, batch, steps, warmup, device, world, rank, primary)
         step()
     if decode is not None:
         decode_u8(step()[:2])
-    # Event-overhead A/B: pass A = K steps with HIP events around the dominant family (the roofline), pass B = K steps with no events
-    # at all.  `value` is pass B when the events cost more than 1 %, else pass A (then the roofline IS the timed region's).
+    # Pass A = K steps, one batch at a time, with HIP events around the dominant family (the roofline: per-launch durations of the kernel,
+    # undisturbed by a second stream); pass B = K steps with no events at all and `--in-flight` batches in flight.  `value` is pass B -
+    # unless one batch is in flight and the events cost less than 1 % (then pass A, and the roofline IS the timed region's).
     dt_ev = prof = None
     if not a.no_profile:
         dt_ev, _, prof, _ = time_leg(step, steps, 0, batch, device, world, rank, decode, events_family=dominant)
-    dt_plain, per_rank, _, last = time_leg(step, steps, 0, batch, device, world, rank, decode)
+    dt_plain, per_rank, _, last = time_leg(flight, steps, 1 if len(flight) > 1 else 0, batch, device, world, rank, decode)
     ev_over = (dt_ev - dt_plain) / dt_plain if dt_ev else None
-    use_plain = dt_ev is None or ev_over > 0.01
+    use_plain = dt_ev is None or ev_over > 0.01 or len(flight) > 1
     dt = dt_plain if use_plain else dt_ev
 
     # N > 1: the reference's payload - uint8 images + int64 ids in ONE all-gather (running/sd1.5/generate.py:372-383) -
@@ -424,11 +503,13 @@ def run_reverse(a, wl, arch, batch, steps, warmup, device, world, rank, primary)
     # 1e-3 rel-L2 of the fp32 oracle); the same loop on the plain fp16 stream of rounds 1 - 3 (1.0 - 1.2e-3) is timed beside it.
     fp16_stream = None
     if a.residual != 0 and not a.no_profile:
-        wl.net.set_option("residual", 0)
+        for w in group:
+            w.net.set_option("residual", 0)
         n_alt = max(2, steps // 2)
-        dt_alt, _, _, _ = time_leg(step, n_alt, 1, batch, device, world, rank, decode)
-        wl.net.set_option("residual", a.residual)
-        step()
+        dt_alt, _, _, _ = time_leg(flight, n_alt, 1, batch, device, world, rank, decode)
+        for w in group:
+            w.net.set_option("residual", a.residual)
+        flight.run(len(flight))
         fp16_stream = {"value": round(batch * n_alt * world / dt_alt, 3), "ms_per_step": round(dt_alt / n_alt * 1e3, 3), "steps": n_alt,
                        "note": "the same leg with UNet option residual = 0 (plain fp16 residual stream, the mode rounds 1-3 reported): "
                                "eps rel-L2 vs the fp32 oracle 1.0-1.2e-3 instead of 0.7-0.85e-3"}
@@ -467,17 +548,23 @@ def run_reverse(a, wl, arch, batch, steps, warmup, device, world, rank, primary)
                    "per_gpu_batch": batch, "global_batch": batch * world, "unet_evals_per_step": 4,
                    "dead_uncond_rows_eliminated": arch == "sd15", "lora_fused": True,
                    "residual_stream": {0: "fp16", 1: "fp16 + fp32 twin", 2: "fp16 + bf8 error carry (the mode that meets 1e-3 parity)"}[a.residual],
+                   "in_flight_batches": len(flight),
                    "parallelism": f"dp{world}", "collective": f"one all-gather (RCCL) of the {payload} + int64 ids at the end of the timed region"},
-        "per_unet_ms": round(dt / steps / 4 * 1e3, 3),
+        "per_unet_ms": round(dt / steps / 4 * 1e3, 3),             # throughput time of one evaluation (wall / evaluations)
         "ms_per_step_per_rank": {"min": round(min(per_rank) / steps * 1e3, 3), "max": round(max(per_rank) / steps * 1e3, 3),
                                  "ranks": len(per_rank)},
         "end_to_end_algorithmic_tflops_per_gpu": round(value / world * algo / 1e12, 1),
         "end_to_end_frac_of_mfma_peak": round(value / world * algo / PEAK_MFMA_F16, 4),
     }
-    if dt_ev is not None:
+    if dt_ev is not None and len(flight) == 1:
         out["event_overhead"] = {"ms_per_step_with_events": round(dt_ev / steps * 1e3, 3), "ms_per_step_without_events": round(dt_plain / steps * 1e3, 3),
                                  "frac": round(ev_over, 4), "value_from": "pass without events" if use_plain else "pass with events",
                                  "note": "pass A: K steps with HIP events around the dominant family (the roofline); pass B: K steps with none"}
+    elif dt_ev is not None:
+        out["one_batch_at_a_time"] = {"value": round(images / dt_ev, 3), "ms_per_step": round(dt_ev / steps * 1e3, 3),
+                                      "note": f"pass A: the sequential loop (one batch in flight) with HIP events around the dominant family - the "
+                                              f"roofline leg; `value` is pass B: the same K steps with {len(flight)} independent batches in flight "
+                                              f"(InFlight: host threads x HIP streams x executor replicas over one set of weights), no events"}
     if fp16_stream is not None:
         out["fp16_stream"] = fp16_stream
     if ref_batching is not None:
@@ -515,7 +602,13 @@ def run_edit(a, wl, arch, batch, steps, warmup, device, world, rank):
     """BASELINE configs[2] (SD1.5: 4-step inversion + 4-step reverse with p2p.AttentionStore, 8 images / GPU) and configs[4]'s per-GPU
     share (SDXL: 3 + 3 steps, dynamic guidance tau 0.7, 16 images / GPU): edited images / s, no events in the timed region."""
     step = wl.edit_step(batch)
-    dt, per_rank, _, _ = time_leg(step, steps, warmup, batch, device, world, rank)
+    n_fl = a.in_flight_edit if arch == "sd15" else a.in_flight
+    group = workload_group(wl, n_fl)
+    steps_fns = [step] + [w.edit_step(batch) for w in group[1:]]
+    flight = InFlight(steps_fns, device)
+    steps = (steps + n_fl - 1) // n_fl * n_fl            # whole rounds of the batches in flight
+    dt, per_rank, _, _ = time_leg(flight, steps, warmup, batch, device, world, rank)
+    step.stored = max(f.stored for f in steps_fns) if arch == "sd15" else 0
     if rank != 0:
         return None
     evals = 8 if arch == "sd15" else 6
@@ -528,7 +621,9 @@ def run_edit(a, wl, arch, batch, steps, warmup, device, world, rank):
                                    "batch=8/GPU, fp16, 64x64 latents" if arch == "sd15" else
                                    "iCD-SDXL 3-step forward inversion (w=0) + 3-step reverse (gs=19, dynamic guidance tau=0.7), batch=16/GPU, fp16, "
                                    "128x128 latents, timesteps fwd [19,339,699] rev [999,699,339]"),
-                      "per_gpu_batch": batch, "global_batch": batch * world, "unet_evals_per_step": evals, "parallelism": f"dp{world}"},
+                      "per_gpu_batch": batch, "global_batch": batch * world, "unet_evals_per_step": evals, "parallelism": f"dp{world}",
+                      "in_flight_batches": len(flight),
+                      "residual_stream": {0: "fp16", 1: "fp16 + fp32 twin", 2: "fp16 + bf8 error carry"}[a.residual]},
            "end_to_end_algorithmic_tflops_per_gpu": round(value / world * algo / 1e12, 1),
            "end_to_end_frac_of_mfma_peak": round(value / world * algo / PEAK_MFMA_F16, 4)}
     if arch == "sd15":
@@ -617,6 +712,10 @@ def main():
 if __name__ == "__main__":
     # the contract is ONE JSON line on stdout: everything else the stack prints (the reference-shaped Generator announces its
     # endpoint tables like utils/generation.py does) goes to stderr
-    _REAL_STDOUT = sys.stdout
+    # - at the file-descriptor level too: native libraries write to fd 1 directly (RCCL prints its version banner there when the
+    # process group comes up), which would put extra lines in front of the JSON line the driver parses.
+    sys.stdout.flush()
+    _REAL_STDOUT = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     sys.stdout = sys.stderr
     main()

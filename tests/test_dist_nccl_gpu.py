@@ -85,7 +85,9 @@ def test_bench_under_torchrun_at_one_gpu_reports_rccl():
            "--no-cpu-baseline", "--no-vae", "--no-ref-batching", "--no-sdxl", "--no-edit"]
     r = subprocess.run(cmd, env=_env(), capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines[:5]             # ONE JSON line on stdout: RCCL's version banner (printed to fd 1) must not reach it
+    d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["value"] > 0
     assert d["rccl"]["rccl_world_size"] == 1 and d["rccl"]["backend"] == "nccl" and d["rccl"]["all_gather_executed"] is True
 

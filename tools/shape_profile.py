@@ -13,6 +13,7 @@ ap.add_argument("--arch", default="sd15")
 ap.add_argument("--batch", type=int, default=32)
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--xattn", type=int, default=2, help="UNet option xattn_fusion: 0 two launches, 1 fused wherever eligible, 2 (default) where faster")
+ap.add_argument("--residual", type=int, default=2, help="UNet option residual: 0 fp16 stream, 1 fp32 twin, 2 error carry (default)")
 ap.add_argument("--xattn-tile", type=int, default=0, help="2: force the 128x128 tile of the fused kernel, 4: the 256x128 tile")
 a = ap.parse_args()
 cfg = SD15 if a.arch == "sd15" else SDXL
@@ -20,6 +21,7 @@ res = 64 if a.arch == "sd15" else 128
 sd = synthetic.synthetic_state_dict(cfg, seed=0, device="cuda", dtype=torch.float16)
 m = unet.UNet2DConditionModel(cfg, sd)
 m.set_option("xattn_fusion", 1 if a.xattn_tile else a.xattn)
+m.set_option("residual", a.residual)
 if a.xattn_tile:
     m.set_option("xattn_tile", a.xattn_tile)
 del sd

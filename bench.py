@@ -700,7 +700,7 @@ def main():
     if sdxl is not None:
         keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "per_unet_ms", "ms_per_step_per_rank", "config",
                 "end_to_end_algorithmic_tflops_per_gpu", "end_to_end_frac_of_mfma_peak", "event_overhead", "roofline", "kernel_families",
-                "fp16_stream")
+                "fp16_stream", "one_batch_at_a_time")
         out["sdxl"] = {k: sdxl[k] for k in keep if k in sdxl}
     if sdxl_edit is not None:
         out["sdxl_edit"] = sdxl_edit

@@ -11,6 +11,9 @@ bar is 1e-3 rel-L2 "of the reference".  Bars (round 4):
     how far an fp16 diffusers-style pipeline - what the reference's configs 2 - 5 run - sits from fp32 on these weights, 1.9 - 2.6e-3)
     and the product must be <= 1.5 x that floor (it is at 0.3 - 0.4 x).
 `pytest -s` output of the GPU suite is kept as profiles/r04_parity.txt.
+(Round 4 dropped three full-width single-forward cases that larger ones subsume - SD1.5 B=2 at 32x32 / 64x64 and SDXL B=1 at 32x32 are
+covered by the carried-stream case at 32x32, the B=8 64x64 benchmarked-tile case, the full-width loop test and the SDXL B=2 128x128 case -
+to keep the whole GPU suite, most of which is CPU oracle time, well inside the driver's 20-minute step on a slow host.)
 """
 import pytest
 import torch
@@ -118,10 +121,6 @@ def test_unet_tiny_sdxl_topology():
     _run_case(cfg, B=2, H=32, W=32, t=999, seed=3, tol=1e-3)
 
 
-def test_unet_full_sd15_small_latent():
-    """Full-width SD1.5 UNet (859.7 M parameters) on a 32x32 latent."""
-    _, _, uc, _ = _mods()
-    _run_case(uc.SD15, B=2, H=32, W=32, t=519, seed=4, tol=1e-3)
 
 
 @pytest.mark.parametrize("which", ["sd15_tiny", "sdxl_tiny", "sd15_full_32"])
@@ -147,18 +146,8 @@ def test_carried_residual_stream_meets_the_north_star_tolerance(which):
     assert torch.equal(r["back"][1], r[None][1])
 
 
-@pytest.mark.slow
-def test_unet_full_sd15_64x64():
-    """BASELINE config-1 shape: full SD1.5, 64x64 latent (512x512 image), CFG-doubled batch of 2."""
-    _, _, uc, _ = _mods()
-    _run_case(uc.SD15, B=2, H=64, W=64, t=999, seed=5, tol=1e-3)
 
 
-@pytest.mark.slow
-def test_unet_full_sdxl_small_latent():
-    """Full-width SDXL UNet (2.57 G parameters) on a 32x32 latent (oracle: ~0.4 TFLOP)."""
-    _, _, uc, _ = _mods()
-    _run_case(uc.SDXL, B=1, H=32, W=32, t=699, seed=6, tol=1e-3)
 
 
 @pytest.mark.slow
@@ -277,3 +266,44 @@ def test_forward_under_inference_mode_and_after_a_failing_hook():
     assert model._kv is None
     model.attn_controller = None
     assert torch.equal(model(x, 519, encoder_hidden_states=ctx).sample, ref)
+
+
+def test_executor_replicas_run_two_batches_in_flight_with_sequential_results():
+    """UNet2DConditionModel.replica(): a second native handle over the SAME packed weights (own arena, caches, plugin slot, the options
+    of the original).  Two host threads on two HIP streams drive one replica each through different batches at the same time (what
+    bench.py's InFlight does): every output equals the sequential single-handle result bit for bit - the library keeps no process-wide
+    execution state, and concurrent launches on the idle CUs change the clock, not the arithmetic."""
+    import threading
+    synthetic, unet, uc, _ = _mods()
+    cfg = uc.SD15.scaled((64, 128, 256, 256), cross_dim=64)
+    model = unet.UNet2DConditionModel(cfg, synthetic.synthetic_state_dict(cfg, seed=41))
+    model.set_option("xattn_fusion", 0)
+    rep = model.replica()
+    assert rep._packed is model._packed and rep._h.value != model._h.value and rep._options == model._options
+    ins = [synthetic.synthetic_inputs(cfg, 3, 32, 32, seed=50 + i) for i in range(4)]
+    xs = [i["latents"].half().cuda() for i in ins]
+    cs = [i["context"].half().cuda() for i in ins]
+    want = [model(x, 519, encoder_hidden_states=c).sample.clone() for x, c in zip(xs, cs)]
+    assert torch.equal(rep(xs[0], 519, encoder_hidden_states=cs[0]).sample, want[0])
+    got, errs = [None] * 4, []
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+
+    def work(net, stream, idx):
+        try:
+            with torch.cuda.stream(stream):
+                for _ in range(3):                                   # several rounds: arenas and caches are reused while the other runs
+                    for k in idx:
+                        got[k] = net(xs[k], 519, encoder_hidden_states=cs[k]).sample.clone()
+                stream.synchronize()
+        except BaseException as e:                                    # noqa: BLE001
+            errs.append(e)
+    torch.cuda.synchronize()
+    th = [threading.Thread(target=work, args=(model, streams[0], (0, 2))), threading.Thread(target=work, args=(rep, streams[1], (1, 3)))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    torch.cuda.synchronize()
+    for g, w in zip(got, want):
+        assert torch.equal(g, w)

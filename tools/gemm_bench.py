@@ -45,6 +45,8 @@ elif kind in ("dense", "geglu"):
         d.a0, d.w, d.out, d.bias = x.data_ptr(), w.data_ptr(), out.data_ptr(), b.data_ptr()
         d.resid = res.data_ptr() if res is not None else None
         d.M, d.N, d.K, d.Nw, d.lda, d.ldw, d.ldo, d.ldr = M, N, K, N, K, K, out.stride(0), N
+        if os.environ.get("LDA0"):                # knock-out: every row of A is row 0 (A served by the L2 - "what if this operand never
+            d.lda = 0                             # came from HBM"); results are meaningless, the timing is the point
         d.mode, d.batch, d.zdiv, d.alpha, d.flags = 0, 1, 1, 1.0, dbg | (1 if kind == "geglu" else 0)
         if skws is not None and kind == "dense":
             d.splitk_ws, d.splitk_ws_bytes = skws.data_ptr(), skws.numel() * 4

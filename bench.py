@@ -325,17 +325,21 @@ class InFlight:
         """n passes; returns their outputs in submission order (the caller's stream may consume them afterwards)."""
         if len(self.steps) == 1:
             return [self.steps[0]() for _ in range(n)]
+        import contextlib
         import itertools
         import threading
         outs, errs, ticket = [None] * n, [], itertools.count()
-        main = torch.cuda.current_stream()
-        for st in self.streams:
-            st.wait_stream(main)                      # inputs produced on the caller's stream are visible to the side streams
+        gpu = self.streams is not None                # (a CPU run - the gloo test - threads the same way, without streams)
+        main = torch.cuda.current_stream() if gpu else None
+        if gpu:
+            for st in self.streams:
+                st.wait_stream(main)                  # inputs produced on the caller's stream are visible to the side streams
 
         def work(i):
             try:
-                torch.cuda.set_device(self.device)
-                with torch.cuda.stream(self.streams[i]):
+                if gpu:
+                    torch.cuda.set_device(self.device)
+                with (torch.cuda.stream(self.streams[i]) if gpu else contextlib.nullcontext()):
                     while True:
                         k = next(ticket)
                         if k >= n:
@@ -350,8 +354,9 @@ class InFlight:
             t.join()
         if errs:
             raise errs[0]
-        for st in self.streams:
-            main.wait_stream(st)                      # the caller's stream continues behind every side stream
+        if gpu:
+            for st in self.streams:
+                main.wait_stream(st)                  # the caller's stream continues behind every side stream
         return outs
 
 

@@ -137,3 +137,33 @@ def test_dist_init_picks_a_free_port_alone_and_the_reference_default_for_a_multi
         assert torch.equal(a, b) and torch.equal(ai, bi) and torch.equal(ai, torch.arange(3))
     finally:
         dist.destroy_process_group()
+
+
+def test_in_flight_runs_exactly_n_passes_in_submission_order_and_propagates_errors():
+    """bench.InFlight (several batches in flight: one host thread per executor replica, all pulling passes from one counter) on CPU
+    callables: exactly n passes, each output at the index of its ticket, a failing pass re-raised on the caller's thread; time_leg
+    accepts it in place of a plain step."""
+    import threading
+    import pytest
+    import bench
+    seen, lock = [], threading.Lock()
+
+    def make(tag):
+        def step():
+            with lock:
+                seen.append(tag)
+            return torch.full((2, 3), float(len(seen)))
+        return step
+    fl = bench.InFlight([make("a"), make("b"), make("c")], "cpu")
+    outs = fl.run(7)
+    assert len(outs) == 7 and len(seen) == 7 and all(o.shape == (2, 3) for o in outs)
+    assert sorted(float(o[0, 0]) for o in outs) == [1.0, 2.0, 3.0, 4.0, 5.0, 6.0, 7.0]
+    dt, per_rank, prof, last = bench.time_leg(fl, steps=4, warmup=1, batch=2, device="cpu", world=1, rank=0)
+    assert dt > 0 and per_rank == [dt] and prof is None and last.shape == (2, 3)
+
+    def boom():
+        raise ValueError("pass failed")
+    with pytest.raises(ValueError, match="pass failed"):
+        bench.InFlight([make("a"), boom], "cpu").run(4)
+    with pytest.raises(AssertionError):
+        bench.time_leg(fl, 2, 0, 2, "cpu", 1, 0, events_family="gemm_conv")     # the event profiler serves one batch at a time

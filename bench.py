@@ -64,6 +64,9 @@ def parse():
     ap.add_argument("--ln-inline-stats", type=int, default=1, choices=[0, 1],
                     help="A/B switch (UNet option ln_inline_stats): 1 = the GEMM behind a LayerNorm computes its statistics (default), "
                          "0 = a separate statistics pass over the residual stream")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not measure roofline.traffic in this run (two rocprofv3 --pmc child passes of one step per architecture after "
+                         "the timed legs, N = 1 only); the committed PMC summary of the same workload is reported instead")
     ap.add_argument("--in-flight", type=int, default=2,
                     help="independent batches in flight per GPU (host threads x HIP streams x executor replicas over one set of weights; "
                          "InFlight): 1 = the sequential loop of rounds 1-3.  Every UNet call still runs the configuration's batch")
@@ -252,6 +255,49 @@ def hbm_traffic(arch, batch, family):
             # latest round wins (sorted by name); the file records the sha of the kernel sources it was measured on
             best = (d["families"][family]["traffic_bytes"], os.path.join("profiles", os.path.basename(f)), d.get("kernels_sha"))
     return best or (None, None, None)
+
+
+def live_traffic(arch, batch, family, timeout_s=240):
+    """roofline.traffic measured IN THIS RUN: two rocprofv3 --pmc child passes (FETCH_SIZE, then WRITE_SIZE - one counter per pass, with
+    --kernel-trace only, as MI355X_MICROARCH.md prescribes) over one step of the same leg in a fresh process, summarised per kernel family
+    with tools/hbm_traffic.py's own code: bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024.  Returns (bytes per launch, seconds
+    spent) or (None, reason): the caller then reports the committed summary instead.  (The counters cannot be read inside the timed
+    process; the child runs after the timed legs, on the same GPU, same binary.)"""
+    import shutil
+    import subprocess
+    import tempfile
+    t0 = time.perf_counter()
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    src = open(os.path.join(ROOT, "tools", "hbm_traffic.py")).read().split("ap = argparse.ArgumentParser()")[0]
+    ns = {}
+    exec(compile(src, "hbm_traffic_head", "exec"), ns)          # family() and collect(): one source of truth with the offline tool
+    tmp = tempfile.mkdtemp(prefix="icd_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR", "TORCHELASTIC_RUN_ID"):
+        env.pop(k, None)
+    child = [sys.executable, os.path.abspath(__file__), "--arch", arch, "--batch", str(batch), "--steps", "1", "--warmup", "1", "--in-flight", "1",
+             "--no-cpu-baseline", "--no-vae", "--no-ref-batching", "--no-profile", "--no-sdxl", "--no-edit", "--no-live-traffic"]
+    try:
+        per = {}
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            r = subprocess.run([exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--"] + child,
+                               cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+            if r.returncode != 0:
+                return None, f"rocprofv3 --pmc {counter} exited {r.returncode}"
+            agg = ns["collect"](d)
+            if family not in agg or not agg[family][0]:
+                return None, f"no {family} dispatches in the {counter} pass"
+            per[counter] = agg[family][1] / agg[family][0]
+        return int((2.0 * per["FETCH_SIZE"] + per["WRITE_SIZE"]) * 1024), time.perf_counter() - t0
+    except subprocess.TimeoutExpired:
+        return None, f"rocprofv3 pass exceeded {timeout_s} s"
+    except Exception as e:                                       # noqa: BLE001
+        return None, f"{type(e).__name__}: {e}"[:200]
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def cpu_baseline(arch, sd, cfg):
@@ -709,6 +755,17 @@ def main():
         out["sdxl"] = {k: sdxl[k] for k in keep if k in sdxl}
     if sdxl_edit is not None:
         out["sdxl_edit"] = sdxl_edit
+    if world == 1 and not a.no_live_traffic and not a.no_profile and out.get("roofline"):
+        # roofline.traffic of the PRIMARY line measured in this run (child rocprofv3 passes, after every timed leg, ~17 s for SD1.5); the
+        # committed summary stays as the fallback, and as the source of the "sdxl" object's figure (building the 2.6 G-parameter workload
+        # under the counter profiler takes minutes - too long for the default run)
+        roof = out["roofline"]
+        t_bytes, info = live_traffic(a.arch, batch, roof["kernel"], timeout_s=120 if a.arch == "sd15" else 600)
+        if t_bytes:
+            roof.update({"traffic": t_bytes, "traffic_source": "live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes of one step, this run",
+                         "traffic_kernels_sha": roof["kernels_sha"], "traffic_seconds": round(info, 1)})
+        else:
+            roof["traffic_live_error"] = info
     if world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(a.arch, None, cfg_for_cpu)
     print(json.dumps(out), file=_REAL_STDOUT, flush=True)

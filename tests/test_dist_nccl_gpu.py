@@ -82,7 +82,7 @@ def test_bench_under_torchrun_at_one_gpu_reports_rccl():
     world of one whose end-of-run all-gather went through RCCL."""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1", "--batch", "4",
-           "--no-cpu-baseline", "--no-vae", "--no-ref-batching", "--no-sdxl", "--no-edit"]
+           "--no-cpu-baseline", "--no-vae", "--no-ref-batching", "--no-sdxl", "--no-edit", "--no-live-traffic"]
     r = subprocess.run(cmd, env=_env(), capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
@@ -106,7 +106,7 @@ def test_world2_nccl_gather_of_uint8_images(tmp_path):
 @needs2
 def test_bench_gpus_2_spawns_two_rccl_ranks():
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--batch", "4",
-           "--no-cpu-baseline", "--no-vae", "--no-ref-batching"]
+           "--no-cpu-baseline", "--no-vae", "--no-ref-batching", "--no-live-traffic"]
     env = _env()
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

@@ -152,7 +152,8 @@ def test_in_flight_runs_exactly_n_passes_in_submission_order_and_propagates_erro
         def step():
             with lock:
                 seen.append(tag)
-            return torch.full((2, 3), float(len(seen)))
+                k = len(seen)                    # (read under the lock: the passes run on three threads)
+            return torch.full((2, 3), float(k))
         return step
     fl = bench.InFlight([make("a"), make("b"), make("c")], "cpu")
     outs = fl.run(7)
@@ -163,7 +164,12 @@ def test_in_flight_runs_exactly_n_passes_in_submission_order_and_propagates_erro
 
     def boom():
         raise ValueError("pass failed")
+    import time
+
+    def slow():                                   # (leaves the other thread time to draw a ticket: passes are handed out dynamically)
+        time.sleep(0.05)
+        return torch.zeros(2, 3)
     with pytest.raises(ValueError, match="pass failed"):
-        bench.InFlight([make("a"), boom], "cpu").run(4)
+        bench.InFlight([slow, boom], "cpu").run(8)
     with pytest.raises(AssertionError):
         bench.time_leg(fl, 2, 0, 2, "cpu", 1, 0, events_family="gemm_conv")     # the event profiler serves one batch at a time

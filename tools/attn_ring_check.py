@@ -29,6 +29,9 @@ def build_sync():
     B.build(verbose=False)
     os.makedirs(os.path.dirname(SYNC_LIB), exist_ok=True)
     obj = os.path.join(ROOT, "ab", "attention_sync.o")
+    deps = [os.path.join(B.CSRC, f) for f in os.listdir(B.CSRC)] + [B.LIB]
+    if os.path.exists(SYNC_LIB) and os.path.getmtime(SYNC_LIB) > max(os.path.getmtime(d) for d in deps):
+        return                                    # up to date (built by __graft_entry__.build() beside the product library)
     cmd = [B.HIPCC] + B.FLAGS + B.EXTRA_FLAGS.get("attention.hip", []) + ["-DICD_ATTN_DEBUG_SYNC", "-x", "hip", "-c",
                                                                           os.path.join(B.CSRC, "attention.hip"), "-o", obj]
     subprocess.run(cmd, check=True)

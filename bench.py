@@ -354,56 +354,7 @@ def cuda_sync():
         torch.cuda.synchronize()
 
 
-class InFlight:
-    """N independent batches in flight: one host thread + one HIP stream per executor replica, all pulling passes from one counter.
-    An iCD evaluation at the reference's batch sizes leaves CUs idle at every launch's ramp and tail (8 images: ~310 launches of 20 - 30 us
-    on half of the chip); the NEXT batch - independent samples, its own handle, arena and controller - fills them.  Results are those
-    of the sequential loop (same kernels, same arithmetic per batch); only the wall clock changes."""
-
-    def __init__(self, steps, device):
-        self.steps, self.device = list(steps), device
-        self.streams = [torch.cuda.Stream(device=device) for _ in self.steps] if len(self.steps) > 1 and torch.cuda.is_available() else None
-
-    def __len__(self):
-        return len(self.steps)
-
-    def run(self, n):
-        """n passes; returns their outputs in submission order (the caller's stream may consume them afterwards)."""
-        if len(self.steps) == 1:
-            return [self.steps[0]() for _ in range(n)]
-        import contextlib
-        import itertools
-        import threading
-        outs, errs, ticket = [None] * n, [], itertools.count()
-        gpu = self.streams is not None                # (a CPU run - the gloo test - threads the same way, without streams)
-        main = torch.cuda.current_stream() if gpu else None
-        if gpu:
-            for st in self.streams:
-                st.wait_stream(main)                  # inputs produced on the caller's stream are visible to the side streams
-
-        def work(i):
-            try:
-                if gpu:
-                    torch.cuda.set_device(self.device)
-                with (torch.cuda.stream(self.streams[i]) if gpu else contextlib.nullcontext()):
-                    while True:
-                        k = next(ticket)
-                        if k >= n:
-                            break
-                        outs[k] = self.steps[i]()
-            except BaseException as e:                # noqa: BLE001  (re-raised on the caller's thread)
-                errs.append(e)
-        th = [threading.Thread(target=work, args=(i,)) for i in range(len(self.steps))]
-        for t in th:
-            t.start()
-        for t in th:
-            t.join()
-        if errs:
-            raise errs[0]
-        if gpu:
-            for st in self.streams:
-                main.wait_stream(st)                  # the caller's stream continues behind every side stream
-        return outs
+from invertible_cd_amd.inflight import InFlight          # noqa: E402  (N independent batches in flight; part of the product)
 
 
 def time_leg(step, steps, warmup, batch, device, world, rank, decode=None, events_family=None):

@@ -67,6 +67,13 @@ def build(force=False, verbose=True):
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+        # hipcc's host pass drops a kernel template it cannot type-check WITHOUT a diagnostic (seen with a device-only builtin type in a
+        # kernel body): the object then lacks the fatbin and the kernels' stubs stay undefined until the first launch.  Fail here instead.
+        nm = subprocess.run(["nm", "-D", "--undefined-only", LIB], capture_output=True, text=True)
+        lost = [l.split()[-1] for l in nm.stdout.splitlines() if "__device_stub__" in l]
+        if lost:
+            os.remove(LIB)
+            raise RuntimeError(f"{len(lost)} kernels have no host stub (device code dropped by the host pass), e.g. {lost[0]}")
         with open(os.path.join(LIBDIR, "build_sha.txt"), "w") as f:
             f.write(sha + "\n")
         if verbose:

@@ -821,7 +821,11 @@ static int gemm_run(const icd_gemm_desc* d, void* stream, icd_gemm_plan_info* in
     hipStream_t st = (hipStream_t)stream;
     // ---- high-intensity tiles (gemm_big.hip), chosen from BIG_TILES by the cost model below ------------------------
     {
-        const bool conv_fast = d->mode == 1 && ((d->C0 + d->C1) % 64 == 0) && (d->C0 % 64 == 0);
+        // (the big conv tiles address their sources with 32-bit buffer offsets whose bit 31 marks a zero-padding read: < 2 GiB per source
+        // tensor, else the 128-wide kernels)
+        const long long conv_src_bytes = d->mode == 1 && d->rows_per_sample > 0
+            ? (long long)((d->M + d->rows_per_sample - 1) / d->rows_per_sample) * d->Hin * d->Win * std::max(d->C0, d->C1) * 2 : 0;
+        const bool conv_fast = d->mode == 1 && ((d->C0 + d->C1) % 64 == 0) && (d->C0 % 64 == 0) && conv_src_bytes < (1LL << 31) - (1 << 22);
         // transposed (V^T) outputs take the big tiles when a 32-row tile never straddles two samples and no pad columns
         // have to be zeroed (ldo == rows_per_sample); otherwise the 128-wide kernel's general epilogue handles them
         const bool trans_ok = !trans || (d->rows_per_sample % 32 == 0 && d->M % 32 == 0 && d->ldo == d->rows_per_sample);

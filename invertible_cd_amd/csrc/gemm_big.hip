@@ -187,6 +187,11 @@ __device__ __forceinline__ void xattn_epilogue_big(const GemmK& p, f32x16 (&acc)
     }
 }
 
+#ifndef ICD_CONV_CHUNK_MAJOR
+#define ICD_CONV_CHUNK_MAJOR 1
+#endif
+constexpr bool CONV_CHUNK_MAJOR = ICD_CONV_CHUNK_MAJOR != 0;       // K order of the conv tiles (see the loader)
+
 constexpr int enc_vmcnt(int n) { return ((n >> 4) << 14) | 0x0F70 | (n & 15); }
 
 template <int MODE, int WM, int WN, int TM, int TN, bool XATTN = false, bool CARRY = false>
@@ -222,25 +227,46 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_big_kernel(GemmK p) {
     const int Hu = p.Hin << p.upsample, Wu = p.Win << p.upsample;
     const int k_begin = kt_begin * BK;
 
-    const half_t* a_ptr[NAJ]; int a_inc[NAJ];
-    int a_pix[NAJ], a_yx[NAJ];                   // conv: b*Hin*Win (or -1 when the row is >= M), (y << 16) | x
+    // conv A operand (round 4): LDS-DMA through a BUFFER descriptor (buffer_load_dwordx4 ... offen lds) instead of 64-bit global pointers.
+    // Per 16-B chunk the loader keeps a 32-bit byte offset of the row's tap-(0,0) pixel in the source being read and the complement of a
+    // 9-bit tap-validity mask (zero padding, rows >= M); per k-tile the offset to issue is (that offset + a wave-uniform tap / channel term)
+    // with bit 31 set where the tap is invalid - out of the descriptor's range (sources < 2 GiB on this path, checked on the host), so the
+    // DMA writes zeros: 3 VALU issues per chunk and k-tile (add, bfe, lshl_or), no zero-page pointer select, no per-tap recompute of
+    // (y, x, pixel), two registers per chunk less than round 3's loader.  That economy is what makes the CHUNK-major K order affordable
+    // (k-tile = chunk * taps + tap: the nine taps of a 64-channel chunk back to back, the nine uses of a [rows + halo] x 64-channel slab inside
+    // nine consecutive k-tiles: L2 hits instead of 9 fabric reads per line; weights stay tap-major in memory), see profiles/r04_conv_korder.txt.
+    const half_t* a_ptr[NAJ]; int a_inc[NAJ];    // dense (MODE 0)
+    unsigned a_off[NAJ], a_nmsk[NAJ], a_voff[NAJ];   // conv: see above; a_nmsk bits 0..8 = tap INVALID, bits 9 / 10 = row / column parity (upsample)
+    int a_pix[NAJ];                              // conv: source pixel index of tap (0, 0) (a_off for the second concat source derives from it)
     const half_t* w_ptr[NWJ]; int w_inc[NWJ];
+    const int cpt = MODE == 1 ? Cin / BK : 1;    // k-tiles per tap
+    int u_tap, u_c;
+    if (CONV_CHUNK_MAJOR && MODE == 1) { const int ch = kt_begin / ntaps; u_tap = kt_begin - ch * ntaps; u_c = ch * BK; }
+    else { u_tap = MODE == 1 ? kt_begin / cpt : 0; u_c = MODE == 1 ? (kt_begin - u_tap * cpt) * BK : 0; }
+    const int w_k0 = (CONV_CHUNK_MAJOR && MODE == 1) ? u_tap * Cin + u_c : k_begin;
 #pragma unroll
     for (int j = 0; j < NAJ; ++j) {
         const int r = (wv * NAJ + j) * 8 + lrow;
         const int lc = pchunk ^ ((r >> 1) & 7);
         const int m = m0 + r;
         const int boff = (j & 3) * 512;          // bias for the instruction's immediate offset (halves)
-        a_ptr[j] = zero - boff; a_inc[j] = 0; a_pix[j] = -1; a_yx[j] = 0;
+        a_ptr[j] = zero - boff; a_inc[j] = 0; a_pix[j] = 0; a_nmsk[j] = 0x1ff; a_off[j] = 0; a_voff[j] = 0x80000000u;
         if (m < p.M) {
             if (MODE == 0) {
                 a_ptr[j] = p.a0 + (long long)m * p.lda + k_begin + lc * 8 - boff; a_inc[j] = BK;
             } else {
                 const int hw = p.Hout * p.Wout;
                 const int b = m / hw, rem = m - b * hw;
-                const int y = rem / p.Wout;
-                a_yx[j] = (y << 16) | (rem - y * p.Wout);
-                a_pix[j] = b * p.Hin * p.Win;
+                const int y = rem / p.Wout, x = rem - y * p.Wout;
+                const int yu0 = y * p.stride - pad, xu0 = x * p.stride - pad;
+                unsigned nm = 0x1ff;
+                for (int t = 0; t < ntaps; ++t) {
+                    const int dy = ntaps == 9 ? t / 3 : 0, dx = ntaps == 9 ? t - dy * 3 : 0;
+                    if ((unsigned)(yu0 + dy) < (unsigned)Hu && (unsigned)(xu0 + dx) < (unsigned)Wu) nm &= ~(1u << t);
+                }
+                if (p.upsample) nm |= ((unsigned)(yu0 & 1) << 9) | ((unsigned)(xu0 & 1) << 10);
+                a_nmsk[j] = nm;
+                a_pix[j] = b * p.Hin * p.Win + (yu0 >> p.upsample) * p.Win + (xu0 >> p.upsample);
             }
         }
     }
@@ -251,12 +277,56 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_big_kernel(GemmK p) {
         const int n = n0 + r;
         const bool ok = n < p.Nw;
         const int boff = (j & 3) * 512;
-        w_ptr[j] = ok ? p.w + (long long)n * p.ldw + k_begin + lc * 8 - boff : zero - boff;
-        w_inc[j] = ok ? BK : 0;
+        w_ptr[j] = ok ? p.w + (long long)n * p.ldw + w_k0 + lc * 8 - boff : zero - boff;
+        w_inc[j] = ok ? ((CONV_CHUNK_MAJOR && MODE == 1) ? -1 : BK) : 0;       // chunk-major: a mask for the per-k-tile step
     }
-    int u_tap = MODE == 1 ? k_begin / Cin : 0;
-    int u_c = MODE == 1 ? k_begin - u_tap * Cin : 0;
-    bool u_recompute = true;
+    // buffer descriptors of the (up to two) conv sources: base, bytes, raw 32-bit offsets, bounds-checked
+    const int conv_nb = MODE == 1 ? (p.M + p.Hout * p.Wout - 1) / (p.Hout * p.Wout) : 0;
+    const unsigned src_px = (unsigned)conv_nb * (unsigned)(p.Hin * p.Win);
+    (void)src_px;
+    // (the descriptor type exists in the device pass only: the host pass of hipcc, which needs nothing but the kernel's stub, would drop
+    //  the whole template silently - stubs undefined at load time - if it met it)
+#if defined(__HIP_DEVICE_COMPILE__)
+    const auto rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(p.a0), 0, MODE == 1 ? src_px * (unsigned)p.C0 * 2u : 0u, 0x00020000);
+    const auto rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(p.a1 ? p.a1 : p.a0), 0, MODE == 1 ? src_px * (unsigned)p.C1 * 2u : 0u, 0x00020000);
+#endif
+    bool u_first = true;                         // which concat source a_off[] was computed for
+    auto set_source = [&](bool first) {
+        const int Cs = first ? p.C0 : p.C1;
+#pragma unroll
+        for (int j = 0; j < NAJ; ++j) {
+            const int r = (wv * NAJ + j) * 8 + lrow;
+            const int lc = pchunk ^ ((r >> 1) & 7);
+            a_off[j] = ((unsigned)a_pix[j] * (unsigned)Cs + (unsigned)(lc * 8)) * 2u;
+        }
+        u_first = first;
+    };
+    int w_step = BK;
+    // offsets of the NEXT k-tile to be issued, computed right after the loads of the current one are in flight
+    auto conv_next = [&]() {
+        const int dy = (u_tap * 11) >> 5, dx = u_tap - dy * 3;       // (0, 0) for a 1 x 1 conv
+        const bool first = u_c < p.C0;
+        if (first != u_first) set_source(first);
+        const int Cs = first ? p.C0 : p.C1, cc = first ? u_c : u_c - p.C0;
+        const unsigned s_tap = (unsigned)(((dy * p.Win + dx) * Cs + cc) * 2);        // wave-uniform (no upsample)
+#pragma unroll
+        for (int j = 0; j < NAJ; ++j) {
+            unsigned off = a_off[j] + s_tap;
+            if (p.upsample) {
+                const int doff = (int)((((a_nmsk[j] >> 9) & 1) + dy) >> 1) * p.Win + (int)((((a_nmsk[j] >> 10) & 1) + dx) >> 1);
+                off = a_off[j] + (unsigned)((doff * Cs + cc) * 2);
+            }
+            a_voff[j] = off | (__builtin_amdgcn_ubfe(a_nmsk[j], (unsigned)u_tap, 1u) << 31);
+        }
+        if (CONV_CHUNK_MAJOR) {                                      // k-tile -> (chunk, tap)
+            w_step = Cin;
+            if (++u_tap == ntaps) { u_tap = 0; u_c += BK; w_step = BK - (ntaps - 1) * Cin; }
+        } else {                                                     // k-tile -> (tap, chunk)
+            u_c += BK;
+            if (u_c == Cin) { u_c = 0; ++u_tap; }
+        }
+    };
+    if (MODE == 1) { set_source(u_c < p.C0); conv_next(); }          // offsets of the first k-tile
 
     const int wave_a = __builtin_amdgcn_readfirstlane(wv * NAJ * 1024);
     const int wave_w = __builtin_amdgcn_readfirstlane(A_BYTES + wv * NWJ * 1024);
@@ -269,35 +339,23 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_big_kernel(GemmK p) {
         unsigned char* sa = smem + stage_off + wave_a;
         unsigned char* sw = smem + stage_off + wave_w;
         if (MODE == 1) {
-            if (u_recompute) {
-                const int dy = (u_tap * 11) >> 5, dx = u_tap - dy * 3;
-                const int oy = (ntaps == 9 ? dy : 0) - pad, ox = (ntaps == 9 ? dx : 0) - pad;
-                const bool first = u_c < p.C0;
+            const bool first = u_first;
 #pragma unroll
-                for (int j = 0; j < NAJ; ++j) {
-                    const int r = (wv * NAJ + j) * 8 + lrow;
-                    const int lc = pchunk ^ ((r >> 1) & 7);
-                    const int yu = (a_yx[j] >> 16) * p.stride + oy, xu = (a_yx[j] & 0xffff) * p.stride + ox;
-                    const bool ok = a_pix[j] >= 0 && (unsigned)yu < (unsigned)Hu && (unsigned)xu < (unsigned)Wu;
-                    const long long pix = a_pix[j] + (yu >> p.upsample) * p.Win + (xu >> p.upsample);
-                    const half_t* s0 = first ? p.a0 + pix * p.C0 + u_c : p.a1 + pix * p.C1 + (u_c - p.C0);
-                    a_ptr[j] = (ok ? s0 + lc * 8 : zero) - (j & 3) * 512;
-                    a_inc[j] = ok ? BK : 0;
-                }
+            for (int j = 0; j < NAJ; ++j) {
+#if defined(__HIP_DEVICE_COMPILE__)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(first ? rs0 : rs1, (__attribute__((address_space(3))) void*)(sa + j * 1024), 16, a_voff[j], 0, 0, 0);
+#endif
             }
-            u_c += BK;
-            u_recompute = false;
-            if (u_c == Cin) { u_c = 0; ++u_tap; u_recompute = true; }
-            else if (u_c == p.C0) u_recompute = true;
-        }
+        } else {
 #pragma unroll
-        for (int j = 0; j < NAJ; ++j) {
-            unsigned char* base = sa + (j >> 2) * 4096;
-            if ((j & 3) == 0) GLDS(a_ptr[j], base, 0);
-            else if ((j & 3) == 1) GLDS(a_ptr[j], base, 1024);
-            else if ((j & 3) == 2) GLDS(a_ptr[j], base, 2048);
-            else GLDS(a_ptr[j], base, 3072);
-            a_ptr[j] += a_inc[j];
+            for (int j = 0; j < NAJ; ++j) {
+                unsigned char* base = sa + (j >> 2) * 4096;
+                if ((j & 3) == 0) GLDS(a_ptr[j], base, 0);
+                else if ((j & 3) == 1) GLDS(a_ptr[j], base, 1024);
+                else if ((j & 3) == 2) GLDS(a_ptr[j], base, 2048);
+                else GLDS(a_ptr[j], base, 3072);
+                a_ptr[j] += a_inc[j];
+            }
         }
 #pragma unroll
         for (int j = 0; j < NWJ; ++j) {
@@ -306,8 +364,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_big_kernel(GemmK p) {
             else if ((j & 3) == 1) GLDS(w_ptr[j], base, 1024);
             else if ((j & 3) == 2) GLDS(w_ptr[j], base, 2048);
             else GLDS(w_ptr[j], base, 3072);
-            w_ptr[j] += w_inc[j];
+            w_ptr[j] += (CONV_CHUNK_MAJOR && MODE == 1) ? (w_step & w_inc[j]) : w_inc[j];
         }
+        if (MODE == 1) conv_next();
     };
 #undef GLDS
 

@@ -160,6 +160,17 @@ int icd_groupnorm(const void* x0, int32_t C0, const void* x1, int32_t C1, int32_
                   const float* gamma, const float* beta, float eps, int32_t silu, void* out, float* stats_ws,
                   void* stream);
 int64_t icd_groupnorm_ws_floats(int32_t B, int32_t HW, int32_t groups);
+/* GroupNorm of tensors of the residual stream that travel with their error carry (icd_gemm_desc.out_carry: value = fp16 + 2^-14 * bf8):
+ * the normalisation reads fp16 + carry (the statistics pass reads the fp16 part only).  carry0 / carry1: uint8 [B*HW, C0 / C1], either may
+ * be NULL.  aux (optional): fp16 [B*HW, ld_aux] written beside `out` for the split shortcut conv of a ResnetBlock2D
+ * (ICD_RESIDUAL_SPLIT) - with two sources [x1 (C1) | lo0 (C0) | lo1 (C1)], with one source [lo0 (C0)], lo = fp16(2^-14 * carry) - so that
+ * a two-source 1x1 conv over (x0, aux) with weights [W0 | W1 | W0 | W1] sees x0 + lo0 and x1 + lo1.  Everything else as icd_groupnorm. */
+int icd_groupnorm_carry(const void* x0, int32_t C0, const void* carry0, const void* x1, int32_t C1, const void* carry1, int32_t B,
+                        int32_t HW, int32_t groups, const float* gamma, const float* beta, float eps, int32_t silu, void* out, void* aux,
+                        int32_t ld_aux, float* stats_ws, void* stream);
+/* lo[i] = fp16(2^-14 * bf8(carry[i])), i < n (n %% 8 == 0): the second K segment of a split-operand GEMM, A = [hi | lo] against
+ * W = [W | W], for consumers of a carried tensor that no GroupNorm reads first (Transformer2DModel.proj_out, the downsampler conv). */
+int icd_carry_expand(const void* carry, int64_t n, void* lo, void* stream);
 
 /* fp32-fidelity path of the VAE (reference: vae.to(torch.float32), utils/generation_sdxl.py:465-466).  Activations that can
  * exceed the fp16 range (conv outputs, residual stream) are fp32 [rows, C]; GEMM operands are fp16 "split3" tensors
@@ -346,8 +357,14 @@ int32_t icd_unet_num_attention_layers(const icd_unet* u);
  *         ICD_RESIDUAL_FP16  (0)  plain fp16 stream (rounds 1 - 3's default);
  *         ICD_RESIDUAL_F32   (1)  fp32 twin: the chain accumulates in fp32 beside the fp16 copy the next operator reads
  *                                 (icd_gemm_desc.out_f32 + ICD_GEMM_RESID_F32): 0.7e-3, 6 more bytes per element and add;
- *         ICD_RESIDUAL_CARRY (2, default)  error carry: one bf8 byte per element keeps what the rounding lost
- *                                 (icd_gemm_desc.resid_carry / out_carry): the same 0.7e-3 for 2 more bytes per element and add.
+ *         ICD_RESIDUAL_CARRY (2)  error carry: one bf8 byte per element keeps what the rounding lost
+ *                                 (icd_gemm_desc.resid_carry / out_carry): the same 0.7e-3 for 2 more bytes per element and add;
+ *         ICD_RESIDUAL_SPLIT (3, default)  the carry, and the consumers that dominate what is left read it too: every GroupNorm
+ *                                 normalises fp16 + carry (icd_groupnorm_carry; conv1 and the sampler convs pass a carry on for it), and
+ *                                 the shortcut conv of the channel-changing resnets, proj_out and the downsampler conv take hi + lo as a
+ *                                 two-source GEMM over [x | lo] against [W | W] (tensors `<name>.weight2`; lo = fp16(2^-14 carry) from
+ *                                 icd_groupnorm_carry's aux output / icd_carry_expand): 0.40 - 0.45e-3, so that the 3 - 4 step forward
+ *                                 and edit loops of the reference stay inside 1e-3 (tests/error_budget_sim.py has the budget).
  *       load_models(dtype='fp32') (the reference's default, utils/loading.py:34,38) adds fp32 latents / eps at the boundary to it.
  *       Set before sizing the workspace.
  * Returns ICD_ERR_INVALID_ARG for an unknown option or value. */
@@ -356,6 +373,7 @@ int32_t icd_unet_num_attention_layers(const icd_unet* u);
 #define ICD_RESIDUAL_FP16  0
 #define ICD_RESIDUAL_F32   1
 #define ICD_RESIDUAL_CARRY 2
+#define ICD_RESIDUAL_SPLIT 3
 #define ICD_UNET_OPT_XATTN_FUSION    1
 #define ICD_UNET_OPT_LN_INLINE_STATS 2
 #define ICD_UNET_OPT_XATTN_TILE      3

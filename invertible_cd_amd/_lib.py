@@ -21,7 +21,7 @@ ICD_UNET_OPT_XATTN_TILE = 3
 ICD_UNET_OPT_ATTN_VALU_SCALE = 4
 ICD_UNET_OPT_RESIDUAL_MODE = 5
 ICD_UNET_OPT_RESIDUAL_F32 = 5           # round-3 name
-ICD_RESIDUAL_FP16, ICD_RESIDUAL_F32, ICD_RESIDUAL_CARRY = 0, 1, 2
+ICD_RESIDUAL_FP16, ICD_RESIDUAL_F32, ICD_RESIDUAL_CARRY, ICD_RESIDUAL_SPLIT = 0, 1, 2, 3
 ICD_ATTN_CAUSAL = 1
 ICD_ATTN_Q_PRESCALED = 2
 ICD_ATTN_TUNE_MODE0 = 4
@@ -101,6 +101,9 @@ SIGNATURES = {
     "icd_groupnorm": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                 C.c_void_p, C.c_void_p, C.c_float, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "icd_groupnorm_ws_floats": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
+    "icd_groupnorm_carry": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                      C.c_void_p, C.c_void_p, C.c_float, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "icd_carry_expand": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "icd_layernorm": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p,
                                 C.c_void_p]),
     "icd_groupnorm_f32_split": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_float,

@@ -110,7 +110,8 @@ __device__ __forceinline__ void carry_add8(float (&v)[8], const unsigned char* c
 __device__ __forceinline__ u32x2 carry_of8(const float (&v)[8], const f16x8& o) {
     float d[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) d[e] = (v[e] - (float)o[e]) * CARRY_SCALE;
+    for (int e = 0; e < 8; ++e)              // clamped to the largest finite e5m2 value: beyond |v| = 2^13 the carry saturates instead of
+        d[e] = __builtin_amdgcn_fmed3f((v[e] - (float)o[e]) * CARRY_SCALE, -57344.f, 57344.f);      // turning into inf / NaN in the stream
     unsigned w0 = __builtin_amdgcn_cvt_pk_bf8_f32(d[0], d[1], 0, false);
     w0 = __builtin_amdgcn_cvt_pk_bf8_f32(d[2], d[3], w0, true);
     unsigned w1 = __builtin_amdgcn_cvt_pk_bf8_f32(d[4], d[5], 0, false);

@@ -139,10 +139,12 @@ __device__ __forceinline__ void wave_epilogue(const GemmK& p, f32x16 (&acc)[TM][
     float* wst = reinterpret_cast<float*>(smem) + wv * (trans ? 64 * LDT : 32 * LDW);
     float* part = p.ksplit > 1 ? p.partial + (long long)split * p.M * p.N : nullptr;
     if constexpr (FAST_OK && CARRY)
-    if (!trans && !geglu && !part && !out_f32 && !p.out32 && p.out_c && !p.rowbias && !p.ln_stats && !(p.flags & ICD_GEMM_RESID_F32)) {
-        // the executor's carried residual stream: h <- h + f with the rounding error of the sum kept beside it, or the start of a chain
-        if (p.resid && p.resid_c) { wave_epilogue_fast<TM, TN, true, false, false, true, true>(p, acc, wst, wm, wn, l, m0, n0, ln_lds); return; }
-        if (!p.resid) { wave_epilogue_fast<TM, TN, false, false, false, false, true>(p, acc, wst, wm, wn, l, m0, n0, ln_lds); return; }
+    if (!trans && !geglu && !part && !out_f32 && !p.out32 && p.out_c && !p.ln_stats && !(p.flags & ICD_GEMM_RESID_F32)) {
+        // the executor's carried residual stream: h <- h + f with the rounding error of the sum kept beside it, or the start of a chain;
+        // round 5: conv1 of a ResnetBlock2D (+ time bias) hands its output to GroupNorm 2 with a carry too
+        if (p.resid && p.resid_c && !p.rowbias) { wave_epilogue_fast<TM, TN, true, false, false, true, true>(p, acc, wst, wm, wn, l, m0, n0, ln_lds); return; }
+        if (!p.resid && !p.rowbias) { wave_epilogue_fast<TM, TN, false, false, false, false, true>(p, acc, wst, wm, wn, l, m0, n0, ln_lds); return; }
+        if (!p.resid && p.rowbias) { wave_epilogue_fast<TM, TN, false, true, false, false, true>(p, acc, wst, wm, wn, l, m0, n0, ln_lds); return; }
     }
     if constexpr (!CARRY)
     if (FAST_OK && !trans && !geglu && !part && !out_f32 && !p.out32 && !(p.flags & ICD_GEMM_RESID_F32)) {

@@ -2,6 +2,7 @@
 //
 // All of them move fp16 NHWC / token-major activations with 16-byte per-lane accesses; statistics are fp32 and
 // reduced in a fixed order (no atomics) so results are bit-reproducible run to run.
+#include <algorithm>
 #include "common.h"
 
 namespace {
@@ -84,13 +85,30 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const half_t* __re
 // ---------------------------------------------------------------------------------------------------------------
 // GroupNorm pass 2: finish the statistics (fixed order), normalise, affine, optional SiLU, write one NHWC tensor.
 // ---------------------------------------------------------------------------------------------------------------
+// CARRY (round 5): the inputs are tensors of the residual stream that travel with their bf8 error carry (value = fp16 + 2^-14 * bf8,
+// gemm_common.h) - the normalisation reads fp16 + carry (the statistics pass keeps reading the fp16 part: a mean over thousands of
+// elements does not see rounding noise), i.e. one byte more per element on this pass only.  `aux` (optional, needs CARRY): the operand
+// the split shortcut conv of a ResnetBlock2D reads beside x0 - with two sources [x1 (C1) | lo0 (C0) | lo1 (C1)], with one source
+// [lo0 (C0)], lo = fp16(2^-14 * carry), row stride ld_aux - so that conv sees x0 + lo0 and x1 + lo1 through its two-source loader
+// (weights [W0 | W1 | W0 | W1]); written here because this kernel is the one that already holds x and its carry in registers.
+struct GnCarry { const unsigned char* c0; const unsigned char* c1; half_t* aux; int ld_aux; };
+
+__device__ __forceinline__ void gn_carry8(float (&f)[8], const u32x2 w) {
+    const f32x2 c0 = __builtin_amdgcn_cvt_pk_f32_bf8(w[0], false), c1 = __builtin_amdgcn_cvt_pk_f32_bf8(w[0], true);
+    const f32x2 c2 = __builtin_amdgcn_cvt_pk_f32_bf8(w[1], false), c3 = __builtin_amdgcn_cvt_pk_f32_bf8(w[1], true);
+    const float k = 1.f / 16384.f;
+    f[0] = c0[0] * k; f[1] = c0[1] * k; f[2] = c1[0] * k; f[3] = c1[1] * k;
+    f[4] = c2[0] * k; f[5] = c2[1] * k; f[6] = c3[0] * k; f[7] = c3[1] * k;
+}
+
+template <bool CARRY>
 __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const half_t* __restrict__ x0, int C0,
                                                                const half_t* __restrict__ x1, int C1, int HW,
                                                                int groups, int nsplit, int pix_per_block,
                                                                const float* __restrict__ ws,
                                                                const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, float eps, int silu,
-                                                               half_t* __restrict__ out) {
+                                                               half_t* __restrict__ out, GnCarry cy) {
     __shared__ float s_mean[64], s_rstd[64];
     const int C = C0 + C1, nchunk = C >> 3;
     const int rpi = GN_THREADS / nchunk;
@@ -129,15 +147,43 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const half_t* __re
     half_t* ob = out + (long long)b * HW * C + ch;
     const int p_begin = blockIdx.x * pix_per_block;
     const int p_end = min(HW, p_begin + pix_per_block);
-    auto norm8 = [&](const f16x8& v) {
+    // carry bytes of this thread's 8 channels (same [pixel][channel] layout as the fp16 tensor, one byte per element)
+    const unsigned char* cbase = nullptr;
+    half_t* aux_lo = nullptr; half_t* aux_hi = nullptr;
+    if (CARRY) {
+        const unsigned char* csrc = first ? cy.c0 : cy.c1;
+        if (csrc) cbase = csrc + (long long)b * HW * cs + (first ? ch : ch - C0);
+        if (cy.aux) {
+            half_t* arow = cy.aux + (long long)b * HW * cy.ld_aux;
+            aux_lo = arow + (C1 ? C1 : 0) + ch;                     // [x1 | lo0 | lo1]: lo of concat channel ch sits at C1 + ch
+            if (!first) aux_hi = arow + (ch - C0);
+        }
+    }
+    auto norm8 = [&](const f16x8& v, const u32x2 w, long long prow) {
         f16x8 o;
+        float cf[8];
+        if (CARRY) gn_carry8(cf, w);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            float f = (float)v[e] * sc[e] + sh[e];
+            float f = (float)v[e];
+            if (CARRY) f += cf[e];
+            f = f * sc[e] + sh[e];
             if (silu) f = silu_f(f);
             o[e] = (half_t)f;
         }
+        if (CARRY && aux_lo) {
+            f16x8 lo;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) lo[e] = (half_t)cf[e];
+            *reinterpret_cast<f16x8*>(aux_lo + prow * cy.ld_aux) = lo;
+            if (aux_hi) *reinterpret_cast<f16x8*>(aux_hi + prow * cy.ld_aux) = v;
+        }
         return o;
+    };
+    auto ldc = [&](long long prow) {
+        u32x2 w = {0u, 0u};
+        if (CARRY && cbase) w = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(cbase + prow * cs));
+        return w;
     };
     int p = p_begin + rsub;
     for (; p + 3 * rpi < p_end; p += 4 * rpi) {          // 4 loads in flight per thread
@@ -145,13 +191,14 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const half_t* __re
         f16x8 v1 = __builtin_nontemporal_load(reinterpret_cast<const f16x8*>(base + (long long)(p + rpi) * cs));
         f16x8 v2 = __builtin_nontemporal_load(reinterpret_cast<const f16x8*>(base + (long long)(p + 2 * rpi) * cs));
         f16x8 v3 = __builtin_nontemporal_load(reinterpret_cast<const f16x8*>(base + (long long)(p + 3 * rpi) * cs));
-        *reinterpret_cast<f16x8*>(ob + (long long)p * C) = norm8(v0);
-        *reinterpret_cast<f16x8*>(ob + (long long)(p + rpi) * C) = norm8(v1);
-        *reinterpret_cast<f16x8*>(ob + (long long)(p + 2 * rpi) * C) = norm8(v2);
-        *reinterpret_cast<f16x8*>(ob + (long long)(p + 3 * rpi) * C) = norm8(v3);
+        const u32x2 w0 = ldc(p), w1 = ldc(p + rpi), w2 = ldc(p + 2 * rpi), w3 = ldc(p + 3 * rpi);
+        *reinterpret_cast<f16x8*>(ob + (long long)p * C) = norm8(v0, w0, p);
+        *reinterpret_cast<f16x8*>(ob + (long long)(p + rpi) * C) = norm8(v1, w1, p + rpi);
+        *reinterpret_cast<f16x8*>(ob + (long long)(p + 2 * rpi) * C) = norm8(v2, w2, p + 2 * rpi);
+        *reinterpret_cast<f16x8*>(ob + (long long)(p + 3 * rpi) * C) = norm8(v3, w3, p + 3 * rpi);
     }
     for (; p < p_end; p += rpi)
-        *reinterpret_cast<f16x8*>(ob + (long long)p * C) = norm8(*reinterpret_cast<const f16x8*>(base + (long long)p * cs));
+        *reinterpret_cast<f16x8*>(ob + (long long)p * C) = norm8(*reinterpret_cast<const f16x8*>(base + (long long)p * cs), ldc(p), p);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -160,11 +207,12 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const half_t* __re
 // LDS in a fixed order, then re-reads it (L2-resident: <= 160 KiB per block) to normalise.  No workspace, no second
 // launch: at small batch the two-kernel form is pure launch latency (61 GroupNorms = 20 % of a B = 1 UNet evaluation).
 // ---------------------------------------------------------------------------------------------------------------
+template <bool CARRY>
 __global__ __launch_bounds__(GN_THREADS) void gn_small_kernel(const half_t* __restrict__ x0, int C0,
                                                                const half_t* __restrict__ x1, int C1, int HW, int groups,
                                                                int GPB, const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, float eps, int silu,
-                                                               half_t* __restrict__ out) {
+                                                               half_t* __restrict__ out, GnCarry cy) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int C = C0 + C1, cpg = C / groups, CB = GPB * cpg, nch = CB >> 3;
     const int rpi = GN_THREADS / nch;
@@ -232,15 +280,42 @@ __global__ __launch_bounds__(GN_THREADS) void gn_small_kernel(const half_t* __re
         sh[e] = beta[ch + e] - stat[g * 2] * sc[e];
     }
     half_t* ob = out + (long long)b * HW * C + ch;
-    auto norm8 = [&](const f16x8& v) {
+    const unsigned char* cbase = nullptr;
+    half_t* aux_lo = nullptr; half_t* aux_hi = nullptr;
+    if (CARRY) {
+        const unsigned char* csrc = first ? cy.c0 : cy.c1;
+        if (csrc) cbase = csrc + (long long)b * HW * cs + (first ? ch : ch - C0);
+        if (cy.aux) {
+            half_t* arow = cy.aux + (long long)b * HW * cy.ld_aux;
+            aux_lo = arow + C1 + ch;
+            if (!first) aux_hi = arow + (ch - C0);
+        }
+    }
+    auto norm8 = [&](const f16x8& v, const u32x2 w, long long prow) {
         f16x8 o;
+        float cf[8];
+        if (CARRY) gn_carry8(cf, w);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            float f = (float)v[e] * sc[e] + sh[e];
+            float f = (float)v[e];
+            if (CARRY) f += cf[e];
+            f = f * sc[e] + sh[e];
             if (silu) f = silu_f(f);
             o[e] = (half_t)f;
         }
+        if (CARRY && aux_lo) {
+            f16x8 lo;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) lo[e] = (half_t)cf[e];
+            *reinterpret_cast<f16x8*>(aux_lo + prow * cy.ld_aux) = lo;
+            if (aux_hi) *reinterpret_cast<f16x8*>(aux_hi + prow * cy.ld_aux) = v;
+        }
         return o;
+    };
+    auto ldc = [&](long long prow) {
+        u32x2 w = {0u, 0u};
+        if (CARRY && cbase) w = *reinterpret_cast<const u32x2*>(cbase + prow * cs);
+        return w;
     };
     int p = rsub;
     for (; p + 3 * rpi < HW; p += 4 * rpi) {
@@ -248,13 +323,14 @@ __global__ __launch_bounds__(GN_THREADS) void gn_small_kernel(const half_t* __re
         f16x8 v1 = *reinterpret_cast<const f16x8*>(base + (long long)(p + rpi) * cs);
         f16x8 v2 = *reinterpret_cast<const f16x8*>(base + (long long)(p + 2 * rpi) * cs);
         f16x8 v3 = *reinterpret_cast<const f16x8*>(base + (long long)(p + 3 * rpi) * cs);
-        *reinterpret_cast<f16x8*>(ob + (long long)p * C) = norm8(v0);
-        *reinterpret_cast<f16x8*>(ob + (long long)(p + rpi) * C) = norm8(v1);
-        *reinterpret_cast<f16x8*>(ob + (long long)(p + 2 * rpi) * C) = norm8(v2);
-        *reinterpret_cast<f16x8*>(ob + (long long)(p + 3 * rpi) * C) = norm8(v3);
+        const u32x2 w0 = ldc(p), w1 = ldc(p + rpi), w2 = ldc(p + 2 * rpi), w3 = ldc(p + 3 * rpi);
+        *reinterpret_cast<f16x8*>(ob + (long long)p * C) = norm8(v0, w0, p);
+        *reinterpret_cast<f16x8*>(ob + (long long)(p + rpi) * C) = norm8(v1, w1, p + rpi);
+        *reinterpret_cast<f16x8*>(ob + (long long)(p + 2 * rpi) * C) = norm8(v2, w2, p + 2 * rpi);
+        *reinterpret_cast<f16x8*>(ob + (long long)(p + 3 * rpi) * C) = norm8(v3, w3, p + 3 * rpi);
     }
     for (; p < HW; p += rpi)
-        *reinterpret_cast<f16x8*>(ob + (long long)p * C) = norm8(*reinterpret_cast<const f16x8*>(base + (long long)p * cs));
+        *reinterpret_cast<f16x8*>(ob + (long long)p * C) = norm8(*reinterpret_cast<const f16x8*>(base + (long long)p * cs), ldc(p), p);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -615,16 +691,20 @@ extern "C" int64_t icd_groupnorm_ws_floats(int32_t B, int32_t HW, int32_t groups
     return (int64_t)B * nsplit * groups * 2;
 }
 
-extern "C" int icd_groupnorm(const void* x0, int32_t C0, const void* x1, int32_t C1, int32_t B, int32_t HW,
-                             int32_t groups, const float* gamma, const float* beta, float eps, int32_t silu,
-                             void* out, float* stats_ws, void* stream) {
-    ICD_CHECK_ARG(x0 && out && stats_ws && gamma && beta, "icd_groupnorm: null pointer");
+static int groupnorm_run(const void* x0, int32_t C0, const void* c0, const void* x1, int32_t C1, const void* c1, int32_t B, int32_t HW,
+                         int32_t groups, const float* gamma, const float* beta, float eps, int32_t silu, void* out, void* aux,
+                         int32_t ld_aux, float* stats_ws, void* stream, const char* who) {
+    ICD_CHECK_ARG(x0 && out && stats_ws && gamma && beta, "%s: null pointer", who);
     const int C = C0 + C1;
-    ICD_CHECK_ARG(C0 > 0 && C0 % 8 == 0 && C1 >= 0 && C1 % 8 == 0, "icd_groupnorm: channels must be multiples of 8");
-    ICD_CHECK_ARG((C1 == 0) == (x1 == nullptr), "icd_groupnorm: x1/C1 mismatch");
-    ICD_CHECK_ARG(groups > 0 && groups <= 32 && C % groups == 0, "icd_groupnorm: bad group count %d for C=%d", groups, C);
-    ICD_CHECK_ARG(C / 8 <= GN_THREADS, "icd_groupnorm: C=%d too large", C);
-    ICD_CHECK_ARG(B > 0 && HW > 0, "icd_groupnorm: empty input");
+    ICD_CHECK_ARG(C0 > 0 && C0 % 8 == 0 && C1 >= 0 && C1 % 8 == 0, "%s: channels must be multiples of 8", who);
+    ICD_CHECK_ARG((C1 == 0) == (x1 == nullptr), "%s: x1/C1 mismatch", who);
+    ICD_CHECK_ARG(groups > 0 && groups <= 32 && C % groups == 0, "%s: bad group count %d for C=%d", who, groups, C);
+    ICD_CHECK_ARG(C / 8 <= GN_THREADS, "%s: C=%d too large", who, C);
+    ICD_CHECK_ARG(B > 0 && HW > 0, "%s: empty input", who);
+    ICD_CHECK_ARG(!(c1 && !x1), "%s: carry of an absent second source", who);
+    ICD_CHECK_ARG(!aux || (ld_aux % 8 == 0 && ld_aux >= C0 + 2 * C1), "%s: aux needs ld_aux %% 8 == 0 and >= C0 + 2 * C1", who);
+    const bool carry = c0 || c1 || aux;
+    const GnCarry cy{(const unsigned char*)c0, (const unsigned char*)c1, (half_t*)aux, ld_aux};
     hipStream_t st = (hipStream_t)stream;
     {   // small maps: one launch, a block per (sample, slab of whole groups whose channel count is a multiple of 8)
         const int cpg = C / groups;
@@ -638,8 +718,12 @@ extern "C" int icd_groupnorm(const void* x0, int32_t C0, const void* x1, int32_t
             const int rpi_s = GN_THREADS / (cb / 8);
             const size_t smem_s = ((size_t)rpi_s * cb * 2 + (size_t)cb * 2 + (size_t)gpb * 2) * sizeof(float);
             if (smem_s <= 64 * 1024) {
-                hipLaunchKernelGGL(gn_small_kernel, dim3(groups / gpb, B), dim3(GN_THREADS), smem_s, st, (const half_t*)x0, C0,
-                                   (const half_t*)x1, C1, HW, groups, gpb, gamma, beta, eps, silu, (half_t*)out);
+                if (carry)
+                    hipLaunchKernelGGL(gn_small_kernel<true>, dim3(groups / gpb, B), dim3(GN_THREADS), smem_s, st, (const half_t*)x0, C0,
+                                       (const half_t*)x1, C1, HW, groups, gpb, gamma, beta, eps, silu, (half_t*)out, cy);
+                else
+                    hipLaunchKernelGGL(gn_small_kernel<false>, dim3(groups / gpb, B), dim3(GN_THREADS), smem_s, st, (const half_t*)x0, C0,
+                                       (const half_t*)x1, C1, HW, groups, gpb, gamma, beta, eps, silu, (half_t*)out, cy);
                 ICD_CHECK_LAUNCH("icd_groupnorm(small)");
                 return ICD_OK;
             }
@@ -649,16 +733,57 @@ extern "C" int icd_groupnorm(const void* x0, int32_t C0, const void* x1, int32_t
     const int nsplit = (HW + pps - 1) / pps;
     const int rpi = GN_THREADS / (C / 8);
     const size_t smem = (size_t)rpi * C * 2 * sizeof(float);
-    ICD_CHECK_ARG(smem <= 64 * 1024, "icd_groupnorm: LDS budget exceeded");
+    ICD_CHECK_ARG(smem <= 64 * 1024, "%s: LDS budget exceeded", who);
     hipLaunchKernelGGL(gn_stats_kernel, dim3(nsplit, B), dim3(GN_THREADS), smem, st, (const half_t*)x0, C0,
                        (const half_t*)x1, C1, HW, groups, pps, stats_ws);
     ICD_CHECK_LAUNCH("icd_groupnorm(stats)");
     // pixels per apply block: 512 - 1024 blocks per launch (same sweep: 128 at B x HW = 131072, 64 at 32768; 256 only pays on the
     // 128 x 128 maps and by < 2 %)
     const int ppb = (long long)B * HW >= 98304 ? 128 : 64;
-    hipLaunchKernelGGL(gn_apply_kernel, dim3((HW + ppb - 1) / ppb, B), dim3(GN_THREADS), 0, st, (const half_t*)x0, C0,
-                       (const half_t*)x1, C1, HW, groups, nsplit, ppb, stats_ws, gamma, beta, eps, silu, (half_t*)out);
+    if (carry)
+        hipLaunchKernelGGL(gn_apply_kernel<true>, dim3((HW + ppb - 1) / ppb, B), dim3(GN_THREADS), 0, st, (const half_t*)x0, C0,
+                           (const half_t*)x1, C1, HW, groups, nsplit, ppb, stats_ws, gamma, beta, eps, silu, (half_t*)out, cy);
+    else
+        hipLaunchKernelGGL(gn_apply_kernel<false>, dim3((HW + ppb - 1) / ppb, B), dim3(GN_THREADS), 0, st, (const half_t*)x0, C0,
+                           (const half_t*)x1, C1, HW, groups, nsplit, ppb, stats_ws, gamma, beta, eps, silu, (half_t*)out, cy);
     ICD_CHECK_LAUNCH("icd_groupnorm(apply)");
+    return ICD_OK;
+}
+
+extern "C" int icd_groupnorm(const void* x0, int32_t C0, const void* x1, int32_t C1, int32_t B, int32_t HW,
+                             int32_t groups, const float* gamma, const float* beta, float eps, int32_t silu,
+                             void* out, float* stats_ws, void* stream) {
+    return groupnorm_run(x0, C0, nullptr, x1, C1, nullptr, B, HW, groups, gamma, beta, eps, silu, out, nullptr, 0, stats_ws, stream,
+                         "icd_groupnorm");
+}
+
+extern "C" int icd_groupnorm_carry(const void* x0, int32_t C0, const void* carry0, const void* x1, int32_t C1, const void* carry1,
+                                   int32_t B, int32_t HW, int32_t groups, const float* gamma, const float* beta, float eps,
+                                   int32_t silu, void* out, void* aux, int32_t ld_aux, float* stats_ws, void* stream) {
+    return groupnorm_run(x0, C0, carry0, x1, C1, carry1, B, HW, groups, gamma, beta, eps, silu, out, aux, ld_aux, stats_ws, stream,
+                         "icd_groupnorm_carry");
+}
+
+// lo = fp16(2^-14 * carry): the second K segment of a split-operand GEMM (A = [hi | lo], W = [W | W]) for consumers of a carried
+// tensor that no GroupNorm reads first (proj_out of a Transformer2DModel, the downsampler conv)
+__global__ __launch_bounds__(256) void carry_expand_kernel(const unsigned char* __restrict__ c, long long n8, half_t* __restrict__ lo) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
+        const u32x2 w = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(c) + i);
+        float cf[8];
+        gn_carry8(cf, w);
+        f16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (half_t)cf[e];
+        *(reinterpret_cast<f16x8*>(lo) + i) = o;
+    }
+}
+
+extern "C" int icd_carry_expand(const void* carry, int64_t n, void* lo, void* stream) {
+    ICD_CHECK_ARG(carry && lo && n > 0 && n % 8 == 0, "icd_carry_expand: null pointer or element count not a multiple of 8");
+    const long long n8 = n / 8;
+    const int blocks = (int)std::min<long long>((n8 + 255) / 256, 4096);
+    hipLaunchKernelGGL(carry_expand_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const unsigned char*)carry, n8, (half_t*)lo);
+    ICD_CHECK_LAUNCH("icd_carry_expand");
     return ICD_OK;
 }
 

@@ -126,9 +126,17 @@ struct icd_unet {
     //   0  fp16 stream.
     //   1  fp32 twin (round 3): the chain accumulates in fp32 beside the fp16 copy every consumer reads - 0.7e-3, 6 more bytes per
     //      element and add (-9 % SD1.5, -7 % SDXL).
-    //   2  error carry (round 4, default): one bf8 byte per element holds what the fp16 rounding lost (icd_gemm_desc.resid_carry /
+    //   2  error carry (round 4): one bf8 byte per element holds what the fp16 rounding lost (icd_gemm_desc.resid_carry /
     //      out_carry) - the same 0.7e-3 for 2 more bytes per element and add.
-    int resid_mode = 2;
+    //   3  carry + split consumers (round 5, default).  With mode 2 the stream itself is accurate, but its CONSUMERS still read the fp16
+    //      part alone, and tests/error_budget_sim.py attributes 60 % of the remaining eps variance to exactly that (profiles/
+    //      r05_error_budget.txt): GroupNorm inputs 25 + 11 % (stream / skips), the shortcut conv of the channel-changing resnets 20 %,
+    //      proj_out 10 %, the sampler convs 8 %; the LayerNorm-folded projections - the expensive readers - only 2 %.  Mode 3:
+    //      every GroupNorm normalises fp16 + carry (one more byte per element on its apply pass; conv1 and the sampler convs hand
+    //      their outputs on with a carry for it), and the shortcut conv, proj_out and the downsampler conv read hi + lo as a
+    //      two-source GEMM over [x | lo] against [W | W] (lo = fp16(2^-14 carry), written by the GroupNorm that reads the same tensor
+    //      or by icd_carry_expand): +2 % of the UNet's flops on its cheapest GEMMs.  eps 0.69e-3 -> 0.40e-3 in the simulation.
+    int resid_mode = 3;
 };
 
 namespace {
@@ -251,10 +259,28 @@ struct Exec {
     }
     void free_act(Act& a) { release(a.p); release(a.aux); a.p = nullptr; a.aux = nullptr; }
     void free_aux(Act& a) { release(a.aux); a.aux = nullptr; }
-    void groupnorm(const Act& x0, const Act* x1, int HW, const float* g, const float* b, float eps, int silu, half_t* out) {
+    // split mode: the inputs' error carries are read by the apply pass; aux (optional) = the [x1 | lo0 | lo1] / [lo0] operand of the
+    // resnet's split shortcut conv (icd_groupnorm_carry)
+    bool split() const { return u->resid_mode == 3; }
+    void groupnorm(const Act& x0, const Act* x1, int HW, const float* g, const float* b, float eps, int silu, half_t* out,
+                   half_t* aux = nullptr, int ld_aux = 0) {
         if (!ok() || dry) return;
-        ProfScope ps(true, st, ICD_PROF_GROUPNORM, 0.0, 6.0 * B * (double)HW * (x0.C + (x1 ? x1->C : 0)));
-        run(icd_groupnorm(x0.p, x0.C, x1 ? x1->p : nullptr, x1 ? x1->C : 0, B, HW, u->cfg.norm_groups, g, b, eps, silu, out, gn_ws, st));
+        const int C = x0.C + (x1 ? x1->C : 0);
+        ProfScope ps(true, st, ICD_PROF_GROUPNORM, 0.0, (split() ? 7.0 : 6.0) * B * (double)HW * C + 2.0 * B * (double)HW * (aux ? ld_aux : 0));
+        if (split())
+            run(icd_groupnorm_carry(x0.p, x0.C, x0.aux, x1 ? x1->p : nullptr, x1 ? x1->C : 0, x1 ? x1->aux : nullptr, B, HW,
+                                    u->cfg.norm_groups, g, b, eps, silu, out, aux, ld_aux, gn_ws, st));
+        else
+            run(icd_groupnorm(x0.p, x0.C, x1 ? x1->p : nullptr, x1 ? x1->C : 0, B, HW, u->cfg.norm_groups, g, b, eps, silu, out, gn_ws, st));
+    }
+    // lo = fp16(2^-14 carry) of a carried tensor for a split consumer that no GroupNorm precedes
+    half_t* expand(const void* carry, long long elems) {
+        half_t* lo = alloc<half_t>(elems);
+        if (ok() && !dry) {
+            ProfScope ps(true, st, ICD_PROF_MISC, 0.0, 3.0 * (double)elems);
+            run(icd_carry_expand(carry, elems, lo, st));
+        }
+        return lo;
     }
     // LayerNorm statistics by a pass over the stream (2 B / element read) - only when the consuming GEMM does not compute them
     void ln_stats(const half_t* x, long long rows, int C, float* stats) {
@@ -268,17 +294,23 @@ struct Exec {
         const int HW = Hh * Ww, Cin = x0.C + (x1 ? x1->C : 0);
         const long long M = (long long)B * HW;
         half_t* n1 = alloc<half_t>(M * Cin);
-        groupnorm(x0, x1, HW, Wf(p + ".norm1.weight", Cin), Wf(p + ".norm1.bias", Cin), 1e-5f, 1, n1);
+        // split mode, channel-changing resnet: norm1 also writes the second source of the split shortcut conv
+        const bool split_sc = split() && Cin != Cout;
+        const int ld_sc = x0.C + (x1 ? 2 * x1->C : 0);
+        half_t* sc_src = split_sc ? alloc<half_t>(M * ld_sc) : nullptr;
+        groupnorm(x0, x1, HW, Wf(p + ".norm1.weight", Cin), Wf(p + ".norm1.bias", Cin), 1e-5f, 1, n1, sc_src, ld_sc);
         half_t* h1 = alloc<half_t>(M * Cout);
+        void* h1c = split() ? alloc_aux(M * Cout) : nullptr;     // conv1's output goes to norm2 with its carry
         Act n1a{n1, Cin};
         conv(n1a, nullptr, Hh, Ww, 3, 1, 0, Wh(p + ".conv1.weight", 9LL * Cin * Cout), Cout, Wf(p + ".conv1.bias", Cout),
-             temb_all + temb_off, u->temb_total, nullptr, h1);
+             temb_all + temb_off, u->temb_total, nullptr, h1, nullptr, h1c);
         temb_off += Cout;
         release(n1);
         half_t* n2 = alloc<half_t>(M * Cout);
         Act h1a{h1, Cout};
+        h1a.aux = h1c;
         groupnorm(h1a, nullptr, HW, Wf(p + ".norm2.weight", Cout), Wf(p + ".norm2.bias", Cout), 1e-5f, 1, n2);
-        release(h1);
+        release(h1); release(h1c);
         const int rm = u->resid_mode;
         const half_t* resid = x0.p;
         const void* resid_aux = rm ? x0.aux : nullptr;
@@ -289,6 +321,13 @@ struct Exec {
                 sc_aux = alloc<float>(M * Cout);
                 conv(x0, x1, Hh, Ww, 1, 1, 0, Wh(p + ".conv_shortcut.weight", (long long)Cin * Cout), Cout,
                      Wf(p + ".conv_shortcut.bias", Cout), nullptr, 0, nullptr, sc_aux, nullptr, nullptr, true);
+            } else if (split_sc) {                   // [x0 | x1 | lo0 | lo1] against [W | W]: the shortcut of the values the stream holds
+                sc = alloc<half_t>(M * Cout);
+                sc_aux = alloc_aux(M * Cout);
+                Act s1{sc_src, ld_sc};
+                conv(x0, &s1, Hh, Ww, 1, 1, 0, Wh(p + ".conv_shortcut.weight2", 2LL * Cin * Cout), Cout,
+                     Wf(p + ".conv_shortcut.bias", Cout), nullptr, 0, nullptr, sc, nullptr, sc_aux);
+                resid = sc;
             } else {                                 // fp16 (+ its error carry in mode 2)
                 sc = alloc<half_t>(M * Cout);
                 sc_aux = alloc_aux(M * Cout);
@@ -296,6 +335,7 @@ struct Exec {
                      Wf(p + ".conv_shortcut.bias", Cout), nullptr, 0, nullptr, sc, nullptr, sc_aux);
                 resid = sc;
             }
+            release(sc_src);
             resid_aux = sc_aux;
         }
         half_t* out = alloc<half_t>(M * Cout);
@@ -452,9 +492,18 @@ struct Exec {
         release(lnst);
         half_t* out = alloc<half_t>(M * C);
         void* out_aux = alloc_aux(M * C);
-        release(hx);                                 // (proj_out reads the fp16 copy of the stream as its operand)
-        linear(h, C, (int)M, C, Wh(p + ".proj_out.weight", (long long)C * C), C, Wf(p + ".proj_out.bias", C), (tw && x.aux) ? nullptr : x.p, C, out, C,
-               0, 0, nullptr, nullptr, x.aux, out_aux);
+        if (split()) {                               // proj_out over [h | lo] against [W | W] (a two-source 1x1 conv)
+            half_t* lo = expand(hx, M * C);
+            release(hx);
+            Act ha{h, C}, la{lo, C};
+            conv(ha, &la, Hh, Ww, 1, 1, 0, Wh(p + ".proj_out.weight2", 2LL * C * C), C, Wf(p + ".proj_out.bias", C), nullptr, 0, x.p, out,
+                 x.aux, out_aux);
+            release(lo);
+        } else {
+            release(hx);                             // (proj_out reads the fp16 copy of the stream as its operand)
+            linear(h, C, (int)M, C, Wh(p + ".proj_out.weight", (long long)C * C), C, Wf(p + ".proj_out.bias", C), (tw && x.aux) ? nullptr : x.p, C, out, C,
+                   0, 0, nullptr, nullptr, x.aux, out_aux);
+        }
         release(h);
         Act o{out, C};
         o.aux = out_aux;
@@ -558,7 +607,9 @@ struct Exec {
         }
         // the skip stack keeps the fp16 tensors (their consumers concatenate them as GEMM / GroupNorm operands); the fp32 twin / error
         // carry of a tensor lives only until the one operator that uses it as a residual has run
-        skips.push_back(Act{h.p, h.C});
+        const bool sp = split();
+        auto skip_of = [&](const Act& a) { Act s{a.p, a.C}; if (sp) s.aux = a.aux; return s; };   // split mode: skips keep their carry
+        skips.push_back(skip_of(h));
         int Hh = H0, Ww = W0;
         // ---------------- down
         for (int i = 0; i < L && ok(); ++i) {
@@ -567,7 +618,7 @@ struct Exec {
                 const std::string rp = "down_blocks." + std::to_string(i) + ".resnets." + std::to_string(j);
                 Act r = resnet(rp, h, nullptr, Hh, Ww, Cout);
                 // h stays alive: it is on the skip stack (its twin / carry has served as this resnet's residual)
-                free_aux(h);
+                if (!sp) free_aux(h);
                 h = r;
                 if (c.down_has_attn[i]) {
                     Act t = transformer("down_blocks." + std::to_string(i) + ".attentions." + std::to_string(j), h, Hh, Ww,
@@ -575,26 +626,34 @@ struct Exec {
                     free_act(h);
                     h = t;
                 }
-                skips.push_back(Act{h.p, h.C});
+                skips.push_back(skip_of(h));
             }
             if (i < L - 1) {
                 const std::string dp = "down_blocks." + std::to_string(i) + ".downsamplers.0.conv";
                 Act dn{alloc<half_t>((long long)B * (Hh / 2) * (Ww / 2) * Cout), Cout};
                 // (it is a residual only where the next level keeps the channel count: SD1.5's last level)
-                if (c.block_out_channels[i + 1] == Cout) dn.aux = alloc_aux((long long)B * (Hh / 2) * (Ww / 2) * Cout);
-                conv(h, nullptr, Hh, Ww, 3, 2, 0, Wh(dp + ".weight", 9LL * Cout * Cout), Cout, Wf(dp + ".bias", Cout), nullptr, 0, nullptr, dn.p,
-                     nullptr, dn.aux);
-                free_aux(h);
+                if (sp || c.block_out_channels[i + 1] == Cout) dn.aux = alloc_aux((long long)B * (Hh / 2) * (Ww / 2) * Cout);
+                if (sp) {                            // the stride-2 conv over [h | lo] against per-tap [W | W]
+                    half_t* lo = expand(h.aux, (long long)B * Hh * Ww * Cout);
+                    Act la{lo, Cout};
+                    conv(h, &la, Hh, Ww, 3, 2, 0, Wh(dp + ".weight2", 18LL * Cout * Cout), Cout, Wf(dp + ".bias", Cout), nullptr, 0, nullptr, dn.p,
+                         nullptr, dn.aux);
+                    release(lo);
+                } else {
+                    conv(h, nullptr, Hh, Ww, 3, 2, 0, Wh(dp + ".weight", 9LL * Cout * Cout), Cout, Wf(dp + ".bias", Cout), nullptr, 0, nullptr, dn.p,
+                         nullptr, dn.aux);
+                    free_aux(h);
+                }
                 Hh /= 2; Ww /= 2;
                 h = dn;
-                skips.push_back(Act{h.p, h.C});
+                skips.push_back(skip_of(h));
             }
         }
         // ---------------- mid
         {
             const int Cm = c.block_out_channels[L - 1];
             Act r0 = resnet("mid_block.resnets.0", h, nullptr, Hh, Ww, Cm);     // h is the last skip: stays alive
-            free_aux(h);
+            if (!sp) free_aux(h);
             Act t = transformer("mid_block.attentions.0", r0, Hh, Ww, c.transformer_layers[L - 1], c.num_heads[L - 1], 1);
             free_act(r0);
             Act r1 = resnet("mid_block.resnets.1", t, nullptr, Hh, Ww, Cm);
@@ -609,7 +668,7 @@ struct Exec {
                 Act sk = skips.back(); skips.pop_back();
                 const std::string rp = "up_blocks." + std::to_string(i) + ".resnets." + std::to_string(j);
                 Act r = resnet(rp, h, &sk, Hh, Ww, Cout);
-                free_act(h); release(sk.p);
+                free_act(h); release(sk.p); release(sk.aux);
                 h = r;
                 if (c.up_has_attn[i]) {
                     Act t = transformer("up_blocks." + std::to_string(i) + ".attentions." + std::to_string(j), h, Hh, Ww,
@@ -617,12 +676,14 @@ struct Exec {
                     free_act(h);
                     h = t;
                 }
-                free_aux(h);                         // the next resnet concatenates h with a skip: Cin != Cout, its residual is the shortcut
-            }
+                if (!sp) free_aux(h);                // the next resnet concatenates h with a skip: Cin != Cout, its residual is the shortcut
+            }                                        // (split mode: its GroupNorm and its split shortcut read the carry)
             if (i < L - 1) {
                 const std::string upn = "up_blocks." + std::to_string(i) + ".upsamplers.0.conv";
                 Act up{alloc<half_t>((long long)B * (Hh * 2) * (Ww * 2) * Cout), Cout};
-                conv(h, nullptr, Hh, Ww, 3, 1, 1, Wh(upn + ".weight", 9LL * Cout * Cout), Cout, Wf(upn + ".bias", Cout), nullptr, 0, nullptr, up.p);
+                if (sp) up.aux = alloc_aux((long long)B * (Hh * 2) * (Ww * 2) * Cout);
+                conv(h, nullptr, Hh, Ww, 3, 1, 1, Wh(upn + ".weight", 9LL * Cout * Cout), Cout, Wf(upn + ".bias", Cout), nullptr, 0, nullptr, up.p,
+                     nullptr, up.aux);
                 free_act(h);
                 Hh *= 2; Ww *= 2;
                 h = up;
@@ -678,7 +739,7 @@ extern "C" int icd_unet_set_option(icd_unet* u, int32_t option, int32_t value) {
         ICD_CHECK_ARG(value == 0 || value == 1, "icd_unet_set_option: ICD_UNET_OPT_ATTN_VALU_SCALE takes 0 or 1 (got %d)", value);
         u->attn_mode0 = value != 0; return ICD_OK;
     case ICD_UNET_OPT_RESIDUAL_MODE:
-        ICD_CHECK_ARG(value >= 0 && value <= 2, "icd_unet_set_option: ICD_UNET_OPT_RESIDUAL_MODE takes 0, 1 or 2 (got %d)", value);
+        ICD_CHECK_ARG(value >= 0 && value <= 3, "icd_unet_set_option: ICD_UNET_OPT_RESIDUAL_MODE takes 0 .. 3 (got %d)", value);
         u->resid_mode = value; return ICD_OK;
     case ICD_UNET_OPT_LN_INLINE_STATS:
         ICD_CHECK_ARG(value == 0 || value == 1, "icd_unet_set_option: ICD_UNET_OPT_LN_INLINE_STATS takes 0 or 1 (got %d)", value);

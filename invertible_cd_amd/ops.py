@@ -124,7 +124,7 @@ def carry_decode(hi, carry):
 def carry_encode(v):
     """(hi, carry) of an fp32 tensor, as the GEMM epilogues produce them (round to nearest even twice)."""
     hi = v.half()
-    return hi, ((v.float() - hi.float()) * CARRY_SCALE).to(torch.float8_e5m2).view(torch.uint8)
+    return hi, ((v.float() - hi.float()) * CARRY_SCALE).clamp(-57344.0, 57344.0).to(torch.float8_e5m2).view(torch.uint8)
 
 
 def conv3x3(x, B, H, W, w_packed, bias=None, x2=None, stride=1, upsample=False, resid=None, rowbias=None, ksize=3,
@@ -170,6 +170,31 @@ def groupnorm(x, B, HW, gamma, beta, eps, silu, x2=None, groups=32):
     _lib.check(lib.icd_groupnorm(_p(x), C0, _p(x2), C1, B, HW, groups, _p(gamma), _p(beta), eps, int(silu), _p(out),
                                  _p(ws), _stream()), "icd_groupnorm")
     return out
+
+
+def groupnorm_carry(x, B, HW, gamma, beta, eps, silu, carry=None, x2=None, carry2=None, groups=32, with_aux=False):
+    """GroupNorm (+SiLU) of carried tensors (icd_groupnorm_carry): normalises fp16 + 2^-14 * bf8 carry.  with_aux: also returns the
+    second source of a split shortcut conv, fp16 [B*HW, C0 + 2 C1] = [x2 | lo | lo2] ([lo] without x2)."""
+    _chk16(x, "x")
+    C0 = x.shape[-1]
+    C1 = x2.shape[-1] if x2 is not None else 0
+    lib = _lib.load()
+    ws = torch.empty((lib.icd_groupnorm_ws_floats(B, HW, groups),), device=x.device, dtype=torch.float32)
+    out = torch.empty((B * HW, C0 + C1), device=x.device, dtype=torch.float16)
+    aux = torch.empty((B * HW, C0 + 2 * C1), device=x.device, dtype=torch.float16) if with_aux else None
+    for c, t in ((carry, x), (carry2, x2)):
+        assert c is None or (c.dtype == torch.uint8 and c.is_cuda and c.is_contiguous() and c.shape == t.shape)
+    _lib.check(lib.icd_groupnorm_carry(_p(x), C0, _p(carry), _p(x2), C1, _p(carry2), B, HW, groups, _p(gamma), _p(beta), eps, int(silu),
+                                       _p(out), _p(aux), C0 + 2 * C1 if with_aux else 0, _p(ws), _stream()), "icd_groupnorm_carry")
+    return (out, aux) if with_aux else out
+
+
+def carry_expand(carry):
+    """lo = fp16(2^-14 * bf8 carry) (icd_carry_expand): the second K segment of a split-operand GEMM."""
+    assert carry.dtype == torch.uint8 and carry.is_cuda and carry.is_contiguous() and carry.numel() % 8 == 0
+    lo = torch.empty(carry.shape, device=carry.device, dtype=torch.float16)
+    _lib.check(_lib.load().icd_carry_expand(_p(carry), carry.numel(), _p(lo), _stream()), "icd_carry_expand")
+    return lo
 
 
 def groupnorm_f32_split(x32, B, HW, gamma, beta, eps, silu, groups=32):

@@ -63,10 +63,18 @@ def pack_state_dict(cfg: UNetConfig, sd, device):
         consumed.add(k)
         return sd[k]
 
-    def conv(name):
+    def conv(name, split=False):
         w = take(name + ".weight")
         packed[name + ".weight"] = w16(w.permute(0, 2, 3, 1).reshape(w.shape[0], -1)) if w.dim() == 4 else w16(w)
         packed[name + ".bias"] = f32(take(name + ".bias"))
+        if split:
+            split2(name, w)
+
+    def split2(name, w):
+        """`.weight2` of a split-operand consumer (residual mode 3): the operand is [x | lo] per tap (lo = what the fp16 rounding of the
+        carried stream lost), the weight [W | W] per tap - W (hi + lo) on the unchanged two-source loader."""
+        w4 = w.reshape(w.shape[0], w.shape[1], -1).permute(0, 2, 1)                      # [O, taps, I]
+        packed[name + ".weight2"] = w16(torch.cat([w4, w4], 2).reshape(w.shape[0], -1))
 
     def dense(name, bias=True):
         w = take(name + ".weight")
@@ -97,7 +105,7 @@ def pack_state_dict(cfg: UNetConfig, sd, device):
         affine(p + ".norm2")
         conv(p + ".conv2")
         if ci != co:
-            conv(p + ".conv_shortcut")
+            conv(p + ".conv_shortcut", split=True)
         tw.append(take(p + ".time_emb_proj.weight"))
         tb.append(take(p + ".time_emb_proj.bias"))
     packed["time_emb_proj_cat.weight"] = w16(torch.cat([t.to(device) for t in tw], 0))
@@ -111,6 +119,7 @@ def pack_state_dict(cfg: UNetConfig, sd, device):
         affine(p + ".norm")
         dense(p + ".proj_in")
         dense(p + ".proj_out")
+        split2(p + ".proj_out", sd[p + ".proj_out.weight"])
         perm = geglu_perm(4 * c).to(device)
         for k in range(depth):
             b = f"{p}.transformer_blocks.{k}"
@@ -146,7 +155,7 @@ def pack_state_dict(cfg: UNetConfig, sd, device):
     packed["attn2_k_cat.weight"] = w16(torch.cat([t.to(device) for t in kcat], 0))
     packed["attn2_v_cat.weight"] = w16(torch.cat([t.to(device) for t in vcat], 0))
     for i in range(cfg.num_levels - 1):
-        conv(f"down_blocks.{i}.downsamplers.0.conv")
+        conv(f"down_blocks.{i}.downsamplers.0.conv", split=True)
         conv(f"up_blocks.{i}.upsamplers.0.conv")
     affine("conv_norm_out")
     conv("conv_out")
@@ -238,9 +247,12 @@ class UNet2DConditionModel:
 
     def set_option(self, name, value):
         """Per-handle execution option (icd_unet_set_option): 'xattn_fusion' 0 / 1 / 2, 'ln_inline_stats' 0 / 1, 'xattn_tile' 0 / 2 / 4,
-        'residual' 0 fp16 stream / 1 fp32 twin / 2 error carry (default; 'residual_f32' is the round-3 name of the same option).  A/B
+        'residual' 0 fp16 stream / 1 fp32 twin / 2 error carry / 3 carry + split consumers (default; 'residual_f32' is the round-3
+        name of the same option).  A/B
         tuning and tests; nothing is process-wide."""
         _lib.check(self._lib.icd_unet_set_option(self._h, self.OPTIONS[name], int(value)), f"icd_unet_set_option({name})")
+        name = {"residual_f32": "residual"}.get(name, name)      # aliases are recorded under one key: a replica replays the final state
+        self._options.pop(name, None)
         self._options[name] = int(value)
         if name in ("residual", "residual_f32"):
             self._ws_key = None                  # the arena holds the twins / carries of the residual stream: size it again

@@ -440,6 +440,111 @@ def test_groupnorm(B, HW, C0, C1, silu, eps):
     assert rel_l2(out, ref.reshape(B * HW, Cc)) < TOL
 
 
+@pytest.mark.parametrize("B,HW,C0,C1,silu", [(2, 4096, 320, 0, True), (2, 1024, 640, 320, True), (3, 64, 1280, 1280, True),
+                                             (1, 4096, 320, 320, False), (2, 100, 32, 0, True)])
+def test_groupnorm_reads_the_error_carry_and_writes_the_split_operand(B, HW, C0, C1, silu):
+    """icd_groupnorm_carry (UNet option residual = 3, the default): the inputs are tensors of the residual stream, fp16 + one bf8 byte of
+    what the rounding lost.  The normalisation reads both (streaming kernels and the one-launch small-map kernel), and the optional
+    aux output is the second source of the split shortcut conv: [x2 | lo | lo2] with lo = fp16(2^-14 carry), bit-exact."""
+    ops = _ops()
+    g32 = torch.Generator().manual_seed(30)
+    v0 = torch.randn(B * HW, C0, generator=g32) * 1.5 + 0.3
+    v1 = torch.randn(B * HW, C1, generator=g32) if C1 else None
+    h0, c0 = ops.carry_encode(v0)
+    h1, c1 = ops.carry_encode(v1) if C1 else (None, None)
+    Cc = C0 + C1
+    g = 1 + 0.1 * torch.randn(Cc, generator=torch.Generator().manual_seed(22))
+    b = 0.1 * torch.randn(Cc, generator=torch.Generator().manual_seed(23))
+    cu = lambda t: None if t is None else t.cuda()
+    out, aux = ops.groupnorm_carry(cu(h0), B, HW, g.cuda(), b.cuda(), 1e-5, silu, carry=cu(c0), x2=cu(h1), carry2=cu(c1), with_aux=True)
+    plain = ops.groupnorm(cu(h0), B, HW, g.cuda(), b.cuda(), 1e-5, silu, x2=cu(h1))
+
+    def gn(t0, t1):
+        xin = t0 if t1 is None else torch.cat([t0, t1], -1)
+        r = F.group_norm(xin.double().reshape(B, HW, Cc).permute(0, 2, 1), 32, g.double(), b.double(), 1e-5).permute(0, 2, 1)
+        return (F.silu(r) if silu else r).reshape(B * HW, Cc)
+    full0, full1 = ops.carry_decode(h0, c0), (ops.carry_decode(h1, c1) if C1 else None)
+    ref = gn(full0, full1)                                 # of the values the stream holds (fp16 + carry)
+    # the fp16 output rounding (~1.7e-4) is common to both; what the carry removes is the input rounding, seen before that rounding:
+    e_c, e_p = rel_l2(out, ref), rel_l2(plain, ref)
+    print(f"[groupnorm carry B={B} HW={HW} C={C0}+{C1}] with carry {e_c:.3e}, fp16 inputs only {e_p:.3e}")
+    assert e_c < 2.2e-4 and e_c < 0.85 * e_p
+    assert rel_l2(out, ref.half()) < 0.25 * rel_l2(plain, ref.half())          # close to the correctly rounded result of the full value
+    # aux: bit-exact layout [x2 | lo0 | lo1]
+    lo0 = (c0.view(torch.float8_e5m2).float() / 16384.0).half()
+    if C1:
+        lo1 = (c1.view(torch.float8_e5m2).float() / 16384.0).half()
+        assert torch.equal(aux.cpu(), torch.cat([h1, lo0, lo1], 1))
+    else:
+        assert torch.equal(aux.cpu(), lo0)
+    # a source without a carry beside one with (skip tensors of other modes): same as a zero carry
+    if C1:
+        o2 = ops.groupnorm_carry(cu(h0), B, HW, g.cuda(), b.cuda(), 1e-5, silu, carry=cu(c0), x2=cu(h1), carry2=None)
+        assert rel_l2(o2, gn(full0, h1.float())) < 2.2e-4
+    assert torch.equal(ops.carry_expand(cu(c0)).cpu(), lo0)
+
+
+def test_split_operand_gemm_sees_the_full_value_of_the_stream():
+    """The split consumers of residual mode 3: a two-source 1x1 conv over [x | lo] against [W | W] (shortcut conv with a concatenated
+    skip: [x0 | x1 | lo0 | lo1] through the GroupNorm's aux output), and a 3x3 stride-2 conv over per-tap [x | lo] (the downsampler).
+    Against fp64 on the values the stream holds, the split result must be much closer than the fp16-operand one - also for
+    activations small enough that lo is subnormal in fp16."""
+    ops = _ops()
+    B, H, W, C0, C1, Co = 2, 32, 32, 320, 320, 320
+    M = B * H * W
+    gg = torch.Generator().manual_seed(40)
+    for scale in (1.5, 0.02):
+        v0, v1 = torch.randn(M, C0, generator=gg) * scale, torch.randn(M, C1, generator=gg) * scale
+        h0, c0 = ops.carry_encode(v0)
+        h1, c1 = ops.carry_encode(v1)
+        w = (torch.randn(Co, C0 + C1, generator=gg) * (C0 + C1) ** -0.5).half()
+        g, b = torch.ones(C0 + C1), torch.zeros(C0 + C1)
+        _, aux = ops.groupnorm_carry(h0.cuda(), B, H * W, g.cuda(), b.cuda(), 1e-5, True, carry=c0.cuda(), x2=h1.cuda(), carry2=c1.cuda(),
+                                     with_aux=True)
+        w2 = torch.cat([w, w], 1).contiguous()
+        out = ops.conv3x3(h0.cuda(), B, H, W, w2.cuda(), None, x2=aux, ksize=1, out_f32=True)
+        plain = ops.conv3x3(h0.cuda(), B, H, W, w.cuda(), None, x2=h1.cuda(), ksize=1, out_f32=True)
+        full = torch.cat([ops.carry_decode(h0, c0), ops.carry_decode(h1, c1)], 1).double()
+        ref = full @ w.double().t()
+        e_s, e_p = rel_l2(out, ref), rel_l2(plain, ref)
+        print(f"[split shortcut, |x| ~ {scale}] split {e_s:.3e}, fp16 operand {e_p:.3e}")
+        assert e_p > 1e-4 and e_s < 0.2 * e_p
+    # downsampler: 3x3 stride 2 over [x | lo] per tap
+    C = 320
+    v = torch.randn(M, C, generator=gg)
+    h, c = ops.carry_encode(v)
+    wt = (torch.randn(C, 9, C, generator=gg) * (9 * C) ** -0.5).half()                         # [O, tap, I]
+    w1 = wt.reshape(C, 9 * C).contiguous()
+    w2 = torch.cat([wt, wt], 2).reshape(C, 18 * C).contiguous()
+    lo = ops.carry_expand(c.cuda())
+    out = ops.conv3x3(h.cuda(), B, H, W, w2.cuda(), None, x2=lo, stride=2, out_f32=True)
+    plain = ops.conv3x3(h.cuda(), B, H, W, w1.cuda(), None, stride=2, out_f32=True)
+    full = ops.carry_decode(h, c).reshape(B, H, W, C).permute(0, 3, 1, 2).double()
+    ref = to_nhwc(F.conv2d(full, wt.reshape(C, 3, 3, C).permute(0, 3, 1, 2).double(), stride=2, padding=1))
+    e_s, e_p = rel_l2(out, ref), rel_l2(plain, ref)
+    print(f"[split downsampler] split {e_s:.3e}, fp16 operand {e_p:.3e}")
+    assert e_p > 1e-4 and e_s < 0.2 * e_p
+
+
+def test_error_carry_saturates_instead_of_overflowing():
+    """|v| >= 2^13: half an ulp of the fp16 value times the carry's 2^14 scale leaves the e5m2 range; the carry is clamped to the largest
+    finite value (57344 = 3.5 in value units) instead of becoming inf / NaN, so the stream stays finite up to the fp16 maximum and is
+    never worse than the plain fp16 stream."""
+    ops = _ops()
+    M, N, K = 256, 256, 64
+    gg = torch.Generator().manual_seed(50)
+    a, w = r16(M, K, seed=51), (r16(N, K, seed=52).float() * K ** -0.5).half()
+    mag = torch.empty(M, N).uniform_(8192.0, 60000.0, generator=gg) * (torch.randint(0, 2, (M, N), generator=gg) * 2 - 1)
+    hi, lo = ops.carry_encode(mag)
+    assert torch.isfinite(ops.carry_decode(hi, lo)).all()
+    o_lo = torch.empty(M, N, device="cuda", dtype=torch.uint8)
+    out = ops.gemm(a.cuda(), w.cuda(), resid=hi.cuda(), resid_carry=lo.cuda(), out_carry=o_lo)
+    got = ops.carry_decode(out, o_lo).cpu()
+    ref = ops.carry_decode(hi, lo).double() + a.double() @ w.double().t()
+    assert torch.isfinite(got).all()
+    assert rel_l2(got, ref) <= rel_l2(out, ref) * 1.0001
+
+
 @pytest.mark.parametrize("rows,C", [(1000, 320), (77, 1280), (513, 640), (5, 32)])
 def test_layernorm(rows, C):
     ops = _ops()

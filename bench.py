@@ -72,9 +72,14 @@ def parse():
                          "InFlight): 1 = the sequential loop of rounds 1-3.  Every UNet call still runs the configuration's batch")
     ap.add_argument("--in-flight-edit", type=int, default=3,
                     help="batches in flight of the SD1.5 edit leg (configs[2]: 8 images per batch, the reference's shipped batch_per_gpu)")
-    ap.add_argument("--residual", type=int, default=2, choices=[0, 1, 2],
-                    help="UNet option residual (precision of the residual stream): 2 (default) = fp16 + bf8 error carry, the mode that "
-                         "meets the 1e-3 parity bar; 0 = plain fp16 stream (rounds 1-3); 1 = fp32 twin (round 3's accurate mode)")
+    ap.add_argument("--precision", default="auto", choices=["auto", "fast", "split", "accurate"],
+                    help="precision policy of the native UNet (unet.py): auto (default, what a user of the library gets) = the error carry "
+                         "for plain generation (one evaluation 0.70-0.85e-3 from fp32; its reverse loops contract that) and the accurate "
+                         "level - GroupNorm reads the carry, shortcut / proj_out / sampler convs take hi + lo, 0.40-0.44e-3 - for "
+                         "inversion loops, dynamic-guidance passes and passes with a controller, i.e. the edit legs")
+    ap.add_argument("--residual", type=int, default=None, choices=[0, 1, 2, 3],
+                    help="override the policy with a fixed UNet option residual: 0 = plain fp16 stream (rounds 1-3); 1 = fp32 twin; 2 = fp16 + bf8 "
+                         "error carry; 3 = carry + split consumers")
     ap.add_argument("--attn-valu-scale", type=int, default=0, choices=[0, 1],
                     help="A/B switch (UNet option attn_valu_scale): 1 = flash attention applies the softmax offset with an FMA per score "
                          "on the VALU, 0 (default) = the MFMA subtracts it")
@@ -427,7 +432,29 @@ def workload_group(wl, n):
     for w in wl._group[1:]:
         for name, value in wl.net._options.items():
             w.net.set_option(name, value)
+        w.net.set_precision(wl.net.precision)
     return wl._group[:n]
+
+
+def set_precision(a, net):
+    """The precision policy (default auto) or, with --residual, a fixed residual mode."""
+    if a.residual is not None:
+        net.set_option("residual", a.residual)
+    else:
+        net.set_precision(a.precision)
+
+
+RESID_NAMES = {0: "fp16", 1: "fp16 + fp32 twin", 2: "fp16 + bf8 error carry", 3: "fp16 + bf8 error carry, split consumers"}
+
+
+def precision_of(a, net):
+    """What the line says about the precision of the leg that has just run (read back from the handle the policy drove)."""
+    applied = getattr(net, "_applied", None)
+    mode = a.residual if a.residual is not None else (applied[0] if applied else None)
+    d = {"policy": "fixed (--residual)" if a.residual is not None else a.precision, "residual_stream": RESID_NAMES.get(mode, str(mode))}
+    if applied and applied[0] == 3:
+        d["split_mask"] = applied[1]
+    return d
 
 
 def run_reverse(a, wl, arch, batch, steps, warmup, device, world, rank, primary):
@@ -435,7 +462,8 @@ def run_reverse(a, wl, arch, batch, steps, warmup, device, world, rank, primary)
     import torch.distributed as dist
     from invertible_cd_amd import dist_utils
     wl.net.set_option("ln_inline_stats", a.ln_inline_stats).set_option("xattn_fusion", a.xattn_fusion)     # per-handle A/B switches
-    wl.net.set_option("attn_valu_scale", a.attn_valu_scale).set_option("residual", a.residual)
+    wl.net.set_option("attn_valu_scale", a.attn_valu_scale)
+    set_precision(a, wl.net)
     step = wl.reverse_step(batch)
     group = workload_group(wl, a.in_flight)              # this workload + its replicas (same weights, own handle / arena / stream)
     flight = InFlight([step] + [w.reverse_step(batch) for w in group[1:]], device)
@@ -504,13 +532,23 @@ def run_reverse(a, wl, arch, batch, steps, warmup, device, world, rank, primary)
     # The price of the parity mode: `value` is measured with the error-carried residual stream (UNet option residual = 2: eps within
     # 1e-3 rel-L2 of the fp32 oracle); the same loop on the plain fp16 stream of rounds 1 - 3 (1.0 - 1.2e-3) is timed beside it.
     fp16_stream = None
+    prec = precision_of(a, wl.net)
+    accurate_level = None
     if a.residual != 0 and not a.no_profile:
         for w in group:
             w.net.set_option("residual", 0)
         n_alt = max(2, steps // 2)
         dt_alt, _, _, _ = time_leg(flight, n_alt, 1, batch, device, world, rank, decode)
+        if a.residual is None and a.precision == "auto":
+            # ... and the same leg at the accurate level (what the edit legs run): the price of 0.40-0.44e-3 instead of 0.70-0.85e-3
+            for w in group:
+                w.net.set_precision("accurate")
+            dt_acc, _, _, _ = time_leg(flight, n_alt, 1, batch, device, world, rank, decode)
+            accurate_level = {"value": round(batch * n_alt * world / dt_acc, 3), "ms_per_step": round(dt_acc / n_alt * 1e3, 3), "steps": n_alt,
+                              "note": "the same leg forced to the accurate precision level (residual = 3, every ICD_SPLIT_* bit) that the policy "
+                                      "selects for inversion / dynamic-guidance / controller passes: eps rel-L2 vs the fp32 oracle 0.40-0.44e-3"}
         for w in group:
-            w.net.set_option("residual", a.residual)
+            set_precision(a, w.net)
         flight.run(len(flight))
         fp16_stream = {"value": round(batch * n_alt * world / dt_alt, 3), "ms_per_step": round(dt_alt / n_alt * 1e3, 3), "steps": n_alt,
                        "note": "the same leg with UNet option residual = 0 (plain fp16 residual stream, the mode rounds 1-3 reported): "
@@ -549,7 +587,7 @@ def run_reverse(a, wl, arch, batch, steps, warmup, device, world, rank, primary)
                                 "iCD-SDXL 4-step reverse, batch=8/GPU, fp16, 128x128 latents (1024x1024), gs=7, timesteps [999,699,499,249]"),
                    "per_gpu_batch": batch, "global_batch": batch * world, "unet_evals_per_step": 4,
                    "dead_uncond_rows_eliminated": arch == "sd15", "lora_fused": True,
-                   "residual_stream": {0: "fp16", 1: "fp16 + fp32 twin", 2: "fp16 + bf8 error carry (the mode that meets 1e-3 parity)"}[a.residual],
+                   "precision": prec,
                    "in_flight_batches": len(flight),
                    "parallelism": f"dp{world}", "collective": f"one all-gather (RCCL) of the {payload} + int64 ids at the end of the timed region"},
         "per_unet_ms": round(dt / steps / 4 * 1e3, 3),             # throughput time of one evaluation (wall / evaluations)
@@ -569,6 +607,8 @@ def run_reverse(a, wl, arch, batch, steps, warmup, device, world, rank, primary)
                                               f"(InFlight: host threads x HIP streams x executor replicas over one set of weights), no events"}
     if fp16_stream is not None:
         out["fp16_stream"] = fp16_stream
+    if accurate_level is not None:
+        out["accurate_level"] = accurate_level
     if ref_batching is not None:
         out["value_reference_cfg_doubled_batching"] = round(ref_batching, 3)
     if image_gather is not None:
@@ -603,6 +643,7 @@ def run_reverse(a, wl, arch, batch, steps, warmup, device, world, rank, primary)
 def run_edit(a, wl, arch, batch, steps, warmup, device, world, rank):
     """BASELINE configs[2] (SD1.5: 4-step inversion + 4-step reverse with p2p.AttentionStore, 8 images / GPU) and configs[4]'s per-GPU
     share (SDXL: 3 + 3 steps, dynamic guidance tau 0.7, 16 images / GPU): edited images / s, no events in the timed region."""
+    set_precision(a, wl.net)
     step = wl.edit_step(batch)
     n_fl = a.in_flight_edit if arch == "sd15" else a.in_flight
     group = workload_group(wl, n_fl)
@@ -625,7 +666,7 @@ def run_edit(a, wl, arch, batch, steps, warmup, device, world, rank):
                                    "128x128 latents, timesteps fwd [19,339,699] rev [999,699,339]"),
                       "per_gpu_batch": batch, "global_batch": batch * world, "unet_evals_per_step": evals, "parallelism": f"dp{world}",
                       "in_flight_batches": len(flight),
-                      "residual_stream": {0: "fp16", 1: "fp16 + fp32 twin", 2: "fp16 + bf8 error carry"}[a.residual]},
+                      "precision": precision_of(a, wl.net)},
            "end_to_end_algorithmic_tflops_per_gpu": round(value / world * algo / 1e12, 1),
            "end_to_end_frac_of_mfma_peak": round(value / world * algo / PEAK_MFMA_F16, 4)}
     if arch == "sd15":

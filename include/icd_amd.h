@@ -374,6 +374,18 @@ int32_t icd_unet_num_attention_layers(const icd_unet* u);
 #define ICD_RESIDUAL_F32   1
 #define ICD_RESIDUAL_CARRY 2
 #define ICD_RESIDUAL_SPLIT 3
+/* ICD_UNET_OPT_SPLIT_MASK: which consumers ICD_RESIDUAL_SPLIT covers (bit mask; default ICD_SPLIT_DEFAULT).  Diagnostic / A-B: the
+ * error budget (profiles/r05_error_budget.txt) switches them one at a time.  Set before sizing the workspace. */
+#define ICD_UNET_OPT_SPLIT_MASK      6
+#define ICD_SPLIT_GN          1    /* every GroupNorm normalises fp16 + carry (skip tensors keep their carry for it) */
+#define ICD_SPLIT_CONV1       2    /* conv1 of a ResnetBlock2D hands its output to GroupNorm 2 with a carry */
+#define ICD_SPLIT_SHORTCUT    4    /* conv_shortcut over [x | lo] (needs ICD_SPLIT_GN: that GroupNorm writes lo) */
+#define ICD_SPLIT_PROJ_OUT    8    /* Transformer2DModel.proj_out over [h | lo] */
+#define ICD_SPLIT_DOWN       16    /* the downsampler conv over [h | lo] */
+#define ICD_SPLIT_SAMPLER_OUT 32   /* down / up sampler outputs carry their rounding error on */
+#define ICD_SPLIT_UP         64    /* the upsampler conv over [h | lo] (2 x its flops: 3.6 % of an SDXL forward, 8.5 % of an SD1.5 one) */
+#define ICD_SPLIT_ALL       127
+#define ICD_SPLIT_DEFAULT    63
 #define ICD_UNET_OPT_XATTN_FUSION    1
 #define ICD_UNET_OPT_LN_INLINE_STATS 2
 #define ICD_UNET_OPT_XATTN_TILE      3

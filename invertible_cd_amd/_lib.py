@@ -21,6 +21,9 @@ ICD_UNET_OPT_XATTN_TILE = 3
 ICD_UNET_OPT_ATTN_VALU_SCALE = 4
 ICD_UNET_OPT_RESIDUAL_MODE = 5
 ICD_UNET_OPT_RESIDUAL_F32 = 5           # round-3 name
+ICD_UNET_OPT_SPLIT_MASK = 6
+ICD_SPLIT_GN, ICD_SPLIT_CONV1, ICD_SPLIT_SHORTCUT, ICD_SPLIT_PROJ_OUT, ICD_SPLIT_DOWN, ICD_SPLIT_SAMPLER_OUT, ICD_SPLIT_UP = 1, 2, 4, 8, 16, 32, 64
+ICD_SPLIT_DEFAULT, ICD_SPLIT_ALL = 63, 127
 ICD_RESIDUAL_FP16, ICD_RESIDUAL_F32, ICD_RESIDUAL_CARRY, ICD_RESIDUAL_SPLIT = 0, 1, 2, 3
 ICD_ATTN_CAUSAL = 1
 ICD_ATTN_Q_PRESCALED = 2

@@ -137,6 +137,8 @@ struct icd_unet {
     //      two-source GEMM over [x | lo] against [W | W] (lo = fp16(2^-14 carry), written by the GroupNorm that reads the same tensor
     //      or by icd_carry_expand): +2 % of the UNet's flops on its cheapest GEMMs.  eps 0.69e-3 -> 0.40e-3 in the simulation.
     int resid_mode = 3;
+    // which consumers mode 3 covers (ICD_UNET_OPT_SPLIT_MASK; the error budget of profiles/r05_error_budget.txt toggles them one at a time)
+    int split_mask = ICD_SPLIT_DEFAULT;
 };
 
 namespace {
@@ -261,7 +263,7 @@ struct Exec {
     void free_aux(Act& a) { release(a.aux); a.aux = nullptr; }
     // split mode: the inputs' error carries are read by the apply pass; aux (optional) = the [x1 | lo0 | lo1] / [lo0] operand of the
     // resnet's split shortcut conv (icd_groupnorm_carry)
-    bool split() const { return u->resid_mode == 3; }
+    bool split(int what = ICD_SPLIT_GN) const { return u->resid_mode == 3 && (u->split_mask & what); }
     void groupnorm(const Act& x0, const Act* x1, int HW, const float* g, const float* b, float eps, int silu, half_t* out,
                    half_t* aux = nullptr, int ld_aux = 0) {
         if (!ok() || dry) return;
@@ -295,12 +297,12 @@ struct Exec {
         const long long M = (long long)B * HW;
         half_t* n1 = alloc<half_t>(M * Cin);
         // split mode, channel-changing resnet: norm1 also writes the second source of the split shortcut conv
-        const bool split_sc = split() && Cin != Cout;
+        const bool split_sc = split(ICD_SPLIT_GN) && split(ICD_SPLIT_SHORTCUT) && Cin != Cout;
         const int ld_sc = x0.C + (x1 ? 2 * x1->C : 0);
         half_t* sc_src = split_sc ? alloc<half_t>(M * ld_sc) : nullptr;
         groupnorm(x0, x1, HW, Wf(p + ".norm1.weight", Cin), Wf(p + ".norm1.bias", Cin), 1e-5f, 1, n1, sc_src, ld_sc);
         half_t* h1 = alloc<half_t>(M * Cout);
-        void* h1c = split() ? alloc_aux(M * Cout) : nullptr;     // conv1's output goes to norm2 with its carry
+        void* h1c = split(ICD_SPLIT_GN) && split(ICD_SPLIT_CONV1) ? alloc_aux(M * Cout) : nullptr;     // conv1's output goes to norm2 with its carry
         Act n1a{n1, Cin};
         conv(n1a, nullptr, Hh, Ww, 3, 1, 0, Wh(p + ".conv1.weight", 9LL * Cin * Cout), Cout, Wf(p + ".conv1.bias", Cout),
              temb_all + temb_off, u->temb_total, nullptr, h1, nullptr, h1c);
@@ -492,7 +494,7 @@ struct Exec {
         release(lnst);
         half_t* out = alloc<half_t>(M * C);
         void* out_aux = alloc_aux(M * C);
-        if (split()) {                               // proj_out over [h | lo] against [W | W] (a two-source 1x1 conv)
+        if (split(ICD_SPLIT_PROJ_OUT)) {             // proj_out over [h | lo] against [W | W] (a two-source 1x1 conv)
             half_t* lo = expand(hx, M * C);
             release(hx);
             Act ha{h, C}, la{lo, C};
@@ -607,7 +609,7 @@ struct Exec {
         }
         // the skip stack keeps the fp16 tensors (their consumers concatenate them as GEMM / GroupNorm operands); the fp32 twin / error
         // carry of a tensor lives only until the one operator that uses it as a residual has run
-        const bool sp = split();
+        const bool sp = u->resid_mode == 3;
         auto skip_of = [&](const Act& a) { Act s{a.p, a.C}; if (sp) s.aux = a.aux; return s; };   // split mode: skips keep their carry
         skips.push_back(skip_of(h));
         int Hh = H0, Ww = W0;
@@ -632,8 +634,8 @@ struct Exec {
                 const std::string dp = "down_blocks." + std::to_string(i) + ".downsamplers.0.conv";
                 Act dn{alloc<half_t>((long long)B * (Hh / 2) * (Ww / 2) * Cout), Cout};
                 // (it is a residual only where the next level keeps the channel count: SD1.5's last level)
-                if (sp || c.block_out_channels[i + 1] == Cout) dn.aux = alloc_aux((long long)B * (Hh / 2) * (Ww / 2) * Cout);
-                if (sp) {                            // the stride-2 conv over [h | lo] against per-tap [W | W]
+                if (split(ICD_SPLIT_SAMPLER_OUT) || c.block_out_channels[i + 1] == Cout) dn.aux = alloc_aux((long long)B * (Hh / 2) * (Ww / 2) * Cout);
+                if (split(ICD_SPLIT_DOWN)) {         // the stride-2 conv over [h | lo] against per-tap [W | W]
                     half_t* lo = expand(h.aux, (long long)B * Hh * Ww * Cout);
                     Act la{lo, Cout};
                     conv(h, &la, Hh, Ww, 3, 2, 0, Wh(dp + ".weight2", 18LL * Cout * Cout), Cout, Wf(dp + ".bias", Cout), nullptr, 0, nullptr, dn.p,
@@ -642,7 +644,7 @@ struct Exec {
                 } else {
                     conv(h, nullptr, Hh, Ww, 3, 2, 0, Wh(dp + ".weight", 9LL * Cout * Cout), Cout, Wf(dp + ".bias", Cout), nullptr, 0, nullptr, dn.p,
                          nullptr, dn.aux);
-                    free_aux(h);
+                    if (!sp) free_aux(h);
                 }
                 Hh /= 2; Ww /= 2;
                 h = dn;
@@ -681,7 +683,14 @@ struct Exec {
             if (i < L - 1) {
                 const std::string upn = "up_blocks." + std::to_string(i) + ".upsamplers.0.conv";
                 Act up{alloc<half_t>((long long)B * (Hh * 2) * (Ww * 2) * Cout), Cout};
-                if (sp) up.aux = alloc_aux((long long)B * (Hh * 2) * (Ww * 2) * Cout);
+                if (split(ICD_SPLIT_SAMPLER_OUT)) up.aux = alloc_aux((long long)B * (Hh * 2) * (Ww * 2) * Cout);
+                if (split(ICD_SPLIT_UP)) {           // the upsampling conv over [h | lo] (twice its flops: off by default)
+                    half_t* lo = expand(h.aux, (long long)B * Hh * Ww * Cout);
+                    Act la{lo, Cout};
+                    conv(h, &la, Hh, Ww, 3, 1, 1, Wh(upn + ".weight2", 18LL * Cout * Cout), Cout, Wf(upn + ".bias", Cout), nullptr, 0, nullptr, up.p,
+                         nullptr, up.aux);
+                    release(lo);
+                } else
                 conv(h, nullptr, Hh, Ww, 3, 1, 1, Wh(upn + ".weight", 9LL * Cout * Cout), Cout, Wf(upn + ".bias", Cout), nullptr, 0, nullptr, up.p,
                      nullptr, up.aux);
                 free_act(h);
@@ -741,6 +750,9 @@ extern "C" int icd_unet_set_option(icd_unet* u, int32_t option, int32_t value) {
     case ICD_UNET_OPT_RESIDUAL_MODE:
         ICD_CHECK_ARG(value >= 0 && value <= 3, "icd_unet_set_option: ICD_UNET_OPT_RESIDUAL_MODE takes 0 .. 3 (got %d)", value);
         u->resid_mode = value; return ICD_OK;
+    case ICD_UNET_OPT_SPLIT_MASK:
+        ICD_CHECK_ARG(value >= 0 && value <= ICD_SPLIT_ALL, "icd_unet_set_option: ICD_UNET_OPT_SPLIT_MASK takes a mask of ICD_SPLIT_* bits (got %d)", value);
+        u->split_mask = value; return ICD_OK;
     case ICD_UNET_OPT_LN_INLINE_STATS:
         ICD_CHECK_ARG(value == 0 || value == 1, "icd_unet_set_option: ICD_UNET_OPT_LN_INLINE_STATS takes 0 or 1 (got %d)", value);
         u->ln_inline = value != 0; return ICD_OK;

@@ -120,6 +120,22 @@ def guided_step(noise_prediction_text, noise_pred_uncond, t, guidance_scale, dyn
     return noise_pred_uncond + guidance_scale * (noise_prediction_text - noise_pred_uncond)
 
 
+class _editing:
+    """`with unet.editing():` when `on` and the model's UNet is the native one (anything else: no-op)."""
+
+    def __init__(self, model, on):
+        ctx = getattr(getattr(model, "unet", None), "editing", None)
+        self._ctx = ctx() if (on and ctx is not None) else None
+
+    def __enter__(self):
+        if self._ctx is not None:
+            self._ctx.__enter__()
+
+    def __exit__(self, *exc):
+        if self._ctx is not None:
+            self._ctx.__exit__(*exc)
+
+
 # ----------------------------------------------------------------------------------------------------------- Generator
 class Generator:
     """Few-step consistency sampler / inverter (utils/generation.py:181-521)."""
@@ -287,16 +303,17 @@ class Generator:
         all_latent = [latent]
         latent = latent.clone().detach()
         ts = self.model.scheduler.timesteps
-        for i in range(n_steps):
-            if uncond_embeddings is not None:
-                self.init_prompt(self.prompt, uncond_embeddings[i])
-            t = ts[len(ts) - i - 1] if is_forward else ts[i]
-            noise_pred = self.get_noise_pred(model=self.model, latent=latent, t=t, context=None, guidance_scale=guidance_scale,
-                                             dynamic_guidance=dynamic_guidance, w_embed_dim=w_embed_dim, tau1=tau1, tau2=tau2)
-            latent = self.next_step(noise_pred, t, latent) if is_forward else self.prev_step(noise_pred, t, latent)
-            if controller is not None:
-                latent = controller.step_callback(latent)
-            all_latent.append(latent)
+        with _editing(self.model, is_forward or dynamic_guidance):
+            for i in range(n_steps):
+                if uncond_embeddings is not None:
+                    self.init_prompt(self.prompt, uncond_embeddings[i])
+                t = ts[len(ts) - i - 1] if is_forward else ts[i]
+                noise_pred = self.get_noise_pred(model=self.model, latent=latent, t=t, context=None, guidance_scale=guidance_scale,
+                                                 dynamic_guidance=dynamic_guidance, w_embed_dim=w_embed_dim, tau1=tau1, tau2=tau2)
+                latent = self.next_step(noise_pred, t, latent) if is_forward else self.prev_step(noise_pred, t, latent)
+                if controller is not None:
+                    latent = controller.step_callback(latent)
+                all_latent.append(latent)
         return all_latent
 
     @torch.no_grad()
@@ -338,14 +355,17 @@ class Generator:
         all_latent = [latent]
         latent = latent.clone().detach()
         alpha_schedule, sigma_schedule = self._schedules()
-        for t, s in zip(self.reverse_timesteps, self.reverse_boundary_timesteps):
-            noise_pred = self.get_noise_pred(model=self.reverse_cons_model, latent=latent, t=t, context=None, tau1=tau1,
-                                             tau2=tau2, w_embed_dim=w_embed_dim, guidance_scale=guidance_scale,
-                                             dynamic_guidance=dynamic_guidance)
-            latent = self._boundary_step(noise_pred, t, s, latent, alpha_schedule, sigma_schedule)
-            if controller is not None:
-                latent = controller.step_callback(latent)
-            all_latent.append(latent)
+        # dynamic guidance is the reference's editing schedule (utils/generation.py:74-82): such passes run at the accurate precision
+        # level of the native UNet, like the inversion loop and every pass with a controller attached (unet.py: precision policy)
+        with _editing(self.reverse_cons_model, dynamic_guidance):
+            for t, s in zip(self.reverse_timesteps, self.reverse_boundary_timesteps):
+                noise_pred = self.get_noise_pred(model=self.reverse_cons_model, latent=latent, t=t, context=None, tau1=tau1,
+                                                 tau2=tau2, w_embed_dim=w_embed_dim, guidance_scale=guidance_scale,
+                                                 dynamic_guidance=dynamic_guidance)
+                latent = self._boundary_step(noise_pred, t, s, latent, alpha_schedule, sigma_schedule)
+                if controller is not None:
+                    latent = controller.step_callback(latent)
+                all_latent.append(latent)
         return all_latent
 
     @torch.no_grad()
@@ -356,10 +376,11 @@ class Generator:
         noise = torch.randn(latent.shape, generator=torch.Generator().manual_seed(seed)).to(latent.device)
         latent = self.noise_scheduler.add_noise(latent, noise, torch.tensor([self.start_timestep]))
         image_rec = self.latent2image(latent)
-        for t, s in zip(self.forward_timesteps, self.forward_boundary_timesteps):
-            noise_pred = self.get_noise_pred(model=self.forward_cons_model, latent=latent, t=t, context=None,
-                                             guidance_scale=guidance_scale, w_embed_dim=w_embed_dim, dynamic_guidance=False)
-            latent = self._boundary_step(noise_pred, t, s, latent, alpha_schedule, sigma_schedule)
+        with _editing(self.forward_cons_model, True):    # forward steps amplify the per-evaluation error: accurate precision level
+            for t, s in zip(self.forward_timesteps, self.forward_boundary_timesteps):
+                noise_pred = self.get_noise_pred(model=self.forward_cons_model, latent=latent, t=t, context=None,
+                                                 guidance_scale=guidance_scale, w_embed_dim=w_embed_dim, dynamic_guidance=False)
+                latent = self._boundary_step(noise_pred, t, s, latent, alpha_schedule, sigma_schedule)
         return image_rec, [latent]
 
 

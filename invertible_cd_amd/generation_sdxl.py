@@ -175,6 +175,22 @@ def _w_embedding(values, device, dtype):
                    .to(device=device, dtype=dtype))
 
 
+class _editing:
+    """`with unet.editing():` when `on` and the pipeline's UNet is the native one (anything else: no-op)."""
+
+    def __init__(self, pipe, on):
+        ctx = getattr(getattr(pipe, "unet", None), "editing", None)
+        self._ctx = ctx() if (on and ctx is not None) else None
+
+    def __enter__(self):
+        if self._ctx is not None:
+            self._ctx.__enter__()
+
+    def __exit__(self, *exc):
+        if self._ctx is not None:
+            self._ctx.__exit__(*exc)
+
+
 def _boundary_step(noise_pred, t, s, latents, prediction_type, alpha_schedule, sigma_schedule, out_dtype):
     B = len(latents)
     if latents.is_cuda and prediction_type == "epsilon":
@@ -222,10 +238,11 @@ def inverse_sample_deterministic(pipe, images, prompt, generator=None, num_scale
     latents = start_latents.clone()
     w_embedding = None if guidance_scale is None else _w_embedding([guidance_scale] * batch_size, latents.device, latents.dtype)
     ptype = pipe.scheduler.config.prediction_type
-    for t, s in zip(timesteps.cpu(), boundary_timesteps.cpu()):
-        noise_pred = pipe.unet(latents.to(prompt_embeds.dtype), t, encoder_hidden_states=prompt_embeds, return_dict=False,
-                               timestep_cond=w_embedding, added_cond_kwargs=encoded_text)[0]
-        latents = _boundary_step(noise_pred, t, s, latents, ptype, alpha_schedule, sigma_schedule, prompt_embeds.dtype)
+    with _editing(pipe, True):                       # forward steps amplify the per-evaluation error: accurate precision level (unet.py)
+        for t, s in zip(timesteps.cpu(), boundary_timesteps.cpu()):
+            noise_pred = pipe.unet(latents.to(prompt_embeds.dtype), t, encoder_hidden_states=prompt_embeds, return_dict=False,
+                                   timestep_cond=w_embedding, added_cond_kwargs=encoded_text)[0]
+            latents = _boundary_step(noise_pred, t, s, latents, ptype, alpha_schedule, sigma_schedule, prompt_embeds.dtype)
     return (latents, start_latents) if return_start_latent else latents
 
 
@@ -271,19 +288,24 @@ def sample_deterministic(pipe, prompt, latents=None, generator=None, num_scales=
         latents = latents.to(prompt_embeds.dtype)
     w_embedding = None if guidance_scale is None else _w_embedding([guidance_scale] * batch_size, latents.device, latents.dtype)
     ptype = pipe.scheduler.config.prediction_type
-    for t, s in zip(timesteps.cpu(), boundary_timesteps.cpu()):
-        if use_dynamic_guidance:
-            t_item = t if isinstance(t, int) else t.item()
-            if t_item > tau1 * 1000 and amplify_prompt is not None:
-                prompt_embeds = amplify_prompt_embeds
-            else:
-                prompt_embeds = prompt_embeds_init
-            # same fp32 arithmetic as the reference's `gamma * (ones(B) * guidance_scale)`, one scalar for the batch
-            gs_t = float(linear_schedule_old(t_item, torch.ones(1) * guidance_scale, tau1=tau1, tau2=tau2)[0])
-            w_embedding = _w_embedding([gs_t] * len(latents), latents.device, latents.dtype)
-        noise_pred = pipe.unet(latents, t, encoder_hidden_states=prompt_embeds, cross_attention_kwargs=None, return_dict=False,
-                               timestep_cond=w_embedding, added_cond_kwargs=encoded_text)[0]
-        latents = _boundary_step(noise_pred, t, s, latents, ptype, alpha_schedule, sigma_schedule, pipe.unet.dtype)
+    edit_ctx = _editing(pipe, use_dynamic_guidance)  # dynamic guidance = the reference's editing schedule: accurate precision level
+    edit_ctx.__enter__()
+    try:
+        for t, s in zip(timesteps.cpu(), boundary_timesteps.cpu()):
+            if use_dynamic_guidance:
+                t_item = t if isinstance(t, int) else t.item()
+                if t_item > tau1 * 1000 and amplify_prompt is not None:
+                    prompt_embeds = amplify_prompt_embeds
+                else:
+                    prompt_embeds = prompt_embeds_init
+                # same fp32 arithmetic as the reference's `gamma * (ones(B) * guidance_scale)`, one scalar for the batch
+                gs_t = float(linear_schedule_old(t_item, torch.ones(1) * guidance_scale, tau1=tau1, tau2=tau2)[0])
+                w_embedding = _w_embedding([gs_t] * len(latents), latents.device, latents.dtype)
+            noise_pred = pipe.unet(latents, t, encoder_hidden_states=prompt_embeds, cross_attention_kwargs=None, return_dict=False,
+                                   timestep_cond=w_embedding, added_cond_kwargs=encoded_text)[0]
+            latents = _boundary_step(noise_pred, t, s, latents, ptype, alpha_schedule, sigma_schedule, pipe.unet.dtype)
+    finally:
+        edit_ctx.__exit__(None, None, None)
 
     vae = getattr(pipe, "vae", None)
     if vae is None:          # VAE decode is outside this path: hand the latents back

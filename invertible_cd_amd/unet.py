@@ -156,7 +156,7 @@ def pack_state_dict(cfg: UNetConfig, sd, device):
     packed["attn2_v_cat.weight"] = w16(torch.cat([t.to(device) for t in vcat], 0))
     for i in range(cfg.num_levels - 1):
         conv(f"down_blocks.{i}.downsamplers.0.conv", split=True)
-        conv(f"up_blocks.{i}.upsamplers.0.conv")
+        conv(f"up_blocks.{i}.upsamplers.0.conv", split=True)
     affine("conv_norm_out")
     conv("conv_out")
     missing = set(cfg.state_dict_shapes()) - consumed
@@ -215,6 +215,8 @@ class UNet2DConditionModel:
         self._ws = None
         self._ws_key = None
         self._ws_mode = 0
+        self._ws_pool = {}         # (B, H, W, n_ctx, residual mode, split mask) -> (arena, probs_mode): the two precision levels keep theirs
+        self._applied = None       # (residual mode, split mask) last sent to the native handle by the precision policy
         # p2p plugin state (set by p2p.register_attention_control / Generator.get_noise_pred)
         self.attn_controller = None
         self.attn_cond_only = False
@@ -224,6 +226,8 @@ class UNet2DConditionModel:
         # every step, so steps 2..n skip the two context projections.  The cached context is kept referenced - its storage
         # cannot be recycled under the cache - and is recognised by (data_ptr, shape, version counter): an in-place update
         # of the tensor bumps the counter and refills the cache.
+        self.precision = getattr(self, "precision", "auto")
+        self._inverting = 0
         self.kv_cache_enabled = True
         self._kv = None            # (ctx tensor, version, cache buffer, stream)
 
@@ -236,14 +240,63 @@ class UNet2DConditionModel:
         for k in ("_lib", "cfg", "device", "dtype", "in_channels", "config", "_packed"):
             setattr(r, k, getattr(self, k))
         r._options = {}
+        r.precision = self.precision
         r._create_handle()
         for name, value in self._options.items():
             r.set_option(name, value)
+        r.precision = self.precision
         return r
 
     OPTIONS = {"xattn_fusion": _lib.ICD_UNET_OPT_XATTN_FUSION, "ln_inline_stats": _lib.ICD_UNET_OPT_LN_INLINE_STATS,
                "xattn_tile": _lib.ICD_UNET_OPT_XATTN_TILE, "attn_valu_scale": _lib.ICD_UNET_OPT_ATTN_VALU_SCALE,
-               "residual": _lib.ICD_UNET_OPT_RESIDUAL_MODE, "residual_f32": _lib.ICD_UNET_OPT_RESIDUAL_MODE}
+               "residual": _lib.ICD_UNET_OPT_RESIDUAL_MODE, "residual_f32": _lib.ICD_UNET_OPT_RESIDUAL_MODE,
+               "split_mask": _lib.ICD_UNET_OPT_SPLIT_MASK}
+
+    # ------------------------------------------------------------------ precision policy
+    # Numerical precision of the residual stream and of its consumers (icd_unet options residual / split_mask):
+    #   "fast"      error carry (mode 2): one evaluation 0.70 - 0.85e-3 from an fp32 evaluation - enough for the REVERSE loops, which
+    #               contract the per-step error (4-step generation: latents 3e-4, every attention-store tensor < 1e-3);
+    #   "accurate"  carry + split consumers incl. the upsampler convs (mode 3, every ICD_SPLIT_* bit): 0.40 - 0.44e-3, +10 % / +5 % time
+    #               (SD1.5 / SDXL) - what the FORWARD (inversion) loops, which amplify the per-step error by ~2.4 x over 3 - 4 steps, and
+    #               the edit passes behind them need to stay inside 1e-3;
+    #   "auto"      (default) accurate inside EDITING pipelines - the evaluations a sampler wraps in `with unet.editing():` (inversion
+    #               loops, reverse passes under dynamic guidance: the reference uses both for editing only) and every evaluation with an
+    #               attention controller attached (edit / store passes) - fast for plain text-to-image generation;
+    #   None        leave the options alone (set_option('residual' | 'split_mask') switches to this).
+    PRECISION = {"fast": (_lib.ICD_RESIDUAL_CARRY, _lib.ICD_SPLIT_DEFAULT), "accurate": (_lib.ICD_RESIDUAL_SPLIT, _lib.ICD_SPLIT_ALL),
+                 "split": (_lib.ICD_RESIDUAL_SPLIT, _lib.ICD_SPLIT_DEFAULT)}
+
+    def set_precision(self, level):
+        if level not in (None, "auto") and level not in self.PRECISION:
+            raise ValueError(f"precision must be one of auto, fast, split, accurate or None (got {level!r})")
+        self.precision = level
+        return self
+
+    def editing(self):
+        """Context manager marking the evaluations inside as part of an editing pipeline (inversion steps, dynamic-guidance reverse
+        passes) for the 'auto' precision policy."""
+        unet = self
+
+        class _Inv:
+            def __enter__(self_):
+                unet._inverting += 1
+
+            def __exit__(self_, *exc):
+                unet._inverting -= 1
+        return _Inv()
+
+    def _apply_precision(self):
+        level = getattr(self, "precision", "auto")
+        if level is None:
+            return
+        if level == "auto":
+            level = "accurate" if (self._inverting > 0 or self.attn_controller is not None) else "fast"
+        want = self.PRECISION[level]
+        if self._applied != want:
+            _lib.check(self._lib.icd_unet_set_option(self._h, _lib.ICD_UNET_OPT_RESIDUAL_MODE, want[0]), "icd_unet_set_option(residual)")
+            _lib.check(self._lib.icd_unet_set_option(self._h, _lib.ICD_UNET_OPT_SPLIT_MASK, want[1]), "icd_unet_set_option(split_mask)")
+            self._applied = want
+            self._ws_key = None
 
     def set_option(self, name, value):
         """Per-handle execution option (icd_unet_set_option): 'xattn_fusion' 0 / 1 / 2, 'ln_inline_stats' 0 / 1, 'xattn_tile' 0 / 2 / 4,
@@ -254,7 +307,10 @@ class UNet2DConditionModel:
         name = {"residual_f32": "residual"}.get(name, name)      # aliases are recorded under one key: a replica replays the final state
         self._options.pop(name, None)
         self._options[name] = int(value)
-        if name in ("residual", "residual_f32"):
+        if name in ("residual", "split_mask"):
+            self.precision = None                # an explicit setting switches the policy off
+            self._applied = None
+            self._ws_pool.clear()
             self._ws_key = None                  # the arena holds the twins / carries of the residual stream: size it again
         return self
 
@@ -283,14 +339,23 @@ class UNet2DConditionModel:
     def _workspace(self, B, H, W, n_ctx, probs_mode):
         """Arena for one forward, sized by the materialisation rule of the attached controller (0 none, 1 the shipped
         controllers' rule, 2 any layer): only grows, so switching controllers does not thrash the allocator."""
-        key = (B, H, W, n_ctx)
+        key = (B, H, W, n_ctx) + (self._applied or (None, None))
         if self._ws_key != key or probs_mode > self._ws_mode:
-            nbytes = self._lib.icd_unet_workspace_bytes_ex(self._h, B, H, W, n_ctx, probs_mode)
-            if nbytes <= 0:
-                raise RuntimeError("icd_unet_workspace_bytes failed")
-            self._ws = None
-            self._ws = torch.empty((nbytes,), dtype=torch.uint8, device=self.device)
-            self._ws_key, self._ws_mode = key, probs_mode
+            hit = self._ws_pool.get(key)
+            if hit is not None and hit[1] >= probs_mode:
+                self._ws, self._ws_mode = hit
+            else:
+                nbytes = self._lib.icd_unet_workspace_bytes_ex(self._h, B, H, W, n_ctx, probs_mode)
+                if nbytes <= 0:
+                    raise RuntimeError("icd_unet_workspace_bytes failed")
+                self._ws = None
+                self._ws_pool.pop(key, None)
+                if len(self._ws_pool) >= 2:          # one arena per precision level of the current shape, not a history of shapes
+                    self._ws_pool.clear()
+                self._ws = torch.empty((nbytes,), dtype=torch.uint8, device=self.device)
+                self._ws_mode = probs_mode
+                self._ws_pool[key] = (self._ws, probs_mode)
+            self._ws_key = key
         return self._ws
 
     def _make_hook(self, errors):
@@ -382,6 +447,7 @@ class UNet2DConditionModel:
             keep += [te, ti]
             io.text_embeds, io.time_ids = te.data_ptr(), ti.data_ptr()
         eps = torch.empty_like(x)
+        self._apply_precision()
         errors = []
         self._live.clear()
         hook, probs_mode = self._make_hook(errors)

@@ -6,14 +6,15 @@ BASELINE configs covered here (reduced widths for the oracle-checked cases, full
   cfg 3  iCD-SD1.5 4-step forward inversion + 4-step reverse edit with p2p controllers (AttentionStore / AttentionReplace)
   cfg 4  iCD-SDXL 4-step reverse
   cfg 5  iCD-SDXL 3-step forward + 3-step reverse with dynamic guidance (tau < 1)
-Tolerances (round 4, residual stream with error carry - the default and the benchmarked mode): the north star's 1e-3 rel-L2 is
-asserted where the arithmetic can meet it - final latents of the reverse loops and EVERY attention-store tensor of a reverse pass,
-reduced width and full width (64x64 latents).  One evaluation is 0.70 - 0.85e-3 from the fp32 oracle (the floor of fp16 MFMA
-operands); the reverse loop contracts that (x0-prediction: 3e-4 after 4 steps), the FORWARD loops amplify it - every
-step adds its own eps error times (sigma_s - alpha_s sigma_t / alpha_t) ~ 0.7 on top of the propagated one - and land at 1.0 - 1.5e-3
-after 3 - 4 steps, the edit (8 evaluations, probabilities rewritten by the controller) at 1.2e-3 / 1.5e-3 on its store.  Those bars are
-stated next to each assert with the measured value; an fp16 diffusers-style pipeline (the oracle graph in fp16 torch) sits at 2 - 2.6e-3
-per evaluation on the same weights.
+Tolerances (round 5): the north star's 1e-3 rel-L2 is asserted on EVERY loop - final latents of the reverse loops, every attention-store
+tensor of a reverse pass (reduced and full width), and since this round also the FORWARD (inversion) loops, the replace edit (latents and
+edited store tensors) and SDXL's forward + dynamic-guidance reverse.  The forward loops amplify the per-evaluation error (every step adds
+its own eps error times (sigma_s - alpha_s sigma_t / alpha_t) ~ 0.7 on top of the propagated one: ~2.4 x after 3 - 4 steps), so they need
+one evaluation at ~0.4e-3: the 'accurate' level of the UNet's precision policy (unet.py; residual mode 3: GroupNorm reads the stream's
+error carry, the shortcut / proj_out / sampler GEMMs take hi + lo; tests/error_budget_sim.py and profiles/r05_error_budget*.txt have the
+budget), which the samplers select for inversion loops, dynamic-guidance passes and every pass with a controller attached.  Plain
+generation runs at the 'fast' level (the error carry of round 4, one evaluation 0.70 - 0.85e-3), whose reverse loops contract the error
+(3e-4 after 4 steps).  For scale: an fp16 diffusers-style pipeline (the oracle graph in fp16 torch) sits at 2 - 2.6e-3 per evaluation.
 """
 import numpy as np
 import pytest
@@ -23,6 +24,7 @@ from conftest import rel_l2
 
 pytestmark = pytest.mark.gpu
 
+STORE_BAR = 1e-3
 REV_T, REV_S = [999, 779, 519, 259], [779, 519, 259, 0]
 FWD_T, FWD_S = [19, 259, 519, 779], [259, 519, 779, 999]
 
@@ -121,7 +123,7 @@ def test_sd15_reverse_with_attention_store(eliminate):
 def test_full_width_sd15_64x64_reverse_store_and_inversion_meet_1e3():
     """SURVEY 8c(3) at full width: the 859.7 M-parameter SD1.5 UNet on 64 x 64 latents (512 x 512 images), B = 2, the benchmarked
     residual mode.  (a) 4-step reverse with an AttentionStore: final latents and EVERY stored tensor (22 per pass at this size: the 32^2,
-    16^2 and 8^2 layers) within 1e-3 of the fp32 oracle loop; (b) the 4-step forward inversion: reported, bar 1.3e-3 (see the header).
+    16^2 and 8^2 layers) within 1e-3 of the fp32 oracle loop; (b) the 4-step forward inversion, within 1e-3 too since round 5 (the accurate level).
     2 x 6.4 TFLOP of CPU oracle."""
     E = _env()
     p2p = E["p2p"]
@@ -156,7 +158,7 @@ def test_full_width_sd15_64x64_reverse_store_and_inversion_meet_1e3():
     ref_inv = _oracle_loop(E, sd, cfg, x0.clone(), ctx, list(zip(FWD_T, FWD_S)), [[0.0, 0.0]] * 4)
     e_inv = rel_l2(inv[0], ref_inv)
     print(f"[sd15 full width 64x64 inversion] rel-L2 = {e_inv:.3e}")
-    assert e_inv < 1.3e-3
+    assert e_inv < 1e-3
 
 
 def test_sd15_inversion_then_replace_edit():
@@ -177,7 +179,7 @@ def test_sd15_inversion_then_replace_edit():
     ref_inv = _oracle_loop(E, sd, cfg, x0.clone(), ctx, list(zip(FWD_T, FWD_S)), [[0.0, 0.0]] * 4)
     e_inv = rel_l2(inv[0], ref_inv)
     print(f"[sd15 inversion] rel-L2 = {e_inv:.3e}")
-    assert e_inv < 1.3e-3                            # measured 1.03e-3 (1.37e-3 on the plain fp16 stream): forward steps amplify, see the header
+    assert e_inv < 1e-3                              # round 5, accurate level: 6.6e-4 (1.03e-3 on the carry alone, 1.37e-3 on the plain fp16 stream)
     # ---- edit: replace controller (cross 0.5 / self 0.5), dynamic guidance tau = 0.8, gs = 19
     p2p.tokenizer = E["synthetic"].SyntheticTokenizer()
     p2p.NUM_DDIM_STEPS = 4
@@ -196,14 +198,18 @@ def test_sd15_inversion_then_replace_edit():
     ref = _oracle_loop(E, sd, cfg, start.clone(), ctx, list(zip(REV_T, REV_S)), ws, controller=ref_ctrl)
     e = rel_l2(outs[-1], ref)
     print(f"[sd15 replace edit] rel-L2 = {e:.3e}")
-    assert e < 1.6e-3                                # measured 1.20e-3 (1.73e-3 before the carry; gs = 19, edited probabilities)
+    assert e < 1e-3                                  # round 5: 7.7e-4 (1.20e-3 on the carry alone; gs = 19, edited probabilities)
     assert ctrl.cur_step == 4
-    worst = 0.0
+    worst, errs = 0.0, []
     for key, refs in ref_ctrl.attention_store.items():
-        for g, r in zip(ctrl.attention_store[key], refs):
-            worst = max(worst, rel_l2(g, r))
-            assert rel_l2(g, r) < 2e-3, key          # worst measured 1.51e-3 (2.10e-3 before the carry)
-    print(f"[sd15 replace edit] worst attention-store tensor rel-L2 = {worst:.3e}")
+        for i, (g, r) in enumerate(zip(ctrl.attention_store[key], refs)):
+            errs.append((rel_l2(g, r), key, i, tuple(r.shape)))
+    errs.sort(reverse=True)
+    worst = errs[0][0]
+    print(f"[sd15 replace edit] worst attention-store tensor rel-L2 = {worst:.3e}; top: " +
+          ", ".join(f"{k}[{i}]{sh} {e:.2e}" for e, k, i, sh in errs[:6]))
+    for e, k, i, sh in errs:
+        assert e < STORE_BAR, (k, i, sh, e)
 
 
 def test_sdxl_reverse_and_dynamic_edit_pipeline():
@@ -242,7 +248,7 @@ def test_sdxl_reverse_and_dynamic_edit_pipeline():
     ref_f = _oracle_loop_xl(E, sd, cfg, x0, ctx, list(zip([19, 339, 699], [339, 699, 999])), [[0.0] * B] * 3, added)
     e5f = rel_l2(fwd, ref_f)
     print(f"[sdxl forward] rel-L2 = {e5f:.3e}")
-    assert e5f < 1.9e-3                              # measured 1.45e-3 (1.98e-3 before the carry): three forward steps amplify
+    assert e5f < 1e-3                                # round 5, accurate level (1.45e-3 on the carry alone): three forward steps amplify
     _, rev = X.sample_deterministic(pipe, ["x"] * B, latents=ref_f.cuda().half(), num_inference_steps=3, guidance_scale=19.0,
                                     is_sdxl=True, timesteps=[339, 699, 999], compute_embeddings_fn=emb, return_latent=True,
                                     use_dynamic_guidance=True, tau1=0.7, tau2=0.7)
@@ -251,7 +257,7 @@ def test_sdxl_reverse_and_dynamic_edit_pipeline():
     ref_r = _oracle_loop_xl(E, sd, cfg, ref_f.half().float(), ctx, list(zip([999, 699, 339], [699, 339, 0])), ws, added)
     e5r = rel_l2(rev, ref_r)
     print(f"[sdxl dynamic reverse] rel-L2 = {e5r:.3e}")
-    assert e5r < 1.7e-3                              # measured 1.31e-3 (1.89e-3 before the carry; gs = 19 from t = 999)
+    assert e5r < 1e-3                                # round 5, accurate level (1.31e-3 on the carry alone; gs = 19 from t = 999)
 
 
 def _oracle_loop_xl(E, sd, cfg, x, ctx, pairs, w_vals, added):

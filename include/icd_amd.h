@@ -138,6 +138,14 @@ typedef struct {
      * elements).  Either may be NULL.  Plain fp16 output only (no GEGLU / transposed / fp32 / batched / fused cross-attention). */
     const void* resid_carry;
     void* out_carry;
+    /* Phase form of Upsample2D (nearest 2x + conv3x3, diffusers): output pixel (2y + py, 2x + px) only sees the 2 x 2 input pixels
+     * (y + py - 1 .. y + py, x + px - 1 .. x + px), so the conv is four 2 x 2 convs on the INPUT grid with tap-summed weights - 16 tap
+     * GEMMs instead of 36, 4/9 of the flops.  One launch per phase: a stride-1 3 x 3 geometry on the input grid (upsample = 0, Hout = Hin)
+     * restricted to the conv_ktaps = 4 taps {t0, t0 + 1, t0 + 3, t0 + 4}, t0 = conv_tap_base = 3 py + px, with K = 4 * Cin and W the
+     * phase's [N, 4 * Cin] tap sums, and the output row of GEMM row m scattered to pixel (2y + py, 2x + px) of the [B, 2H, 2W] output:
+     * out_remap_w = Win (> 0 switches it on: row(m) = 2 m + 2 Win (m / Win) + out_remap_c), out_remap_c = 2 py Win + px... times ldo
+     * elements as usual; out_carry follows the same rows.  conv_ktaps = 0: all ksize^2 taps, no remap (everything above off). */
+    int32_t conv_tap_base, conv_ktaps, out_remap_w, out_remap_c;
 } icd_gemm_desc;
 
 int icd_gemm(const icd_gemm_desc* d, void* stream);
@@ -377,6 +385,10 @@ int32_t icd_unet_num_attention_layers(const icd_unet* u);
 /* ICD_UNET_OPT_SPLIT_MASK: which consumers ICD_RESIDUAL_SPLIT covers (bit mask; default ICD_SPLIT_DEFAULT).  Diagnostic / A-B: the
  * error budget (profiles/r05_error_budget.txt) switches them one at a time.  Set before sizing the workspace. */
 #define ICD_UNET_OPT_SPLIT_MASK      6
+/* ICD_UNET_OPT_UPSAMPLE_PHASES: 1 (default) = Upsample2D's nearest-2x + conv3x3 runs as four 2 x 2 convs on the input grid, one per
+ * output pixel phase, with tap-summed weights `<name>.phase.<2 py + px>` (icd_gemm_desc.conv_ktaps): 4/9 of the flops; 0 = the 3 x 3
+ * conv with the upsampling folded into its loader (rounds 1 - 4). */
+#define ICD_UNET_OPT_UPSAMPLE_PHASES 7
 #define ICD_SPLIT_GN          1    /* every GroupNorm normalises fp16 + carry (skip tensors keep their carry for it) */
 #define ICD_SPLIT_CONV1       2    /* conv1 of a ResnetBlock2D hands its output to GroupNorm 2 with a carry */
 #define ICD_SPLIT_SHORTCUT    4    /* conv_shortcut over [x | lo] (needs ICD_SPLIT_GN: that GroupNorm writes lo) */

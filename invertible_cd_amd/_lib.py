@@ -22,6 +22,7 @@ ICD_UNET_OPT_ATTN_VALU_SCALE = 4
 ICD_UNET_OPT_RESIDUAL_MODE = 5
 ICD_UNET_OPT_RESIDUAL_F32 = 5           # round-3 name
 ICD_UNET_OPT_SPLIT_MASK = 6
+ICD_UNET_OPT_UPSAMPLE_PHASES = 7
 ICD_SPLIT_GN, ICD_SPLIT_CONV1, ICD_SPLIT_SHORTCUT, ICD_SPLIT_PROJ_OUT, ICD_SPLIT_DOWN, ICD_SPLIT_SAMPLER_OUT, ICD_SPLIT_UP = 1, 2, 4, 8, 16, 32, 64
 ICD_SPLIT_DEFAULT, ICD_SPLIT_ALL = 63, 127
 ICD_RESIDUAL_FP16, ICD_RESIDUAL_F32, ICD_RESIDUAL_CARRY, ICD_RESIDUAL_SPLIT = 0, 1, 2, 3
@@ -50,6 +51,7 @@ class GemmDesc(C.Structure):
         ("ln_eps", C.c_float),
         ("tune_group_m", C.c_int32), ("tune_xattn_tile", C.c_int32), ("debug_timeline", C.c_void_p), ("out_f32", C.c_void_p),
         ("resid_carry", C.c_void_p), ("out_carry", C.c_void_p),
+        ("conv_tap_base", C.c_int32), ("conv_ktaps", C.c_int32), ("out_remap_w", C.c_int32), ("out_remap_c", C.c_int32),
     ]
 
 

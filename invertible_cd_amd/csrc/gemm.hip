@@ -209,7 +209,7 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_kernel(GemmK p) {
     // the steady-state loader is one 64-bit add per chunk, no selects.
     const int lrow = l >> 3, pchunk = l & 7;
     const int Cin = p.C0 + p.C1;
-    const int ntaps = p.ksize * p.ksize, pad = (p.flags & ICD_GEMM_PAD_HI) ? 0 : p.ksize >> 1;
+    const int ntaps = (int)(p.tapmap >> 60), pad = (p.flags & ICD_GEMM_PAD_HI) ? 0 : p.ksize >> 1;      // taps iterated (a 2 x 2 subset in the phase form)
     const int Hu = p.Hin << p.upsample, Wu = p.Win << p.upsample;
     const bool ktail = (p.K & 63) != 0;
 
@@ -259,9 +259,10 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_kernel(GemmK p) {
     bool u_recompute = true;
 
     auto conv_src = [&](int j, int tap, int c, bool& ok) -> const half_t* {
-        const int dy = (tap * 11) >> 5, dx = tap - dy * 3;                  // tap / 3, tap % 3 for tap < 9
-        const int yu = a_y[j] * p.stride + (ntaps == 9 ? dy : 0) - pad;
-        const int xu = a_x[j] * p.stride + (ntaps == 9 ? dx : 0) - pad;
+        const int t3 = (int)((p.tapmap >> (4 * min(tap, 8))) & 15u);        // iterated tap -> tap of the 3 x 3 geometry
+        const int dy = (t3 * 11) >> 5, dx = t3 - dy * 3;                    // tap / 3, tap % 3 for tap < 9
+        const int yu = a_y[j] * p.stride + (ntaps != 1 ? dy : 0) - pad;
+        const int xu = a_x[j] * p.stride + (ntaps != 1 ? dx : 0) - pad;
         ok = a_ok[j] && tap < ntaps && (unsigned)yu < (unsigned)Hu && (unsigned)xu < (unsigned)Wu;
         const long long pix = a_pix[j] + (yu >> p.upsample) * p.Win + (xu >> p.upsample);
         return (c < p.C0) ? p.a0 + pix * p.C0 + c : p.a1 + pix * p.C1 + (c - p.C0);
@@ -579,16 +580,17 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_kernel(GemmK p) {
                     *reinterpret_cast<f32x4*>(o32) = (f32x4){v[0], v[1], v[2], v[3]};
                     *reinterpret_cast<f32x4*>(o32 + 4) = (f32x4){v[4], v[5], v[6], v[7]};
                 }
+                const long long orow = out_row(p, m) * p.ldo + n;
                 if (out_f32) {
-                    float* out = reinterpret_cast<float*>(p.out) + o_off + (long long)m * p.ldo + n;
+                    float* out = reinterpret_cast<float*>(p.out) + o_off + orow;
                     *reinterpret_cast<f32x4*>(out) = (f32x4){v[0], v[1], v[2], v[3]};
                     *reinterpret_cast<f32x4*>(out + 4) = (f32x4){v[4], v[5], v[6], v[7]};
                 } else {
                     f16x8 o;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) o[e] = (half_t)v[e];
-                    *reinterpret_cast<f16x8*>(reinterpret_cast<half_t*>(p.out) + o_off + (long long)m * p.ldo + n) = o;
-                    if (p.out_c) *reinterpret_cast<u32x2*>(p.out_c + (long long)m * p.ldo + n) = carry_of8(v, o);
+                    *reinterpret_cast<f16x8*>(reinterpret_cast<half_t*>(p.out) + o_off + orow) = o;
+                    if (p.out_c) *reinterpret_cast<u32x2*>(p.out_c + orow) = carry_of8(v, o);
                 }
             }
         }
@@ -643,16 +645,17 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmK p) {
         *reinterpret_cast<f32x4*>(o32) = (f32x4){v[0], v[1], v[2], v[3]};
         *reinterpret_cast<f32x4*>(o32 + 4) = (f32x4){v[4], v[5], v[6], v[7]};
     }
+    const long long orow = out_row(p, m) * p.ldo + n;
     if (p.flags & ICD_GEMM_OUT_F32) {
-        float* out = reinterpret_cast<float*>(p.out) + (long long)m * p.ldo + n;
+        float* out = reinterpret_cast<float*>(p.out) + orow;
         *reinterpret_cast<f32x4*>(out) = (f32x4){v[0], v[1], v[2], v[3]};
         *reinterpret_cast<f32x4*>(out + 4) = (f32x4){v[4], v[5], v[6], v[7]};
     } else {
         f16x8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = (half_t)v[e];
-        *reinterpret_cast<f16x8*>(reinterpret_cast<half_t*>(p.out) + (long long)m * p.ldo + n) = o;
-        if (p.out_c) *reinterpret_cast<u32x2*>(p.out_c + (long long)m * p.ldo + n) = carry_of8(v, o);
+        *reinterpret_cast<f16x8*>(reinterpret_cast<half_t*>(p.out) + orow) = o;
+        if (p.out_c) *reinterpret_cast<u32x2*>(p.out_c + orow) = carry_of8(v, o);
     }
 }
 
@@ -744,6 +747,28 @@ static int gemm_run(const icd_gemm_desc* d, void* stream, icd_gemm_plan_info* in
     k.rps = d->rows_per_sample > 0 ? d->rows_per_sample : 1;
     k.C0 = d->C0; k.C1 = d->C1; k.Hin = d->Hin; k.Win = d->Win; k.Hout = d->Hout; k.Wout = d->Wout;
     k.ksize = d->ksize; k.stride = d->stride; k.upsample = d->upsample;
+    int ktaps = d->ksize * d->ksize;
+    k.tapmap = 0x876543210ULL | ((unsigned long long)ktaps << 60);
+    k.orm_pack = 1; k.orm_magic = 0;
+    if (d->conv_ktaps || d->out_remap_w) {
+        // phase form of the upsampling conv (icd_amd.h): 4 of the 9 taps on the input grid, output rows scattered to one pixel phase
+        ICD_CHECK_ARG(d->mode == 1 && d->ksize == 3 && d->stride == 1 && d->upsample == 0 && d->conv_ktaps == 4 && !(d->flags & ICD_GEMM_PAD_HI),
+                      "icd_gemm: conv_ktaps = 4 goes with a stride-1 3x3 geometry without upsample");
+        ICD_CHECK_ARG(d->conv_tap_base == 0 || d->conv_tap_base == 1 || d->conv_tap_base == 3 || d->conv_tap_base == 4,
+                      "icd_gemm: conv_tap_base must be 3 py + px, py / px in {0, 1}");
+        ICD_CHECK_ARG(d->out_remap_w == 0 || (d->out_remap_w == d->Wout && !trans && !geglu && !d->resid && !d->out_f32 && d->batch <= 1),
+                      "icd_gemm: out_remap_w must equal Wout (plain fp16 / fp32 output, no residual)");
+        ktaps = 4;
+        { const unsigned long long t0 = (unsigned long long)d->conv_tap_base; k.tapmap = t0 | ((t0 + 1) << 4) | ((t0 + 3) << 8) | ((t0 + 4) << 12) | (4ULL << 60); }
+        if (d->out_remap_w) {
+            const unsigned W = (unsigned)d->out_remap_w;
+            ICD_CHECK_ARG(W >= 2 && W < 8192 && d->out_remap_c >= 0 && d->out_remap_c < 32768, "icd_gemm: out_remap_w must be 2 .. 8191");
+            k.orm_pack = 2u | ((2u * W) << 2) | ((unsigned)d->out_remap_c << 17);
+            k.orm_magic = (unsigned)((0x100000000ULL + W - 1) / W);             // floor(m / W) = umulhi(m, magic) for m * (magic W - 2^32) < 2^32
+            ICD_CHECK_ARG((unsigned long long)d->M * (unsigned long long)((unsigned long long)k.orm_magic * W - 0x100000000ULL) < 0x100000000ULL,
+                          "icd_gemm: out_remap_w: M too large for the row map");
+        }
+    }
     k.zdiv = d->zdiv > 0 ? d->zdiv : 1;
     k.a_bs0 = d->a_bs0; k.a_bs1 = d->a_bs1; k.w_bs0 = d->w_bs0; k.w_bs1 = d->w_bs1; k.o_bs0 = d->o_bs0; k.o_bs1 = d->o_bs1;
     k.alpha = d->alpha; k.flags = d->flags;
@@ -869,7 +894,7 @@ static int gemm_run(const icd_gemm_desc* d, void* stream, icd_gemm_plan_info* in
             k.ksplit = (nk_total + k.kt_per_split - 1) / k.kt_per_split;
             if (d->mode == 1) {
                 ICD_CHECK_ARG(d->ksize == 1 || d->ksize == 3, "icd_gemm: conv ksize must be 1 or 3");
-                ICD_CHECK_ARG(d->K == d->ksize * d->ksize * (d->C0 + d->C1), "icd_gemm: K != taps*Cin");
+                ICD_CHECK_ARG(d->K == ktaps * (d->C0 + d->C1), "icd_gemm: K != taps*Cin");
                 ICD_CHECK_ARG((d->C1 == 0) == (d->a1 == nullptr), "icd_gemm: a1/C1 mismatch");
             } else {
                 k.ksize = 0; k.Hout = 0;
@@ -906,7 +931,7 @@ static int gemm_run(const icd_gemm_desc* d, void* stream, icd_gemm_plan_info* in
         ICD_CHECK_ARG(d->upsample == 0 || d->upsample == 1, "icd_gemm: upsample must be 0 or 1");
         ICD_CHECK_ARG(d->C0 > 0 && d->C0 % 8 == 0 && d->C1 % 8 == 0 && d->C1 >= 0, "icd_gemm: conv channels must be multiples of 8");
         ICD_CHECK_ARG((d->C1 == 0) == (d->a1 == nullptr), "icd_gemm: a1/C1 mismatch");
-        ICD_CHECK_ARG(d->K == d->ksize * d->ksize * (d->C0 + d->C1), "icd_gemm: K != taps*Cin");
+        ICD_CHECK_ARG(d->K == ktaps * (d->C0 + d->C1), "icd_gemm: K != taps*Cin");
         ICD_CHECK_ARG(d->Hin > 0 && d->Win > 0 && d->Hout > 0 && d->Wout > 0 && d->M % (d->Hout * d->Wout) == 0,
                       "icd_gemm: bad conv geometry");
         ICD_CHECK_ARG(batch == 1 && !trans, "icd_gemm: conv mode is not batched / transposed");

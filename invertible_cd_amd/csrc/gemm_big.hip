@@ -224,6 +224,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_big_kernel(GemmK p) {
     const int lrow = l >> 3, pchunk = l & 7;
     const int Cin = p.C0 + p.C1;
     const int ntaps = p.ksize * p.ksize, pad = (p.flags & ICD_GEMM_PAD_HI) ? 0 : p.ksize >> 1;
+    const int ktaps = (int)(p.tapmap >> 60);     // taps iterated: ntaps, or 4 of the 9 (phase form of the upsampling conv: tap u -> tap_base + (u & 1) + 3 (u >> 1))
     const int Hu = p.Hin << p.upsample, Wu = p.Win << p.upsample;
     const int k_begin = kt_begin * BK;
 
@@ -241,7 +242,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_big_kernel(GemmK p) {
     const half_t* w_ptr[NWJ]; int w_inc[NWJ];
     const int cpt = MODE == 1 ? Cin / BK : 1;    // k-tiles per tap
     int u_tap, u_c;
-    if (CONV_CHUNK_MAJOR && MODE == 1) { const int ch = kt_begin / ntaps; u_tap = kt_begin - ch * ntaps; u_c = ch * BK; }
+    if (CONV_CHUNK_MAJOR && MODE == 1) { const int ch = kt_begin / ktaps; u_tap = kt_begin - ch * ktaps; u_c = ch * BK; }
     else { u_tap = MODE == 1 ? kt_begin / cpt : 0; u_c = MODE == 1 ? (kt_begin - u_tap * cpt) * BK : 0; }
     const int w_k0 = (CONV_CHUNK_MAJOR && MODE == 1) ? u_tap * Cin + u_c : k_begin;
 #pragma unroll
@@ -304,7 +305,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_big_kernel(GemmK p) {
     int w_step = BK;
     // offsets of the NEXT k-tile to be issued, computed right after the loads of the current one are in flight
     auto conv_next = [&]() {
-        const int dy = (u_tap * 11) >> 5, dx = u_tap - dy * 3;       // (0, 0) for a 1 x 1 conv
+        const int t3 = (int)((p.tapmap >> (4 * u_tap)) & 15u);       // iterated tap -> tap of the 3 x 3 geometry (wave-uniform: one 64-bit scalar shift)
+        const int dy = (t3 * 11) >> 5, dx = t3 - dy * 3;             // (0, 0) for a 1 x 1 conv
         const bool first = u_c < p.C0;
         if (first != u_first) set_source(first);
         const int Cs = first ? p.C0 : p.C1, cc = first ? u_c : u_c - p.C0;
@@ -316,11 +318,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_big_kernel(GemmK p) {
                 const int doff = (int)((((a_nmsk[j] >> 9) & 1) + dy) >> 1) * p.Win + (int)((((a_nmsk[j] >> 10) & 1) + dx) >> 1);
                 off = a_off[j] + (unsigned)((doff * Cs + cc) * 2);
             }
-            a_voff[j] = off | (__builtin_amdgcn_ubfe(a_nmsk[j], (unsigned)u_tap, 1u) << 31);
+            a_voff[j] = off | (__builtin_amdgcn_ubfe(a_nmsk[j], (unsigned)t3, 1u) << 31);
         }
         if (CONV_CHUNK_MAJOR) {                                      // k-tile -> (chunk, tap)
             w_step = Cin;
-            if (++u_tap == ntaps) { u_tap = 0; u_c += BK; w_step = BK - (ntaps - 1) * Cin; }
+            if (++u_tap == ktaps) { u_tap = 0; u_c += BK; w_step = BK - (ktaps - 1) * Cin; }
         } else {                                                     // k-tile -> (tap, chunk)
             u_c += BK;
             if (u_c == Cin) { u_c = 0; ++u_tap; }

@@ -30,7 +30,19 @@ struct GemmK {
     const unsigned char* resid_c;                // error carry of `resid` (icd_gemm_desc.resid_carry): bf8 e5m2 of what fp16 lost, x 2^14
     unsigned char* out_c;                        // error carry of `out` (icd_gemm_desc.out_carry), or null
     unsigned long long* timeline;                // diagnostics (icd_debug_gemm_timeline): 4 s_memrealtime stamps per block, or null
+    // conv over a 2 x 2 subset of the 3 x 3 taps (icd_gemm_desc.conv_tap_base / conv_ktaps: the phase form of the upsampling conv):
+    // ktaps taps are iterated (4, or ksize^2), iterated tap u is tap tap_base + (u & 1) + 3 (u >> 1) of the 3 x 3 geometry
+    // (few fields on purpose: the conv kernels sit at the scalar-register limit, every kernel argument is one more live SGPR)
+    unsigned long long tapmap;                   // bits 4u..4u+3: index of iterated tap u in the 3 x 3 geometry (identity 0x876543210); bits 60..63: taps iterated
+    // output row of GEMM row m = f * m + s * floor(m / W) + c, floor(m / W) = umulhi(m, orm_magic); orm_pack = f | s << 2 | c << 17 (identity: 1, magic 0)
+    unsigned orm_pack, orm_magic;
 };
+
+// output row of GEMM row m (icd_gemm_desc.out_remap_w: pixel (2y + py, 2x + px) of the upsampled map; identity otherwise)
+__device__ __forceinline__ long long out_row(const GemmK& p, int m) {
+    const unsigned f = p.orm_pack & 3u, s = (p.orm_pack >> 2) & 0x7fffu, c = p.orm_pack >> 17;
+    return (long long)(f * (unsigned)m + s * __umulhi((unsigned)m, p.orm_magic) + c);
+}
 
 // block id -> (m-tile, n-tile).  Block b runs on XCD b % 8 (observed, speed only): every XCD gets a contiguous range of
 // the tile sequence, and inside it tiles are ordered in groups of `gm` m-tiles with the n-tile index outermost, so the

@@ -96,8 +96,9 @@ __device__ __forceinline__ void fast_patch(const GemmK& p, const f32x16& acc0, c
         if (RC) carry_add8(a, rc[pass]);
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = (half_t)a[e];
-        if (okl) *reinterpret_cast<f16x8*>(outp + (long long)m * p.ldo + n) = o;
-        if (OC && okl) *reinterpret_cast<u32x2*>(p.out_c + (long long)m * p.ldo + n) = carry_of8(a, o);
+        const long long orow = out_row(p, m) * p.ldo + n;
+        if (okl) *reinterpret_cast<f16x8*>(outp + orow) = o;
+        if (OC && okl) *reinterpret_cast<u32x2*>(p.out_c + orow) = carry_of8(a, o);
     }
 }
 
@@ -317,8 +318,9 @@ __device__ __forceinline__ void wave_epilogue(const GemmK& p, f32x16 (&acc)[TM][
                         f16x8 o;
 #pragma unroll
                         for (int e = 0; e < 8; ++e) o[e] = (half_t)v[e];
-                        *reinterpret_cast<f16x8*>(reinterpret_cast<half_t*>(p.out) + (long long)m * p.ldo + n) = o;
-                        if constexpr (CARRY) { if (p.out_c) *reinterpret_cast<u32x2*>(p.out_c + (long long)m * p.ldo + n) = carry_of8(v, o); }
+                        const long long orow = out_row(p, m) * p.ldo + n;
+                        *reinterpret_cast<f16x8*>(reinterpret_cast<half_t*>(p.out) + orow) = o;
+                        if constexpr (CARRY) { if (p.out_c) *reinterpret_cast<u32x2*>(p.out_c + orow) = carry_of8(v, o); }
                     }
                 }
             }

@@ -128,7 +128,7 @@ def carry_encode(v):
 
 
 def conv3x3(x, B, H, W, w_packed, bias=None, x2=None, stride=1, upsample=False, resid=None, rowbias=None, ksize=3,
-            debug_flags=0, pad_hi=False, out_f32=False, alpha=1.0, resid_carry=None, out_carry=None):
+            debug_flags=0, pad_hi=False, out_f32=False, alpha=1.0, resid_carry=None, out_carry=None, phase=None, out=None):
     """Implicit-GEMM conv over NHWC x [B*H*W, C0] (optionally cat with x2 [.., C1]); returns [B*Ho*Wo, Cout].
     pad_hi: zero padding on the bottom/right edge only (AutoencoderKL Downsample2D).  out_f32 / an fp32 `resid` / alpha: the
     fp32-fidelity VAE path (fp32 conv outputs and residual stream, power-of-two input scaling undone by alpha)."""
@@ -138,13 +138,18 @@ def conv3x3(x, B, H, W, w_packed, bias=None, x2=None, stride=1, upsample=False, 
     Hu, Wu = (H * 2, W * 2) if upsample else (H, W)
     Ho, Wo = (Hu + stride - 1) // stride, (Wu + stride - 1) // stride
     N = w_packed.shape[0]
-    out = torch.empty((B * Ho * Wo, N), device=x.device, dtype=torch.float32 if out_f32 else torch.float16)
+    if phase is None:
+        out = torch.empty((B * Ho * Wo, N), device=x.device, dtype=torch.float32 if out_f32 else torch.float16)
+    else:       # one pixel phase (2 py + px) of the upsampling conv: writes its quarter of `out` [B * 2H * 2W, N] (icd_gemm_desc.conv_ktaps)
+        assert ksize == 3 and stride == 1 and not upsample and out is not None and out.shape == (B * 4 * H * W, N) and out.is_contiguous()
     d = GemmDesc()
     d.a0, d.a1, d.w, d.out = x.data_ptr(), (x2.data_ptr() if x2 is not None else None), w_packed.data_ptr(), out.data_ptr()
     d.bias = bias.data_ptr() if bias is not None else None
     d.resid = resid.data_ptr() if resid is not None else None
     d.rowbias = rowbias.data_ptr() if rowbias is not None else None
-    d.M, d.N, d.K, d.Nw = B * Ho * Wo, N, ksize * ksize * (C0 + C1), N
+    d.M, d.N, d.K, d.Nw = B * Ho * Wo, N, (4 if phase is not None else ksize * ksize) * (C0 + C1), N
+    if phase is not None:
+        d.conv_tap_base, d.conv_ktaps, d.out_remap_w, d.out_remap_c = 3 * (phase >> 1) + (phase & 1), 4, W, 2 * (phase >> 1) * W + (phase & 1)
     d.lda, d.ldw, d.ldo = 0, w_packed.stride(0), N
     d.ldr = resid.stride(0) if resid is not None else 0
     d.ld_rowbias = rowbias.stride(0) if rowbias is not None else 0

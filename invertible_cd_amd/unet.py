@@ -36,6 +36,23 @@ class UNetOutput:
         return iter((self.sample,))
 
 
+def upsample_phase_weights(w):
+    """[O, I, 3, 3] -> four [O, 4, I] tap-summed weights, phase 2 py + px, taps (dy, dx) in {0, 1}^2 row-major: nearest-2x upsampling
+    followed by conv3x3 (pad 1) equals, at output pixel (2y + py, 2x + px), a 2 x 2 conv over input pixels (y + py - 1 + dy, x + px - 1 + dx)
+    whose weights are the sums of the 3 x 3 taps that land on the same input pixel (ky -> input row y + floor((py + ky - 1) / 2))."""
+    sets = {(0, 0): (0,), (0, 1): (1, 2), (1, 0): (0, 1), (1, 1): (2,)}          # (phase, d) -> 3 x 3 tap indices
+    w = w.float()
+    out = []
+    for py in (0, 1):
+        for px in (0, 1):
+            taps = []
+            for dy in (0, 1):
+                for dx in (0, 1):
+                    taps.append(sum(w[:, :, ky, kx] for ky in sets[(py, dy)] for kx in sets[(px, dx)]))
+            out.append(torch.stack(taps, 1))                                         # [O, 4, I]
+    return out
+
+
 def pack_state_dict(cfg: UNetConfig, sd, device):
     """diffusers-layout state dict -> the packed tensors the native executor binds (fp16 weights, fp32 bias/norm).
 
@@ -157,6 +174,9 @@ def pack_state_dict(cfg: UNetConfig, sd, device):
     for i in range(cfg.num_levels - 1):
         conv(f"down_blocks.{i}.downsamplers.0.conv", split=True)
         conv(f"up_blocks.{i}.upsamplers.0.conv", split=True)
+        for ph, wp in enumerate(upsample_phase_weights(sd[f"up_blocks.{i}.upsamplers.0.conv.weight"].to(device))):
+            packed[f"up_blocks.{i}.upsamplers.0.conv.phase.{ph}"] = w16(wp.reshape(wp.shape[0], -1))
+            packed[f"up_blocks.{i}.upsamplers.0.conv.phase2.{ph}"] = w16(torch.cat([wp, wp], 2).reshape(wp.shape[0], -1))
     affine("conv_norm_out")
     conv("conv_out")
     missing = set(cfg.state_dict_shapes()) - consumed
@@ -250,7 +270,7 @@ class UNet2DConditionModel:
     OPTIONS = {"xattn_fusion": _lib.ICD_UNET_OPT_XATTN_FUSION, "ln_inline_stats": _lib.ICD_UNET_OPT_LN_INLINE_STATS,
                "xattn_tile": _lib.ICD_UNET_OPT_XATTN_TILE, "attn_valu_scale": _lib.ICD_UNET_OPT_ATTN_VALU_SCALE,
                "residual": _lib.ICD_UNET_OPT_RESIDUAL_MODE, "residual_f32": _lib.ICD_UNET_OPT_RESIDUAL_MODE,
-               "split_mask": _lib.ICD_UNET_OPT_SPLIT_MASK}
+               "split_mask": _lib.ICD_UNET_OPT_SPLIT_MASK, "upsample_phases": _lib.ICD_UNET_OPT_UPSAMPLE_PHASES}
 
     # ------------------------------------------------------------------ precision policy
     # Numerical precision of the residual stream and of its consumers (icd_unet options residual / split_mask):

@@ -526,6 +526,30 @@ def test_split_operand_gemm_sees_the_full_value_of_the_stream():
     assert e_p > 1e-4 and e_s < 0.2 * e_p
 
 
+@pytest.mark.parametrize("B,H,W,C,Co", [(2, 16, 16, 1280, 1280), (3, 8, 12, 64, 128), (2, 32, 32, 640, 640), (1, 8, 8, 1280, 1280), (2, 6, 10, 40, 24)])
+def test_upsampling_conv_in_phase_form(B, H, W, C, Co):
+    """Upsample2D (nearest 2x + conv3x3 pad 1) as four 2 x 2 convs on the input grid with tap-summed weights (icd_gemm_desc.conv_ktaps,
+    out_remap_w; unet.upsample_phase_weights): against torch's interpolate + conv2d in fp64 on the fp16 operands, and against the 3 x 3
+    form with the upsampling in its loader.  Covers the big conv tiles, split-K + reduce (small maps), the 128-wide kernels and the
+    general loader (channels not a multiple of 64), and a carried output."""
+    ops = _ops()
+    from invertible_cd_amd.unet import upsample_phase_weights
+    x = r16(B, C, H, W, seed=60)
+    w = r16(Co, C, 3, 3, seed=61, scale=(9 * C) ** -0.5)
+    bias = torch.randn(Co, generator=torch.Generator().manual_seed(62))
+    ref = to_nhwc(F.conv2d(F.interpolate(x.double(), scale_factor=2.0, mode="nearest"), w.double(), bias.double(), padding=1))
+    xn = to_nhwc(x).cuda()
+    out = torch.empty(B * 4 * H * W, Co, device="cuda", dtype=torch.float16)
+    oc = torch.zeros(B * 4 * H * W, Co, device="cuda", dtype=torch.uint8)
+    for ph, wp in enumerate(upsample_phase_weights(w)):
+        ops.conv3x3(xn, B, H, W, wp.reshape(Co, -1).half().contiguous().cuda(), bias.cuda(), phase=ph, out=out, out_carry=oc)
+    old = ops.conv3x3(xn, B, H, W, ops.pack_conv_weight(w).cuda(), bias.cuda(), upsample=True)
+    e_new, e_old = rel_l2(out, ref), rel_l2(old, ref)
+    print(f"[upsample phases B={B} {H}x{W} C={C}->{Co}] phase form {e_new:.3e}, 3x3 form {e_old:.3e}")
+    assert e_new < 3e-4 and e_old < 3e-4                    # (fp16 output rounding 1.7e-4 + the fp16 rounding of the summed taps)
+    assert rel_l2(ops.carry_decode(out, oc), ref) < 0.6 * e_new
+
+
 def test_error_carry_saturates_instead_of_overflowing():
     """|v| >= 2^13: half an ulp of the fp16 value times the carry's 2^14 scale leaves the e5m2 range; the carry is clamped to the largest
     finite value (57344 = 3.5 in value units) instead of becoming inf / NaN, so the stream stays finite up to the fp16 maximum and is

@@ -179,6 +179,10 @@ int icd_groupnorm_carry(const void* x0, int32_t C0, const void* carry0, const vo
 /* lo[i] = fp16(2^-14 * bf8(carry[i])), i < n (n %% 8 == 0): the second K segment of a split-operand GEMM, A = [hi | lo] against
  * W = [W | W], for consumers of a carried tensor that no GroupNorm reads first (Transformer2DModel.proj_out, the downsampler conv). */
 int icd_carry_expand(const void* carry, int64_t n, void* lo, void* stream);
+/* out[r] = [lo (C) | hi (C)] for rows r < rows of a carried tensor hi [rows, C] + carry: the second source of a conv over [x | lo | x] against
+ * per-tap weights [W_hi | W_hi | W_lo] - split activations and split weights (the tap sums of the phase-form upsampling conv are not fp16
+ * numbers; with W_lo = fp16(W - W_hi) the product is that of the exact sums). */
+int icd_carry_expand2(const void* carry, const void* hi, int64_t rows, int32_t C, void* out, void* stream);
 
 /* fp32-fidelity path of the VAE (reference: vae.to(torch.float32), utils/generation_sdxl.py:465-466).  Activations that can
  * exceed the fp16 range (conv outputs, residual stream) are fp32 [rows, C]; GEMM operands are fp16 "split3" tensors

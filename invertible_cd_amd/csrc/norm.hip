@@ -778,6 +778,37 @@ __global__ __launch_bounds__(256) void carry_expand_kernel(const unsigned char* 
     }
 }
 
+// ... and [lo | hi] rows (hi copied): the second source of a conv over [x | lo | x] against per-tap [W_hi | W_hi | W_lo] - split activations
+// AND split weights (the phase form of the upsampling conv sums taps, and the sums are not fp16 numbers)
+__global__ __launch_bounds__(256) void carry_expand2_kernel(const unsigned char* __restrict__ c, const half_t* __restrict__ hi, long long rows,
+                                                            int C8, half_t* __restrict__ out) {
+    const long long n8 = rows * C8;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
+        const long long r = i / C8;
+        const int k = (int)(i - r * C8);
+        const u32x2 w = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(c) + i);
+        const f16x8 h = __builtin_nontemporal_load(reinterpret_cast<const f16x8*>(hi) + i);
+        float cf[8];
+        gn_carry8(cf, w);
+        f16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (half_t)cf[e];
+        f16x8* row = reinterpret_cast<f16x8*>(out) + r * (2 * C8);
+        row[k] = o;
+        row[C8 + k] = h;
+    }
+}
+
+extern "C" int icd_carry_expand2(const void* carry, const void* hi, int64_t rows, int32_t C, void* out, void* stream) {
+    ICD_CHECK_ARG(carry && hi && out && rows > 0 && C > 0 && C % 8 == 0, "icd_carry_expand2: null pointer or C not a multiple of 8");
+    const long long n8 = rows * (C / 8);
+    const int blocks = (int)std::min<long long>((n8 + 255) / 256, 4096);
+    hipLaunchKernelGGL(carry_expand2_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const unsigned char*)carry, (const half_t*)hi,
+                       (long long)rows, C / 8, (half_t*)out);
+    ICD_CHECK_LAUNCH("icd_carry_expand2");
+    return ICD_OK;
+}
+
 extern "C" int icd_carry_expand(const void* carry, int64_t n, void* lo, void* stream) {
     ICD_CHECK_ARG(carry && lo && n > 0 && n % 8 == 0, "icd_carry_expand: null pointer or element count not a multiple of 8");
     const long long n8 = n / 8;

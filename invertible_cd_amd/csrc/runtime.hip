@@ -694,13 +694,21 @@ struct Exec {
                 Act up{alloc<half_t>((long long)B * (Hh * 2) * (Ww * 2) * Cout), Cout};
                 if (split(ICD_SPLIT_SAMPLER_OUT)) up.aux = alloc_aux((long long)B * (Hh * 2) * (Ww * 2) * Cout);
                 const bool sup = split(ICD_SPLIT_UP);
-                half_t* lo = sup ? expand(h.aux, (long long)B * Hh * Ww * Cout) : nullptr;    // the upsampling conv over [h | lo]
-                Act la{lo, Cout};
+                const long long hin = (long long)B * Hh * Ww;
+                half_t* lo = nullptr;                // the upsampling conv over [h | lo]
+                if (sup && u->up_phases) {           // ... in the phase form over [h | lo | h] against [W_hi | W_hi | W_lo] (the tap sums are not fp16 numbers)
+                    lo = alloc<half_t>(hin * 2 * Cout);
+                    if (ok() && !dry) {
+                        ProfScope ps(true, st, ICD_PROF_MISC, 0.0, 7.0 * (double)hin * Cout);
+                        run(icd_carry_expand2(h.aux, h.p, hin, Cout, lo, st));
+                    }
+                } else if (sup) lo = expand(h.aux, hin * Cout);
+                Act la{lo, (sup && u->up_phases) ? 2 * Cout : Cout};
                 if (u->up_phases) {
                     // nearest 2x + conv3x3 as four 2 x 2 convs on the input grid, one per output pixel phase: 16 tap GEMMs instead of 36
                     for (int ph = 0; ph < 4 && ok(); ++ph) {
-                        const std::string wn = upn + (sup ? ".phase2." : ".phase.") + std::to_string(ph);
-                        conv(h, sup ? &la : nullptr, Hh, Ww, 3, 1, 0, Wh(wn, (sup ? 8LL : 4LL) * Cout * Cout), Cout, Wf(upn + ".bias", Cout),
+                        const std::string wn = upn + (sup ? ".phase3." : ".phase.") + std::to_string(ph);
+                        conv(h, sup ? &la : nullptr, Hh, Ww, 3, 1, 0, Wh(wn, (sup ? 12LL : 4LL) * Cout * Cout), Cout, Wf(upn + ".bias", Cout),
                              nullptr, 0, nullptr, up.p, nullptr, up.aux, false, ph);
                     }
                 } else {

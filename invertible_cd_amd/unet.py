@@ -176,7 +176,9 @@ def pack_state_dict(cfg: UNetConfig, sd, device):
         conv(f"up_blocks.{i}.upsamplers.0.conv", split=True)
         for ph, wp in enumerate(upsample_phase_weights(sd[f"up_blocks.{i}.upsamplers.0.conv.weight"].to(device))):
             packed[f"up_blocks.{i}.upsamplers.0.conv.phase.{ph}"] = w16(wp.reshape(wp.shape[0], -1))
-            packed[f"up_blocks.{i}.upsamplers.0.conv.phase2.{ph}"] = w16(torch.cat([wp, wp], 2).reshape(wp.shape[0], -1))
+            hi = wp.half().float()                                                   # the accurate level: [W_hi | W_hi | W_lo] per tap against
+            lo = wp - hi                                                             # [h | lo | h] - the products of the exact tap sums
+            packed[f"up_blocks.{i}.upsamplers.0.conv.phase3.{ph}"] = w16(torch.cat([hi, hi, lo], 2).reshape(wp.shape[0], -1))
     affine("conv_norm_out")
     conv("conv_out")
     missing = set(cfg.state_dict_shapes()) - consumed

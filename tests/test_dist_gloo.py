@@ -107,6 +107,55 @@ def test_bench_timed_leg_world2_takes_the_max_over_ranks_and_gathers_every_sampl
     assert [r[:2] for r in res] == [(0, True), (1, True)] and res[0][2] == res[1][2]
 
 
+def _bench_inflight_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world))
+    import sys
+    import threading
+    import time
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from invertible_cd_amd import dist_utils
+    dist_utils.init(backend="gloo", timeout_s=60)
+    lock, calls, threads = threading.Lock(), [], set()
+
+    def make(tag):                                # one "executor replica" per step callable: 2 samples per pass, rank 1 is slower
+        def step():
+            with lock:
+                calls.append(tag)
+                threads.add(threading.get_ident())
+            time.sleep(0.02 * (rank + 1))
+            return torch.full((2, 4, 2, 2), float(rank))
+        return step
+    flight = bench.InFlight([make("a"), make("b")], "cpu")
+    dt, per_rank, prof, last = bench.time_leg(flight, steps=6, warmup=2, batch=2, device="cpu", world=world, rank=rank)
+    # 2 x 2 warm-up (W per batch in flight) + 6 timed passes per RANK, drawn dynamically by the two host threads of this rank (both must have worked); the gather
+    # inside time_leg has asserted batch * K * world samples with ids in global order; two passes overlap, so 6 passes take ~3 sleeps
+    ok = len(calls) == 10 and len(threads) == 2 and set(calls) == {"a", "b"} and prof is None and len(per_rank) == world and dt == max(per_rank)
+    ok &= dt >= 3 * 0.04 * 0.9                    # (the slower rank's three rounds of two overlapped passes bound the leg from below)
+    ok &= tuple(last.shape) == (2, 4, 2, 2)
+    dist.barrier()
+    q.put((rank, bool(ok), per_rank, len(calls), len(threads)))
+    dist.destroy_process_group()
+
+
+def test_bench_timed_leg_world2_with_two_batches_in_flight_per_rank():
+    """What `bench.py --gpus N` runs since round 4 - ranks x host threads x executor replicas - before its first contact with N > 1 GPUs:
+    time_leg driven by an InFlight of two step callables under a 2-rank gloo group.  Every rank runs exactly W + K passes split over its
+    two threads, the barrier / max-over-ranks / all-gather bookkeeping is that of the plain leg, and every rank reports the same list."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_inflight_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [r[:2] for r in res] == [(0, True), (1, True)], res
+    assert res[0][2] == res[1][2] and res[0][3] == res[1][3] == 10 and res[0][4] == res[1][4] == 2
+
+
 def test_dist_init_picks_a_free_port_alone_and_the_reference_default_for_a_multi_rank_run(monkeypatch):
     """A lone process takes a port that is free right now; WORLD_SIZE > 1 without MASTER_PORT (launchers that export only RANK /
     WORLD_SIZE / MASTER_ADDR) meets on the reference's fixed 29500 (utils/dist_utils.py:11-12) and says so - every rank must agree on

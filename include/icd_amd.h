@@ -464,6 +464,8 @@ typedef struct {
     double ms;        /* sum of event-to-event durations */
     double flops;     /* ALGORITHMIC flops (2*M*N*K incl. zero-padded taps; 4*B*H*Nq*Nk*d for attention) */
     double bytes;     /* ALGORITHMIC HBM bytes for the bandwidth-bound families */
+    double flops_executed;  /* flops issued to the matrix cores: = flops except for the split-operand launches (K doubled by the lo */
+                            /* segment: more) and the phase form of the upsampling conv (4 of the 9 taps: fewer)                   */
 } icd_profile_row;
 /* enable > 0: start a fresh recording of every family; enable < 0: record only the families whose bit is set in
  * (-enable) (bit k = family k; keeps the event overhead out of a timed region); enable == 0: stop.  While enabled every

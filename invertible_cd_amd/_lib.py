@@ -75,7 +75,8 @@ ATTN_HOOK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.
 
 
 class ProfileRow(C.Structure):
-    _fields_ = [("kind", C.c_int32), ("launches", C.c_int32), ("ms", C.c_double), ("flops", C.c_double), ("bytes", C.c_double)]
+    _fields_ = [("kind", C.c_int32), ("launches", C.c_int32), ("ms", C.c_double), ("flops", C.c_double), ("bytes", C.c_double),
+                ("flops_executed", C.c_double)]
 
 
 class ProfileRecord(C.Structure):
@@ -221,7 +222,8 @@ def profile_read():
     n = load().icd_profile_read(rows, len(PROF_KINDS))
     if n < 0:
         check(n, "icd_profile_read")
-    return {PROF_KINDS[r.kind]: dict(launches=r.launches, ms=r.ms, flops=r.flops, bytes=r.bytes) for r in rows[:n]}
+    return {PROF_KINDS[r.kind]: dict(launches=r.launches, ms=r.ms, flops=r.flops, bytes=r.bytes, flops_executed=r.flops_executed)
+            for r in rows[:n]}
 
 
 def profile_dump():

@@ -20,7 +20,7 @@ namespace {
 struct Tensor { const void* ptr; int dtype; long long numel; };
 
 // ---- per-family launch timing (HIP events on the launch stream) ------------------------------------------------
-struct ProfRec { hipEvent_t a, b; int kind; double flops, bytes; int M, N, K, aux; int tile_m, tile_n, plan_flags, ksplit; };
+struct ProfRec { hipEvent_t a, b; int kind; double flops, bytes; int M, N, K, aux; int tile_m, tile_n, plan_flags, ksplit; double xflops; };
 bool g_prof_on = false;
 unsigned g_prof_mask = 0xffffffffu;     // bit k: record launches of family k
 std::vector<ProfRec> g_prof;
@@ -37,12 +37,13 @@ struct ProfScope {
     ProfScope(bool active, hipStream_t s, int kind, double flops, double bytes, int M = 0, int N = 0, int K = 0, int aux = 0)
         : on(active && g_prof_on && ((g_prof_mask >> kind) & 1u)), st(s), idx(0) {
         if (!on) return;
-        ProfRec r{prof_event(), prof_event(), kind, flops, bytes, M, N, K, aux, 0, 0, 0, 0};
+        ProfRec r{prof_event(), prof_event(), kind, flops, bytes, M, N, K, aux, 0, 0, 0, 0, flops};
         (void)hipEventRecord(r.a, st);
         idx = g_prof.size();
         g_prof.push_back(r);
     }
     ~ProfScope() { if (on) (void)hipEventRecord(g_prof[idx].b, st); }
+    void executed(double xf) { if (on) g_prof[idx].xflops = xf; }      // flops issued to the matrix cores when they differ from the algorithmic count
     void plan(const icd_gemm_desc& d) {          // which tile the planner takes for this launch (tests assert the code path)
         if (!on) return;
         icd_gemm_plan_info pi;
@@ -169,6 +170,7 @@ struct Exec {
     int kv_off = 0;
     bool kv_external = false;
     int status = ICD_OK;
+    long long alg_k = 0;                     // algorithmic K of the NEXT gemm_desc launch when it differs from the K it issues (see gemm_desc)
 
     const void* T(const std::string& name, int dtype, long long numel) {
         auto it = u->tensors.find(name);
@@ -214,8 +216,14 @@ struct Exec {
         struct Rel { Exec* e; void* p; ~Rel() { if (p) e->release(p); } } rel{this, ws};
         if (!ok() || dry) return;
         const int nb = d.batch > 0 ? d.batch : 1;
+        // algorithmic flops = those of the operator as the reference computes it (2 M N K with the 9-tap, unsplit K); the split-operand
+        // launches (K doubled by the lo segment) and the phase form of the upsampling conv (4 of 9 taps) issue a different number
+        const double xf = 2.0 * d.M * (double)d.N * d.K * nb;
+        const double af = alg_k > 0 ? 2.0 * d.M * (double)d.N * alg_k : xf;
+        alg_k = 0;
         ProfScope ps(true, st, d.mode == 1 ? ICD_PROF_GEMM_CONV : (nb > 1 ? ICD_PROF_GEMM_BATCHED : ICD_PROF_GEMM_DENSE),
-                     2.0 * d.M * (double)d.N * d.K * nb, 0.0, d.M, d.N, d.K, d.mode == 1 ? d.ksize * 100 + d.stride * 10 + d.upsample : d.flags);
+                     af, 0.0, d.M, d.N, d.K, d.mode == 1 ? d.ksize * 100 + d.stride * 10 + d.upsample : d.flags);
+        ps.executed(xf);
         ps.plan(d);
         run(icd_gemm(&d, st));
     }
@@ -336,6 +344,7 @@ struct Exec {
                 sc = alloc<half_t>(M * Cout);
                 sc_aux = alloc_aux(M * Cout);
                 Act s1{sc_src, ld_sc};
+                alg_k = Cin;
                 conv(x0, &s1, Hh, Ww, 1, 1, 0, Wh(p + ".conv_shortcut.weight2", 2LL * Cin * Cout), Cout,
                      Wf(p + ".conv_shortcut.bias", Cout), nullptr, 0, nullptr, sc, nullptr, sc_aux);
                 resid = sc;
@@ -507,6 +516,7 @@ struct Exec {
             half_t* lo = expand(hx, M * C);
             release(hx);
             Act ha{h, C}, la{lo, C};
+            alg_k = C;
             conv(ha, &la, Hh, Ww, 1, 1, 0, Wh(p + ".proj_out.weight2", 2LL * C * C), C, Wf(p + ".proj_out.bias", C), nullptr, 0, x.p, out,
                  x.aux, out_aux);
             release(lo);
@@ -647,6 +657,7 @@ struct Exec {
                 if (split(ICD_SPLIT_DOWN)) {         // the stride-2 conv over [h | lo] against per-tap [W | W]
                     half_t* lo = expand(h.aux, (long long)B * Hh * Ww * Cout);
                     Act la{lo, Cout};
+                    alg_k = 9LL * Cout;
                     conv(h, &la, Hh, Ww, 3, 2, 0, Wh(dp + ".weight2", 18LL * Cout * Cout), Cout, Wf(dp + ".bias", Cout), nullptr, 0, nullptr, dn.p,
                          nullptr, dn.aux);
                     release(lo);
@@ -708,10 +719,12 @@ struct Exec {
                     // nearest 2x + conv3x3 as four 2 x 2 convs on the input grid, one per output pixel phase: 16 tap GEMMs instead of 36
                     for (int ph = 0; ph < 4 && ok(); ++ph) {
                         const std::string wn = upn + (sup ? ".phase3." : ".phase.") + std::to_string(ph);
+                        alg_k = 9LL * Cout;          // per phase: a quarter of the output pixels x all 9 taps of the reference's conv
                         conv(h, sup ? &la : nullptr, Hh, Ww, 3, 1, 0, Wh(wn, (sup ? 12LL : 4LL) * Cout * Cout), Cout, Wf(upn + ".bias", Cout),
                              nullptr, 0, nullptr, up.p, nullptr, up.aux, false, ph);
                     }
                 } else {
+                    alg_k = 9LL * Cout;
                     conv(h, sup ? &la : nullptr, Hh, Ww, 3, 1, 1, Wh(upn + (sup ? ".weight2" : ".weight"), (sup ? 18LL : 9LL) * Cout * Cout), Cout,
                          Wf(upn + ".bias", Cout), nullptr, 0, nullptr, up.p, nullptr, up.aux);
                 }
@@ -797,11 +810,12 @@ extern "C" int icd_profile_enable(int32_t enable) {
 
 extern "C" int icd_profile_read(icd_profile_row* rows, int32_t max_rows) {
     ICD_CHECK_ARG(rows && max_rows >= ICD_PROF_KINDS, "icd_profile_read: need room for %d rows", ICD_PROF_KINDS);
-    for (int k = 0; k < ICD_PROF_KINDS; ++k) { rows[k].kind = k; rows[k].launches = 0; rows[k].ms = rows[k].flops = rows[k].bytes = 0.0; }
+    for (int k = 0; k < ICD_PROF_KINDS; ++k) { rows[k].kind = k; rows[k].launches = 0; rows[k].ms = rows[k].flops = rows[k].bytes = rows[k].flops_executed = 0.0; }
     for (auto& r : g_prof) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) { icd_set_error("icd_profile_read: events not complete (synchronise the stream first)"); return ICD_ERR_HIP; }
         rows[r.kind].launches += 1; rows[r.kind].ms += ms; rows[r.kind].flops += r.flops; rows[r.kind].bytes += r.bytes;
+        rows[r.kind].flops_executed += r.xflops;
     }
     return ICD_PROF_KINDS;
 }

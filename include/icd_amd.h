@@ -245,6 +245,11 @@ int icd_attention_probs(const void* q, const void* k, void* probs, int32_t B, in
  * kind 1: guidance_scale_embedding (utils/generation.py:96-122) -> [sin || cos] of 1000*w, denominator half-1.
  * vals: fp32 [n] on device; out fp16 [n, dim]. */
 int icd_sinusoid(const float* vals, int32_t n, int32_t dim, int32_t kind, void* out, void* stream);
+/* The same with fp32 output and the correctly rounded fp32 frequency table (the precise time-embedding path, ICD_SPLIT_TEMB). */
+int icd_sinusoid_f32(const float* vals, int32_t n, int32_t dim, int32_t kind, float* out, void* stream);
+/* out[r] = [hi (C) | lo (C)] fp16 of act(x[r]) (act 0: identity, 1: SiLU) for fp32 x [rows, C]: hi = fp16(v), lo = fp16(v - hi); a GEMM
+ * over it against [W | W] sees v to ~2^-22.  The time-embedding MLPs of the precise path run on it (fp32 in, fp32 out). */
+int icd_split2_act(const float* x, int64_t rows, int32_t C, int32_t act, void* out, void* stream);
 
 /* y = silu(x) over n fp16 elements (time-embedding activation shared by all ResnetBlock2D.time_emb_proj). */
 int icd_silu(const void* x, int64_t n, void* out, void* stream);
@@ -400,8 +405,11 @@ int32_t icd_unet_num_attention_layers(const icd_unet* u);
 #define ICD_SPLIT_DOWN       16    /* the downsampler conv over [h | lo] */
 #define ICD_SPLIT_SAMPLER_OUT 32   /* down / up sampler outputs carry their rounding error on */
 #define ICD_SPLIT_UP         64    /* the upsampler conv over [h | lo] (2 x its flops: 3.6 % of an SDXL forward, 8.5 % of an SD1.5 one) */
-#define ICD_SPLIT_ALL       127
-#define ICD_SPLIT_DEFAULT    63
+#define ICD_SPLIT_TEMB      128    /* the time-embedding path (Timesteps -> MLPs -> add_embedding -> SiLU -> time_emb_proj) in fp32 precision: */
+                                   /* fp32 sinusoids, split [hi | lo] operands, fp32 outputs; only the per-resnet time biases are fp16.   */
+                                   /* An error there is the same perturbation in every ResnetBlock2D (20 % of SDXL's remaining variance). */
+#define ICD_SPLIT_ALL       255
+#define ICD_SPLIT_DEFAULT   191
 #define ICD_UNET_OPT_XATTN_FUSION    1
 #define ICD_UNET_OPT_LN_INLINE_STATS 2
 #define ICD_UNET_OPT_XATTN_TILE      3

@@ -23,8 +23,8 @@ ICD_UNET_OPT_RESIDUAL_MODE = 5
 ICD_UNET_OPT_RESIDUAL_F32 = 5           # round-3 name
 ICD_UNET_OPT_SPLIT_MASK = 6
 ICD_UNET_OPT_UPSAMPLE_PHASES = 7
-ICD_SPLIT_GN, ICD_SPLIT_CONV1, ICD_SPLIT_SHORTCUT, ICD_SPLIT_PROJ_OUT, ICD_SPLIT_DOWN, ICD_SPLIT_SAMPLER_OUT, ICD_SPLIT_UP = 1, 2, 4, 8, 16, 32, 64
-ICD_SPLIT_DEFAULT, ICD_SPLIT_ALL = 63, 127
+ICD_SPLIT_GN, ICD_SPLIT_CONV1, ICD_SPLIT_SHORTCUT, ICD_SPLIT_PROJ_OUT, ICD_SPLIT_DOWN, ICD_SPLIT_SAMPLER_OUT, ICD_SPLIT_UP, ICD_SPLIT_TEMB = 1, 2, 4, 8, 16, 32, 64, 128
+ICD_SPLIT_DEFAULT, ICD_SPLIT_ALL = 191, 255
 ICD_RESIDUAL_FP16, ICD_RESIDUAL_F32, ICD_RESIDUAL_CARRY, ICD_RESIDUAL_SPLIT = 0, 1, 2, 3
 ICD_ATTN_CAUSAL = 1
 ICD_ATTN_Q_PRESCALED = 2
@@ -110,6 +110,8 @@ SIGNATURES = {
     "icd_groupnorm_carry": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                       C.c_void_p, C.c_void_p, C.c_float, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "icd_carry_expand": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "icd_sinusoid_f32": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "icd_split2_act": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "icd_carry_expand2": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     "icd_layernorm": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p,
                                 C.c_void_p]),

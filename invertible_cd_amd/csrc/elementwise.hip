@@ -8,25 +8,43 @@ namespace {
 // kind 0: diffusers Timesteps(dim, flip_sin_to_cos=True, downscale_freq_shift=0): [cos(t f_i) || sin(t f_i)],
 //         f_i = exp(-ln(1e4) i / half)
 // kind 1: guidance_scale_embedding (utils/generation.py:96-122): [sin(1000 w f_i) || cos(..)], f_i = exp(-ln(1e4) i/(half-1))
-__global__ void sinusoid_kernel(const float* __restrict__ vals, int n, int dim, int kind, half_t* __restrict__ out) {
+// OUT: half_t, or float for the precise time-embedding path of the UNet (ICD_SPLIT_TEMB): there the angle is vals * f with f the
+// CORRECTLY ROUNDED fp32 frequency (exp in double), so that an fp32 host evaluation of the same expression sees the same angles - at
+// t = 999 / time_ids = 1024 one fp32 ulp of f moves the angle by 1e-4, as much as the fp16 rounding this path removes
+template <typename OUT>
+__global__ void sinusoid_kernel(const float* __restrict__ vals, int n, int dim, int kind, OUT* __restrict__ out) {
     const int half = dim >> 1;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n * half) return;
     const int r = idx / half, i = idx - r * half;
     const float lg = 9.210340371976184f;   // ln(10000)
     if (kind == 0) {
-        const float f = expf(-lg * (float)i / (float)half);
+        const float f = sizeof(OUT) == 4 ? (float)exp((double)(-lg * (float)i / (float)half)) : expf(-lg * (float)i / (float)half);
         const float a = vals[r] * f;
-        out[(long long)r * dim + i] = (half_t)cosf(a);
-        out[(long long)r * dim + half + i] = (half_t)sinf(a);
+        out[(long long)r * dim + i] = (OUT)cosf(a);
+        out[(long long)r * dim + half + i] = (OUT)sinf(a);
     } else {
         const float step = lg / (float)(half - 1);
         const float f = expf((float)i * -step);
         const float a = (vals[r] * 1000.0f) * f;
-        out[(long long)r * dim + i] = (half_t)sinf(a);
-        out[(long long)r * dim + half + i] = (half_t)cosf(a);
-        if ((dim & 1) && i == 0) out[(long long)r * dim + dim - 1] = (half_t)0.f;
+        out[(long long)r * dim + i] = (OUT)sinf(a);
+        out[(long long)r * dim + half + i] = (OUT)cosf(a);
+        if ((dim & 1) && i == 0) out[(long long)r * dim + dim - 1] = (OUT)0.f;
     }
+}
+
+// out[r] = [hi (C) | lo (C)] of act(x[r]) for an fp32 tensor: hi = fp16(v), lo = fp16(v - hi) - the operand of a GEMM over [hi | lo]
+// against [W | W] that sees v to ~2^-22 (the time-embedding MLPs of the precise path: a handful of rows, every resnet downstream)
+__global__ void split2_act_kernel(const float* __restrict__ x, long long rows, int C, int act, half_t* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * C) return;
+    const long long r = i / C;
+    const int c = (int)(i - r * C);
+    float v = x[i];
+    if (act == 1) v = v / (1.0f + expf(-v));
+    const half_t hi = (half_t)v;
+    out[r * 2 * C + c] = hi;
+    out[r * 2 * C + C + c] = (half_t)(v - (float)hi);
 }
 
 // KIND 0: silu   1: quick_gelu x*sigmoid(1.702x) (CLIP ViT-L text MLP)   2: gelu (erf form; OpenCLIP bigG text MLP)
@@ -277,9 +295,28 @@ extern "C" int icd_sinusoid(const float* vals, int32_t n, int32_t dim, int32_t k
     ICD_CHECK_ARG(kind == 0 || kind == 1, "icd_sinusoid: kind must be 0 or 1");
     ICD_CHECK_ARG(kind == 1 || dim % 2 == 0, "icd_sinusoid: Timesteps dim must be even");
     const int total = n * (dim / 2);
-    hipLaunchKernelGGL(sinusoid_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, vals, n, dim, kind,
+    hipLaunchKernelGGL(sinusoid_kernel<half_t>, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, vals, n, dim, kind,
                        (half_t*)out);
     ICD_CHECK_LAUNCH("icd_sinusoid");
+    return ICD_OK;
+}
+
+extern "C" int icd_sinusoid_f32(const float* vals, int32_t n, int32_t dim, int32_t kind, float* out, void* stream) {
+    ICD_CHECK_ARG(vals && out && n > 0 && dim >= 2, "icd_sinusoid_f32: bad arguments");
+    ICD_CHECK_ARG(kind == 0 || kind == 1, "icd_sinusoid_f32: kind must be 0 or 1");
+    ICD_CHECK_ARG(kind == 1 || dim % 2 == 0, "icd_sinusoid_f32: Timesteps dim must be even");
+    const int total = n * (dim / 2);
+    hipLaunchKernelGGL(sinusoid_kernel<float>, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, vals, n, dim, kind, out);
+    ICD_CHECK_LAUNCH("icd_sinusoid_f32");
+    return ICD_OK;
+}
+
+extern "C" int icd_split2_act(const float* x, int64_t rows, int32_t C, int32_t act, void* out, void* stream) {
+    ICD_CHECK_ARG(x && out && rows > 0 && C > 0 && (act == 0 || act == 1), "icd_split2_act: bad arguments (act: 0 none, 1 silu)");
+    const long long total = (long long)rows * C;
+    hipLaunchKernelGGL(split2_act_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, (long long)rows, C, act,
+                       (half_t*)out);
+    ICD_CHECK_LAUNCH("icd_split2_act");
     return ICD_OK;
 }
 

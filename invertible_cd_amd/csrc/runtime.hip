@@ -531,11 +531,70 @@ struct Exec {
         return o;
     }
 
+    // The time-embedding path in fp32 precision (ICD_SPLIT_TEMB): fp32 sinusoids, every Linear over the split operand [hi | lo] of its fp32
+    // input against [W | W] with an fp32 output, SiLU on fp32; only temb_all (the per-resnet time biases) is rounded to fp16.  A handful of
+    // rows - but an error in emb is the SAME perturbation in all 22 / 17 resnets (tests/error_budget_sim.py: 20 % of what is left on SDXL).
+    half_t* split2(const float* x, int rows, int C, int act) {
+        half_t* o = alloc<half_t>((long long)rows * 2 * C);
+        if (ok() && !dry) run(icd_split2_act(x, rows, C, act, o, st));
+        return o;
+    }
+    int time_embedding_precise() {
+        const icd_unet_config& c = u->cfg;
+        const int ch0 = c.block_out_channels[0], temb = ch0 * 4;
+        const int F32 = ICD_GEMM_OUT_F32, R32 = ICD_GEMM_RESID_F32;
+        float* tin = alloc<float>((long long)B * ch0);
+        if (ok() && !dry) run(icd_sinusoid_f32(io->timesteps, B, ch0, 0, tin, st));
+        if (c.time_cond_proj_dim > 0 && (dry ? true : io->timestep_cond != nullptr))      // + cond_proj(w) (an fp16 input: exact operand)
+            linear((const half_t*)io->timestep_cond, c.time_cond_proj_dim, B, c.time_cond_proj_dim,
+                   Wh("time_embedding.cond_proj.weight", (long long)ch0 * c.time_cond_proj_dim), ch0, nullptr, (const half_t*)tin, ch0,
+                   (half_t*)tin, ch0, F32 | R32);
+        half_t* s = split2(tin, B, ch0, 0);
+        float* e1 = alloc<float>((long long)B * temb);
+        linear(s, 2 * ch0, B, 2 * ch0, Wh("time_embedding.linear_1.weight2", 2LL * temb * ch0), temb, Wf("time_embedding.linear_1.bias", temb),
+               nullptr, 0, (half_t*)e1, temb, F32);
+        release(s); release(tin);
+        s = split2(e1, B, temb, 1);
+        float* emb = alloc<float>((long long)B * temb);
+        linear(s, 2 * temb, B, 2 * temb, Wh("time_embedding.linear_2.weight2", 2LL * temb * temb), temb, Wf("time_embedding.linear_2.bias", temb),
+               nullptr, 0, (half_t*)emb, temb, F32);
+        release(s);
+        if (c.add_in_dim > 0) {
+            const int tdim = c.addition_time_embed_dim, pooled = c.add_in_dim - 6 * tdim;
+            if (!dry && (!io->time_ids || !io->text_embeds)) { icd_set_error("SDXL forward needs text_embeds and time_ids"); return ICD_ERR_INVALID_ARG; }
+            float* tid = alloc<float>((long long)B * 6 * tdim);
+            if (ok() && !dry) run(icd_sinusoid_f32(io->time_ids, B * 6, tdim, 0, tid, st));
+            half_t* st2 = split2(tid, B, 6 * tdim, 0);
+            release(tid);
+            // Linear over cat([text_embeds (fp16 input: exact), hi(time_embeds), lo(time_embeds)]) against [W_text | W_time | W_time]
+            Act s0{(half_t*)io->text_embeds, pooled}, s1{st2, 12 * tdim};
+            conv(s0, &s1, 1, 1, 1, 1, 0, Wh("add_embedding.linear_1.weight2", (long long)temb * (pooled + 12 * tdim)), temb,
+                 Wf("add_embedding.linear_1.bias", temb), nullptr, 0, nullptr, e1, nullptr, nullptr, true);
+            release(st2);
+            s = split2(e1, B, temb, 1);
+            linear(s, 2 * temb, B, 2 * temb, Wh("add_embedding.linear_2.weight2", 2LL * temb * temb), temb, Wf("add_embedding.linear_2.bias", temb),
+                   (const half_t*)emb, temb, (half_t*)emb, temb, F32 | R32);
+            release(s);
+        }
+        release(e1);
+        s = split2(emb, B, temb, 1);                                  // SiLU(emb), shared by every resnet
+        release(emb);
+        temb_all = alloc<half_t>((long long)B * u->temb_total);
+        linear(s, 2 * temb, B, 2 * temb, Wh("time_emb_proj_cat.weight2", 2LL * u->temb_total * temb), u->temb_total,
+               Wf("time_emb_proj_cat.bias", u->temb_total), nullptr, 0, temb_all, u->temb_total);
+        release(s);
+        return status;
+    }
+
     int forward() {
         const icd_unet_config& c = u->cfg;
         const int L = c.num_levels, ch0 = c.block_out_channels[0], temb = ch0 * 4;
         const int HW0 = H0 * W0;
         gn_ws = alloc<float>(icd_groupnorm_ws_floats(B, HW0, c.norm_groups));
+        if (split(ICD_SPLIT_TEMB)) {
+            const int rc = time_embedding_precise();
+            if (rc != ICD_OK) return rc;
+        } else {
         // ---------------- time embedding: Timesteps -> (+cond_proj) -> Linear -> SiLU -> Linear (+ SDXL add_embedding)
         half_t* tsin = alloc<half_t>((long long)B * ch0);
         if (ok() && !dry) run(icd_sinusoid(io->timesteps, B, ch0, 0, tsin, st));
@@ -580,6 +639,8 @@ struct Exec {
         temb_all = alloc<half_t>((long long)B * u->temb_total);
         linear(e1, temb, B, temb, Wh("time_emb_proj_cat.weight", (long long)u->temb_total * temb), u->temb_total,
                Wf("time_emb_proj_cat.bias", u->temb_total), nullptr, 0, temb_all, u->temb_total);
+        release(e1); release(emb); if (tin != tsin) release(tin); release(tsin);
+        }
         temb_off = 0;
         // every cross-attention K / V projection depends on the context only: two GEMMs for the whole forward
         {
@@ -607,7 +668,6 @@ struct Exec {
             }
             kv_off = 0;
         }
-        release(e1); release(emb); if (tin != tsin) release(tin); release(tsin);
 
         // ---------------- conv_in
         std::vector<Act> skips;

@@ -93,11 +93,14 @@ def pack_state_dict(cfg: UNetConfig, sd, device):
         w4 = w.reshape(w.shape[0], w.shape[1], -1).permute(0, 2, 1)                      # [O, taps, I]
         packed[name + ".weight2"] = w16(torch.cat([w4, w4], 2).reshape(w.shape[0], -1))
 
-    def dense(name, bias=True):
+    def dense(name, bias=True, split=False):
         w = take(name + ".weight")
         packed[name + ".weight"] = w16(w.reshape(w.shape[0], -1))
         if bias:
             packed[name + ".bias"] = f32(take(name + ".bias"))
+        if split:            # the precise time-embedding path (ICD_SPLIT_TEMB): the operand is [hi | lo] of an fp32 activation
+            w2 = w.reshape(w.shape[0], -1)
+            packed[name + ".weight2"] = w16(torch.cat([w2, w2], 1))
 
     def affine(name):
         packed[name + ".weight"] = f32(take(name + ".weight"))
@@ -108,13 +111,15 @@ def pack_state_dict(cfg: UNetConfig, sd, device):
     w8 = torch.zeros((w_in.shape[0], 3, 3, 8), device=device, dtype=torch.float32)
     w8[..., :4] = w_in.permute(0, 2, 3, 1).float()
     packed["conv_in.weight8"] = w16(w8.reshape(w_in.shape[0], 72))
-    dense("time_embedding.linear_1")
-    dense("time_embedding.linear_2")
+    dense("time_embedding.linear_1", split=True)
+    dense("time_embedding.linear_2", split=True)
     if cfg.time_cond_proj_dim:
         dense("time_embedding.cond_proj", bias=False)
     if cfg.add_in_dim:
         dense("add_embedding.linear_1")
-        dense("add_embedding.linear_2")
+        dense("add_embedding.linear_2", split=True)
+        wa = sd["add_embedding.linear_1.weight"]                 # input = cat([text_embeds (fp16: exact), time sinusoids (fp32: [hi | lo])])
+        packed["add_embedding.linear_1.weight2"] = w16(torch.cat([wa, wa[:, cfg.pooled_dim:]], 1))
     tw, tb = [], []
     for p, ci, co in cfg.resnet_names():
         affine(p + ".norm1")
@@ -126,6 +131,7 @@ def pack_state_dict(cfg: UNetConfig, sd, device):
         tw.append(take(p + ".time_emb_proj.weight"))
         tb.append(take(p + ".time_emb_proj.bias"))
     packed["time_emb_proj_cat.weight"] = w16(torch.cat([t.to(device) for t in tw], 0))
+    packed["time_emb_proj_cat.weight2"] = torch.cat([packed["time_emb_proj_cat.weight"]] * 2, 1).contiguous()
     packed["time_emb_proj_cat.bias"] = f32(torch.cat([t.to(device) for t in tb], 0))
     kcat, vcat = [], []
     for p, c, depth, heads, _ in cfg.transformer_names():

@@ -288,7 +288,10 @@ def live_traffic(arch, batch, family, timeout_s=240):
         per = {}
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             d = os.path.join(tmp, counter)
-            r = subprocess.run([exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--"] + child,
+            # counters only on the family's kernels: every other dispatch of the child (building 2.6 G synthetic parameters is thousands of
+            # small torch kernels) runs unserialised - the SDXL pass fits the default run that way
+            only = ["--kernel-include-regex", "gemm"] if family.startswith("gemm") else []
+            r = subprocess.run([exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p"] + only + ["--"] + child,
                                cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
             if r.returncode != 0:
                 return None, f"rocprofv3 --pmc {counter} exited {r.returncode}"

@@ -848,8 +848,17 @@ static int gemm_run(const icd_gemm_desc* d, void* stream, icd_gemm_plan_info* in
     {
         // (the big conv tiles address their sources with 32-bit buffer offsets whose bit 31 marks a zero-padding read: < 2 GiB per source
         // tensor, else the 128-wide kernels)
-        const long long conv_src_bytes = d->mode == 1 && d->rows_per_sample > 0
-            ? (long long)((d->M + d->rows_per_sample - 1) / d->rows_per_sample) * d->Hin * d->Win * std::max(d->C0, d->C1) * 2 : 0;
+        // (sample count from the output geometry, as the kernel derives its descriptor size - not from rows_per_sample, which a caller
+        // may leave unset; the geometry itself is validated before any tile is chosen)
+        if (d->mode == 1) {
+            ICD_CHECK_ARG(d->ksize == 1 || d->ksize == 3, "icd_gemm: conv ksize must be 1 or 3");
+            ICD_CHECK_ARG(d->stride == 1 || d->stride == 2, "icd_gemm: conv stride must be 1 or 2");
+            ICD_CHECK_ARG(d->upsample == 0 || d->upsample == 1, "icd_gemm: upsample must be 0 or 1");
+            ICD_CHECK_ARG(d->Hin > 0 && d->Win > 0 && d->Hout > 0 && d->Wout > 0 && d->M % (d->Hout * d->Wout) == 0,
+                          "icd_gemm: bad conv geometry");
+        }
+        const long long conv_hw = d->mode == 1 ? (long long)d->Hout * d->Wout : 0;
+        const long long conv_src_bytes = conv_hw > 0 ? ((d->M + conv_hw - 1) / conv_hw) * d->Hin * d->Win * std::max(d->C0, d->C1) * 2 : 0;
         const bool conv_fast = d->mode == 1 && ((d->C0 + d->C1) % 64 == 0) && (d->C0 % 64 == 0) && conv_src_bytes < (1LL << 31) - (1 << 22);
         // transposed (V^T) outputs take the big tiles when a 32-row tile never straddles two samples and no pad columns
         // have to be zeroed (ldo == rows_per_sample); otherwise the 128-wide kernel's general epilogue handles them

@@ -604,6 +604,7 @@ def run_reverse(a, wl, arch, batch, steps, warmup, device, world, rank, primary)
                                  "frac": round(ev_over, 4), "value_from": "pass without events" if use_plain else "pass with events",
                                  "note": "pass A: K steps with HIP events around the dominant family (the roofline); pass B: K steps with none"}
     elif dt_ev is not None:
+        out["value_one_batch_at_a_time"] = round(images / dt_ev, 3)       # top level too: the figure comparable with rounds 1 - 3 (advisor r4)
         out["one_batch_at_a_time"] = {"value": round(images / dt_ev, 3), "ms_per_step": round(dt_ev / steps * 1e3, 3),
                                       "note": f"pass A: the sequential loop (one batch in flight) with HIP events around the dominant family - the "
                                               f"roofline leg; `value` is pass B: the same K steps with {len(flight)} independent batches in flight "

@@ -240,6 +240,11 @@ int icd_attention_fused_ex(const void* q, const void* k, const void* vt, void* o
  * callback and P.V (icd_gemm, batched) follow as before.  q / k layouts as in icd_attention_fused. */
 int icd_attention_probs(const void* q, const void* k, void* probs, int32_t B, int32_t H, int32_t Nq, int32_t Nk, int32_t d,
                         int32_t ldq, int32_t ldk, int32_t ldp, float scale, void* stream);
+/* The same with split operands: q_carry / k_carry (either may be NULL) are the error carries of q / k as icd_gemm_desc.out_carry writes
+ * them (uint8, the indexing of q / k); scores = qh.kh + 2^-14 (ql.kh + qh.kl).  A stored probability is the exponential of its score:
+ * the fp16 rounding of q and k is an absolute error of the exponent, i.e. a relative error of every map a controller keeps. */
+int icd_attention_probs_split(const void* q, const void* q_carry, const void* k, const void* k_carry, void* probs, int32_t B, int32_t H,
+                              int32_t Nq, int32_t Nk, int32_t d, int32_t ldq, int32_t ldk, int32_t ldp, float scale, void* stream);
 
 /* Sinusoidal embeddings.  kind 0: diffusers Timesteps(dim, flip_sin_to_cos=True, shift=0) -> [cos || sin];
  * kind 1: guidance_scale_embedding (utils/generation.py:96-122) -> [sin || cos] of 1000*w, denominator half-1.
@@ -408,8 +413,10 @@ int32_t icd_unet_num_attention_layers(const icd_unet* u);
 #define ICD_SPLIT_TEMB      128    /* the time-embedding path (Timesteps -> MLPs -> add_embedding -> SiLU -> time_emb_proj) in fp32 precision: */
                                    /* fp32 sinusoids, split [hi | lo] operands, fp32 outputs; only the per-resnet time biases are fp16.   */
                                    /* An error there is the same perturbation in every ResnetBlock2D (20 % of SDXL's remaining variance). */
-#define ICD_SPLIT_ALL       255
-#define ICD_SPLIT_DEFAULT   191
+#define ICD_SPLIT_QK        256    /* layers whose probabilities a controller keeps: q and k leave their projections with an error carry and the  */
+                                   /* probability kernel computes qh.kh + 2^-14 (ql.kh + qh.kl) (icd_attention_probs_split)                        */
+#define ICD_SPLIT_ALL       511
+#define ICD_SPLIT_DEFAULT   447
 #define ICD_UNET_OPT_XATTN_FUSION    1
 #define ICD_UNET_OPT_LN_INLINE_STATS 2
 #define ICD_UNET_OPT_XATTN_TILE      3

@@ -24,7 +24,8 @@ ICD_UNET_OPT_RESIDUAL_F32 = 5           # round-3 name
 ICD_UNET_OPT_SPLIT_MASK = 6
 ICD_UNET_OPT_UPSAMPLE_PHASES = 7
 ICD_SPLIT_GN, ICD_SPLIT_CONV1, ICD_SPLIT_SHORTCUT, ICD_SPLIT_PROJ_OUT, ICD_SPLIT_DOWN, ICD_SPLIT_SAMPLER_OUT, ICD_SPLIT_UP, ICD_SPLIT_TEMB = 1, 2, 4, 8, 16, 32, 64, 128
-ICD_SPLIT_DEFAULT, ICD_SPLIT_ALL = 191, 255
+ICD_SPLIT_QK = 256
+ICD_SPLIT_DEFAULT, ICD_SPLIT_ALL = 447, 511
 ICD_RESIDUAL_FP16, ICD_RESIDUAL_F32, ICD_RESIDUAL_CARRY, ICD_RESIDUAL_SPLIT = 0, 1, 2, 3
 ICD_ATTN_CAUSAL = 1
 ICD_ATTN_Q_PRESCALED = 2
@@ -126,6 +127,7 @@ SIGNATURES = {
                                       C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64,
                                       C.c_float, C.c_void_p]),
     "icd_attention_probs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int32] * 8 + [C.c_float, C.c_void_p]),
+    "icd_attention_probs_split": (C.c_int, [C.c_void_p] * 5 + [C.c_int32] * 8 + [C.c_float, C.c_void_p]),
     "icd_sinusoid": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "icd_silu": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "icd_conv_in": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,

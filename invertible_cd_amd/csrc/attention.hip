@@ -728,9 +728,22 @@ struct ProbsK {
     const half_t* q; const half_t* k; half_t* p;
     int B, H, Nq, Nk, d, ldq, ldk, ldp;
     float scale_log2;
+    const unsigned char* qc; const unsigned char* kc;      // SPLIT: error carries of q / k (same indexing, one byte per element), or null
 };
 
-template <int KS>
+// 8 carry bytes -> 8 fp16 values bf8_e5m2(byte) (UNSCALED: a bf8 e5m2 number is the top byte of the fp16 with the same value)
+__device__ __forceinline__ f16x8 carry8_as_f16(const u32x2 w) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 r = {__builtin_amdgcn_perm(w[0], 0u, 0x050c040cu), __builtin_amdgcn_perm(w[0], 0u, 0x070c060cu),
+                     __builtin_amdgcn_perm(w[1], 0u, 0x050c040cu), __builtin_amdgcn_perm(w[1], 0u, 0x070c060cu)};
+    return __builtin_bit_cast(f16x8, r);
+}
+
+// SPLIT (round 5, the accurate precision level on layers whose probabilities a controller keeps): q and k arrive with the error carry
+// of their fp16 rounding (icd_gemm_desc.out_carry) and the scores are q.k = qh.kh + 2^-14 (ql.kh + qh.kl) - three MFMAs per k-step on
+// two accumulators (the lo products in their own, unscaled).  A stored probability map is exp of these scores: its relative error IS the
+// absolute error of the score, and the fp16 rounding of q and k is 12 % of the attention-store error budget (tests/error_budget_sim.py).
+template <int KS, bool SPLIT = false>
 __global__ __launch_bounds__(256, 2) void attn_probs_kernel(ProbsK a) {
     __shared__ __attribute__((aligned(16))) half_t patch_all[4][32 * 72];
     const int tid = threadIdx.x, l = tid & 63, lr = l & 31, lh = l >> 5;
@@ -742,31 +755,48 @@ __global__ __launch_bounds__(256, 2) void attn_probs_kernel(ProbsK a) {
     f16x8 z8;
 #pragma unroll
     for (int e = 0; e < 8; ++e) z8[e] = (half_t)0.f;
-    f16x8 qf[KS];
+    constexpr int KF = SPLIT ? 2 * KS : KS;            // fragments per operand: [hi (KS) | lo (KS)]
+    const u32x2 zc = {0u, 0u};
+    f16x8 qf[KF];
     {
         const int qrow = q0 + lr;
-        const half_t* qp = a.q + ((long long)b * a.Nq + qrow) * a.ldq + h * a.d;
+        const long long qoff = ((long long)b * a.Nq + qrow) * a.ldq + h * a.d;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const int dd = ks * 16 + lh * 8;
-            qf[ks] = (qrow < a.Nq && dd < a.d) ? *reinterpret_cast<const f16x8*>(qp + dd) : z8;
+            const bool okq = qrow < a.Nq && dd < a.d;
+            qf[ks] = okq ? *reinterpret_cast<const f16x8*>(a.q + qoff + dd) : z8;
+            if (SPLIT) qf[KS + ks] = carry8_as_f16((okq && a.qc) ? *reinterpret_cast<const u32x2*>(a.qc + qoff + dd) : zc);
         }
     }
-    const half_t* Kb = a.k + (long long)b * a.Nk * a.ldk + h * a.d;
+    const long long koff0 = (long long)b * a.Nk * a.ldk + h * a.d;
     const int prow = (lr & 0x13) | ((lr & 4) << 1) | ((lr & 8) >> 1);
-    auto load_k = [&](f16x8 (&kf)[KS], int kt) {
+    auto load_k = [&](f16x8 (&kf)[KF], int kt) {
         const int key = kt * 32 + prow;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const int dd = ks * 16 + lh * 8;
-            kf[ks] = (key < a.Nk && dd < a.d) ? *reinterpret_cast<const f16x8*>(Kb + (long long)key * a.ldk + dd) : z8;
+            const bool okk = key < a.Nk && dd < a.d;
+            const long long off = koff0 + (long long)key * a.ldk + dd;
+            kf[ks] = okk ? *reinterpret_cast<const f16x8*>(a.k + off) : z8;
+            if (SPLIT) kf[KS + ks] = carry8_as_f16((okk && a.kc) ? *reinterpret_cast<const u32x2*>(a.kc + off) : zc);
         }
     };
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const float c = a.scale_log2;
-    auto scores = [&](f32x16& s, const f16x8 (&kf)[KS], int kt) {            // s = log2(e) * scale * q.k, keys past Nk -> -inf
+    auto scores = [&](f32x16& s, const f16x8 (&kf)[KF], int kt) {            // s = log2(e) * scale * q.k, keys past Nk -> -inf
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[ks], qf[ks], ks == 0 ? zero16 : s, 0, 0, 0);
+        if (SPLIT) {                                                           // + 2^-14 (kl.qh + kh.ql)
+            f32x16 t;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                t = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[KS + ks], qf[ks], ks == 0 ? zero16 : t, 0, 0, 0);
+                t = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[ks], qf[KS + ks], t, 0, 0, 0);
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s[e] = __builtin_fmaf(t[e], 1.f / 16384.f, s[e]);
+        }
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             s[e] = 16 * (e >> 3) + (e & 7) < a.Nk - kt * 32 - 8 * lh ? s[e] * c : -INFINITY;      // key < Nk
@@ -808,7 +838,7 @@ __global__ __launch_bounds__(256, 2) void attn_probs_kernel(ProbsK a) {
 #pragma unroll
         for (int kt = 0; kt < 3; ++kt) {
             if (kt < nt) {
-                f16x8 kf[KS];
+                f16x8 kf[KF];
                 load_k(kf, kt);
                 scores(s[kt], kf, kt);
 #pragma unroll
@@ -837,7 +867,7 @@ __global__ __launch_bounds__(256, 2) void attn_probs_kernel(ProbsK a) {
     // ---- many keys: sweep 1 = running row maximum and sum, sweep 2 = probabilities ----
     float m_run = -INFINITY, l_run = 0.f;
     {
-        f16x8 ka[KS], kb[KS];
+        f16x8 ka[KF], kb[KF];
         load_k(ka, 0);
         for (int kt = 0; kt < nt; kt += 2) {
             if (kt + 1 < nt) load_k(kb, kt + 1);
@@ -875,7 +905,7 @@ __global__ __launch_bounds__(256, 2) void attn_probs_kernel(ProbsK a) {
     }
     const float inv = 1.0f / l_run;
     {
-        f16x8 ka[KS], kb[KS];
+        f16x8 ka[KF], kb[KF];
         load_k(ka, 0);
         for (int kt = 0; kt < nt; kt += 2) {
             if (kt + 1 < nt) load_k(kb, kt + 1);
@@ -938,8 +968,8 @@ extern "C" int icd_attention_fused_ex(const void* q, const void* k, const void* 
                                       int32_t Nq, int32_t Nk, int32_t d, int32_t ldq, int32_t ldk, int32_t ldvt, int32_t ldo,
                                       int64_t vt_batch_stride, float scale, int32_t flags, void* stream);
 
-extern "C" int icd_attention_probs(const void* q, const void* k, void* probs, int32_t B, int32_t H, int32_t Nq, int32_t Nk,
-                                   int32_t d, int32_t ldq, int32_t ldk, int32_t ldp, float scale, void* stream) {
+static int attention_probs_run(const void* q, const void* qc, const void* k, const void* kc, void* probs, int32_t B, int32_t H, int32_t Nq,
+                               int32_t Nk, int32_t d, int32_t ldq, int32_t ldk, int32_t ldp, float scale, void* stream) {
     ICD_CHECK_ARG(q && k && probs, "icd_attention_probs: null pointer");
     ICD_CHECK_ARG(B > 0 && H > 0 && Nq > 0 && Nk > 0, "icd_attention_probs: empty shape");
     ICD_CHECK_ARG(d > 0 && d % 8 == 0 && d <= 160, "icd_attention_probs: head dim must be a multiple of 8, <= 160 (got %d)", d);
@@ -950,14 +980,33 @@ extern "C" int icd_attention_probs(const void* q, const void* k, void* probs, in
     a.q = (const half_t*)q; a.k = (const half_t*)k; a.p = (half_t*)probs;
     a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.d = d; a.ldq = ldq; a.ldk = ldk; a.ldp = ldp;
     a.scale_log2 = scale * 1.4426950408889634f;
+    a.qc = (const unsigned char*)qc; a.kc = (const unsigned char*)kc;
     const dim3 grid((unsigned)((Nq + 127) / 128), (unsigned)(B * H));
     hipStream_t st = (hipStream_t)stream;
-    if (d <= 48) hipLaunchKernelGGL(attn_probs_kernel<3>, grid, dim3(256), 0, st, a);
-    else if (d <= 80) hipLaunchKernelGGL(attn_probs_kernel<5>, grid, dim3(256), 0, st, a);
-    else if (d <= 128) hipLaunchKernelGGL(attn_probs_kernel<8>, grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(attn_probs_kernel<10>, grid, dim3(256), 0, st, a);
+    if (qc || kc) {
+        if (d <= 48) hipLaunchKernelGGL((attn_probs_kernel<3, true>), grid, dim3(256), 0, st, a);
+        else if (d <= 80) hipLaunchKernelGGL((attn_probs_kernel<5, true>), grid, dim3(256), 0, st, a);
+        else if (d <= 128) hipLaunchKernelGGL((attn_probs_kernel<8, true>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((attn_probs_kernel<10, true>), grid, dim3(256), 0, st, a);
+    } else {
+        if (d <= 48) hipLaunchKernelGGL((attn_probs_kernel<3, false>), grid, dim3(256), 0, st, a);
+        else if (d <= 80) hipLaunchKernelGGL((attn_probs_kernel<5, false>), grid, dim3(256), 0, st, a);
+        else if (d <= 128) hipLaunchKernelGGL((attn_probs_kernel<8, false>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((attn_probs_kernel<10, false>), grid, dim3(256), 0, st, a);
+    }
     ICD_CHECK_LAUNCH("icd_attention_probs");
     return ICD_OK;
+}
+
+extern "C" int icd_attention_probs(const void* q, const void* k, void* probs, int32_t B, int32_t H, int32_t Nq, int32_t Nk,
+                                   int32_t d, int32_t ldq, int32_t ldk, int32_t ldp, float scale, void* stream) {
+    return attention_probs_run(q, nullptr, k, nullptr, probs, B, H, Nq, Nk, d, ldq, ldk, ldp, scale, stream);
+}
+
+extern "C" int icd_attention_probs_split(const void* q, const void* q_carry, const void* k, const void* k_carry, void* probs, int32_t B,
+                                         int32_t H, int32_t Nq, int32_t Nk, int32_t d, int32_t ldq, int32_t ldk, int32_t ldp, float scale,
+                                         void* stream) {
+    return attention_probs_run(q, q_carry, k, k_carry, probs, B, H, Nq, Nk, d, ldq, ldk, ldp, scale, stream);
 }
 
 extern "C" int icd_attention_fused(const void* q, const void* k, const void* vt, void* out, int32_t B, int32_t H,

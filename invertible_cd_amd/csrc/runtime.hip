@@ -167,6 +167,7 @@ struct Exec {
     int temb_off = 0;
     half_t* k_all = nullptr;                 // [B*nctx, kv_total]: K of every cross-attention layer
     half_t* vt_all = nullptr;                // [B, kv_total, ldv_cross]: V^T of every cross-attention layer
+    unsigned char* k_all_c = nullptr;        // error carry of k_all (split mode, ICD_SPLIT_QK), or null
     int kv_off = 0;
     bool kv_external = false;
     int status = ICD_OK;
@@ -389,8 +390,10 @@ struct Exec {
     }
 
     // one attention module: q [B*Nq, ldq] (head h at col h*d), k [B*Nk, ldk], vt [B, C, ldv]; out [B*Nq, C]
+    // q_c / k_c: error carries of q / k (split mode, materialised layers only), or null
     void attention(const AttnPlan& plan, bool is_cross, int place, const half_t* q, int ldq, const half_t* k, int ldk, const half_t* vt,
-                   int ldv, long long vt_bs, int heads, int Nq, int Nk, int d, half_t* out, int C) {
+                   int ldv, long long vt_bs, int heads, int Nq, int Nk, int d, half_t* out, int C, const void* q_c = nullptr,
+                   const void* k_c = nullptr) {
         const int my_layer = plan.layer;
         const long long ldp = (Nk + 7) / 8 * 8;
         // The packer (unet.pack_state_dict) folds d^-1/2 * log2(e) into every query projection: q.k already is the base-2
@@ -414,7 +417,7 @@ struct Exec {
         const long long per_b = (long long)heads * Nq * ldp;            // elements of P per sample
         if (!dry && ok()) {
             ProfScope ps(true, st, ICD_PROF_SOFTMAX, 2.0 * B * heads * (double)Nq * Nk * d, (double)B * per_b * 2.0);
-            run(icd_attention_probs(q, k, probs, B, heads, Nq, Nk, d, ldq, ldk, (int)ldp, scale, st));
+            run(icd_attention_probs_split(q, q_c, k, k_c, probs, B, heads, Nq, Nk, d, ldq, ldk, (int)ldp, scale, st));
         }
         if (!dry && ok()) {
             const int r = io->hook(io->hook_user, ICD_HOOK_PROBS, my_layer, is_cross, place, (long long)B * heads, Nq, Nk, ldp, &probs);
@@ -452,16 +455,20 @@ struct Exec {
             const std::string b = p + ".transformer_blocks." + std::to_string(kb);
             // ---- self attention ----
             ln_stats(h, M, C, lnst);
+            // (the controller is asked before the projection is enqueued: a layer whose probabilities it keeps gets q and k with their
+            //  error carry in split mode - through the general epilogue and a statistics launch, only on such layers)
+            const AttnPlan self_plan = attn_query(false, place, heads, HW, HW);
             half_t* qk = alloc<half_t>(M * 2 * C);
+            void* qk_c = (self_plan.mat && split(ICD_SPLIT_QK)) ? alloc_aux(M * 2 * C) : nullptr;
             linear(h, C, (int)M, C, Wh(b + ".attn1.to_qk.weight", 2LL * C * C), 2 * C, Wf(b + ".attn1.to_qk.lnbias", 2 * C), nullptr, 0, qk,
-                   2 * C, lnc, 0, lnst, Wf(b + ".attn1.to_qk.lnsum", 2 * C));
+                   2 * C, qk_c ? (lnc | ICD_GEMM_TUNE_NO_LN_INLINE) : lnc, 0, lnst, Wf(b + ".attn1.to_qk.lnsum", 2 * C), nullptr, qk_c);
             half_t* vt = alloc<half_t>((long long)B * C * ldv_self);
             linear(h, C, (int)M, C, Wh(b + ".attn1.to_v.weight", (long long)C * C), C, nullptr, nullptr, 0, vt, ldv_self,
                    ICD_GEMM_OUT_TRANS, HW, lnst, Wf(b + ".attn1.to_v.lnsum", C));      // (W_v beta) rides in to_out's bias
             half_t* ao = alloc<half_t>(M * C);
-            const AttnPlan self_plan = attn_query(false, place, heads, HW, HW);
-            attention(self_plan, false, place, qk, 2 * C, qk + C, 2 * C, vt, ldv_self, (long long)C * ldv_self, heads, HW, HW, d, ao, C);
-            release(qk); release(vt);
+            attention(self_plan, false, place, qk, 2 * C, qk + C, 2 * C, vt, ldv_self, (long long)C * ldv_self, heads, HW, HW, d, ao, C,
+                      qk_c, qk_c ? (const unsigned char*)qk_c + C : nullptr);
+            release(qk); release(vt); release(qk_c);
             linear(ao, C, (int)M, C, Wh(b + ".attn1.to_out.0.weight", (long long)C * C), C, Wf(b + ".attn1.to_out.0.bias", C), tw ? nullptr : h, C,
                    h, C, 0, 0, nullptr, nullptr, hx, hx);
             // ---- cross attention ----
@@ -492,9 +499,11 @@ struct Exec {
                 }
             } else {
                 half_t* q2 = alloc<half_t>(M * C);
-                linear(h, C, (int)M, C, wq, C, bq, nullptr, 0, q2, C, lnc, 0, lnst, sq);
-                attention(cross_plan, true, place, q2, C, kx, u->kv_total, vx, ldv_cross, vx_bs, heads, HW, nctx, d, ao, C);
-                release(q2);
+                void* q2_c = (cross_plan.mat && split(ICD_SPLIT_QK)) ? alloc_aux(M * C) : nullptr;
+                linear(h, C, (int)M, C, wq, C, bq, nullptr, 0, q2, C, q2_c ? (lnc | ICD_GEMM_TUNE_NO_LN_INLINE) : lnc, 0, lnst, sq, nullptr, q2_c);
+                attention(cross_plan, true, place, q2, C, kx, u->kv_total, vx, ldv_cross, vx_bs, heads, HW, nctx, d, ao, C, q2_c,
+                          (q2_c && k_all_c) ? k_all_c + kv_off : nullptr);
+                release(q2); release(q2_c);
             }
             kv_off += C;
             linear(ao, C, (int)M, C, Wh(b + ".attn2.to_out.0.weight", (long long)C * C), C, Wf(b + ".attn2.to_out.0.bias", C), tw ? nullptr : h, C,
@@ -648,19 +657,21 @@ struct Exec {
             const long long k_elems = (long long)Mc * u->kv_total, v_elems = (long long)B * u->kv_total * ldvc;
             bool have = false;
             if (!dry && io->kv_cache) {                  // caller-owned cache of the context projections (icd_unet_io.kv_cache)
-                if (io->kv_cache_bytes < (k_elems + v_elems) * 2) {
+                if (io->kv_cache_bytes < (k_elems + v_elems) * 2 + k_elems) {
                     icd_set_error("icd_unet_forward: kv_cache too small (%lld bytes given); query icd_unet_kv_cache_bytes", (long long)io->kv_cache_bytes);
                     return ICD_ERR_WORKSPACE;
                 }
                 k_all = (half_t*)io->kv_cache; vt_all = k_all + k_elems; kv_external = true;
+                if (split(ICD_SPLIT_QK)) k_all_c = (unsigned char*)(vt_all + v_elems);       // (the cache has room for it: icd_unet_kv_cache_bytes)
                 have = io->kv_cache_valid != 0;
             } else {
                 k_all = alloc<half_t>(k_elems);
                 vt_all = alloc<half_t>(v_elems);
+                if (split(ICD_SPLIT_QK)) k_all_c = (unsigned char*)alloc_aux(k_elems);
             }
             if (!have) {
                 linear((const half_t*)io->context, X, Mc, X, Wh("attn2_k_cat.weight", (long long)u->kv_total * X), u->kv_total, nullptr,
-                       nullptr, 0, k_all, u->kv_total);
+                       nullptr, 0, k_all, u->kv_total, 0, 0, nullptr, nullptr, nullptr, k_all_c);
                 linear((const half_t*)io->context, X, Mc, X, Wh("attn2_v_cat.weight", (long long)u->kv_total * X), u->kv_total, nullptr,
                        nullptr, 0, vt_all, ldvc, ICD_GEMM_OUT_TRANS, nctx);
             } else {                                     // (a finalize-style walk still checks that the weights are bound)
@@ -806,7 +817,7 @@ struct Exec {
         }
         release(n);
         release(temb_all);
-        if (!kv_external) { release(k_all); release(vt_all); }
+        if (!kv_external) { release(k_all); release(vt_all); release(k_all_c); }
         return status;
     }
 };
@@ -980,7 +991,8 @@ extern "C" int64_t icd_unet_workspace_bytes(const icd_unet* u, int32_t batch, in
 extern "C" int64_t icd_unet_kv_cache_bytes(const icd_unet* u, int32_t batch, int32_t n_ctx) {
     if (!u || batch <= 0 || n_ctx <= 0) return -1;
     const long long ldvc = (n_ctx + 7) / 8 * 8;
-    return ((long long)batch * n_ctx * u->kv_total + (long long)batch * u->kv_total * ldvc) * 2;
+    // K [B n_ctx, kv_total] + V^T [B, kv_total, ldvc] in fp16, + one byte per K element for its error carry (ICD_SPLIT_QK)
+    return ((long long)batch * n_ctx * u->kv_total + (long long)batch * u->kv_total * ldvc) * 2 + (long long)batch * n_ctx * u->kv_total;
 }
 
 extern "C" int icd_unet_forward(icd_unet* u, const icd_unet_io* io, void* stream) {

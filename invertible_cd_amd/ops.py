@@ -345,14 +345,21 @@ def attention_fused(q, k, vt, B, H, Nq, Nk, d, scale, causal=False, prescaled=Fa
     return out
 
 
-def attention_probs(q, k, B, H, Nq, Nk, d, scale, ld=None, out=None):
-    """P[b*H+h, n, :Nk] = softmax(scale * q.k) as fp16 [B*H, Nq, ld] in one pass (no fp32 score tensor); pad columns zero."""
+def attention_probs(q, k, B, H, Nq, Nk, d, scale, ld=None, out=None, q_carry=None, k_carry=None):
+    """P[b*H+h, n, :Nk] = softmax(scale * q.k) as fp16 [B*H, Nq, ld] in one pass (no fp32 score tensor); pad columns zero.
+    q_carry / k_carry: uint8 error carries of q / k (icd_attention_probs_split: scores from hi + lo operands)."""
     _chk_rows(q, "q"); _chk_rows(k, "k")
     ld = ld or (Nk + 7) // 8 * 8
     if out is None:
         out = torch.empty((B * H, Nq, ld), device=q.device, dtype=torch.float16)
-    _lib.check(_lib.load().icd_attention_probs(_p(q), _p(k), _p(out), B, H, Nq, Nk, d, q.stride(0), k.stride(0), ld, scale, _stream()),
-               "icd_attention_probs")
+    if q_carry is None and k_carry is None:
+        _lib.check(_lib.load().icd_attention_probs(_p(q), _p(k), _p(out), B, H, Nq, Nk, d, q.stride(0), k.stride(0), ld, scale, _stream()),
+                   "icd_attention_probs")
+    else:
+        for c, t in ((q_carry, q), (k_carry, k)):
+            assert c is None or (c.dtype == torch.uint8 and c.is_cuda and c.shape == t.shape and c.stride() == t.stride())
+        _lib.check(_lib.load().icd_attention_probs_split(_p(q), _p(q_carry), _p(k), _p(k_carry), _p(out), B, H, Nq, Nk, d, q.stride(0),
+                                                         k.stride(0), ld, scale, _stream()), "icd_attention_probs_split")
     return out
 
 

@@ -325,6 +325,7 @@ class UNet2DConditionModel:
             _lib.check(self._lib.icd_unet_set_option(self._h, _lib.ICD_UNET_OPT_SPLIT_MASK, want[1]), "icd_unet_set_option(split_mask)")
             self._applied = want
             self._ws_key = None
+            self._kv = None                      # (the cached context projections carry their error byte only at the split levels)
 
     def set_option(self, name, value):
         """Per-handle execution option (icd_unet_set_option): 'xattn_fusion' 0 / 1 / 2, 'ln_inline_stats' 0 / 1, 'xattn_tile' 0 / 2 / 4,
@@ -338,6 +339,7 @@ class UNet2DConditionModel:
         if name in ("residual", "split_mask"):
             self.precision = None                # an explicit setting switches the policy off
             self._applied = None
+            self._kv = None
             self._ws_pool.clear()
             self._ws_key = None                  # the arena holds the twins / carries of the residual stream: size it again
         return self

@@ -914,6 +914,31 @@ def test_attention_probs_one_pass(B, H, Nq, Nk, d):
     assert float((P.float() - P2.float()).abs().max()) < 2e-3
 
 
+@pytest.mark.parametrize("B,H,Nq,Nk,d", [(2, 8, 1024, 1024, 40), (2, 4, 256, 77, 64), (1, 8, 300, 256, 80), (2, 8, 64, 64, 160)])
+def test_attention_probs_from_split_operands(B, H, Nq, Nk, d):
+    """icd_attention_probs_split (UNet split bit ICD_SPLIT_QK, layers whose probabilities a controller keeps): q and k with the error
+    carry of their fp16 rounding; scores = qh.kh + 2^-14 (ql.kh + qh.kl).  Against the fp64 softmax of the values q and k hold (hi +
+    carry): the split maps sit at the fp16 rounding of P itself, the fp16-operand maps visibly above it (sharp rows: the score error is
+    the map's relative error)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(170)
+    q32, k32 = torch.randn(B * Nq, H * d, generator=g) * 2.5, torch.randn(B * Nk, H * d, generator=g) * 2.5
+    qh, qc = ops.carry_encode(q32)
+    kh, kc = ops.carry_encode(k32)
+    scale = d ** -0.5
+    P = ops.attention_probs(qh.cuda(), kh.cuda(), B, H, Nq, Nk, d, scale, q_carry=qc.cuda(), k_carry=kc.cuda())
+    P0 = ops.attention_probs(qh.cuda(), kh.cuda(), B, H, Nq, Nk, d, scale)
+    qq = ops.carry_decode(qh, qc).double().reshape(B, Nq, H, d).permute(0, 2, 1, 3)
+    kk = ops.carry_decode(kh, kc).double().reshape(B, Nk, H, d).permute(0, 2, 1, 3)
+    ref = torch.softmax(qq @ kk.transpose(-1, -2) * scale, -1).reshape(B * H, Nq, Nk)
+    e_s, e_p = rel_l2(P[:, :, :Nk], ref), rel_l2(P0[:, :, :Nk], ref)
+    print(f"[probs split B={B} H={H} {Nq}x{Nk} d={d}] split {e_s:.3e}, fp16 operands {e_p:.3e}")
+    assert e_s < 2.6e-4 and e_s < 0.6 * e_p
+    # one-sided carries (cross-attention whose K comes without one) are accepted
+    P1 = ops.attention_probs(qh.cuda(), kh.cuda(), B, H, Nq, Nk, d, scale, q_carry=qc.cuda())
+    assert rel_l2(P1[:, :, :Nk], ref) < e_p
+
+
 def test_flash_attention_ring_is_bit_identical_to_a_fully_fenced_build():
     """The flash kernels hand tiles over with a counted s_waitcnt vmcnt(N) + a bare s_barrier (attention.hip wait_landed); a miscounted
     ring would read LDS rows that have not landed.  tools/attn_ring_check.py builds attention.hip again with a full fence at every tile

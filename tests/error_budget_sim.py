@@ -309,8 +309,11 @@ def loops():
     from oracle import sched_ref as S
     ac = S.alphas_cumprod()
     alpha, sigma = np.sqrt(ac), np.sqrt(1 - ac)
-    package = dict(exact_reads=("sr_gn", "sr_skip", "sr_sc", "sr_po"), misc_carry=True, c1_carry=True, temb_f32_out=True)
-    variants = [("product (round 4)", {}), ("GN reads carry", dict(exact_reads=("sr_gn", "sr_skip"))), ("round-5 package", package)]
+    split = dict(exact_reads=("sr_gn", "sr_skip", "sr_sc", "sr_po", "sr_down"), misc_carry=True, c1_carry=True)
+    accurate = dict(split, exact_reads=split["exact_reads"] + ("sr_conv",))
+    no_temb = [c for c in ALL if c != "temb"]
+    variants = [("carry only (round 4)", ALL, {}), ("GroupNorm reads the carry", ALL, dict(exact_reads=("sr_gn", "sr_skip"))),
+                ("split level (mask default)", no_temb, split), ("accurate level (every bit)", no_temb, accurate)]
     for which, pairs, seed, xl in (("sd15", list(zip([19, 259, 519, 779], [259, 519, 779, 999])), 12, False),
                                    ("sdxl", list(zip([19, 339, 699], [339, 699, 999])), 21, True)):
         sd, o, lat, _, ctx, _, added = case(which, False, seed=seed)
@@ -328,9 +331,9 @@ def loops():
                     x = x.half().float()
             return x
         ref = loop(lambda x, t: unet_ref.unet_forward(sd, o, x, t, ctx, timestep_cond=wemb, added_cond=added))
-        for name, ex in variants:
-            got = loop(lambda x, t: Sim(sd, o, ALL, extra=ex).forward(x, t, ctx, wemb, added))
-            print(f"[{which} forward loop, {len(pairs)} steps] {name:20s} rel-L2 = {rel_l2(got, ref):.3e}")
+        for name, on, ex in variants:
+            got = loop(lambda x, t: Sim(sd, o, on, extra=ex).forward(x, t, ctx, wemb, added))
+            print(f"[{which} forward loop, {len(pairs)} steps] {name:28s} rel-L2 = {rel_l2(got, ref):.3e}")
 
 
 if __name__ == "__main__":

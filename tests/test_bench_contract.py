@@ -1,4 +1,4 @@
-"""The bench line the driver parses, checked on the committed evidence (profiles/r04_bench_default.json is the stdout of
+"""The bench line the driver parses, checked on the committed evidence (profiles/r05_bench_default.json is the stdout of
 `python bench.py --steps 20 --warmup 5` on an MI355X): every key of the contract is there, with the types and relations the contract states."""
 import json
 import os
@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _line():
-    lines = [l for l in open(os.path.join(ROOT, "profiles", "r04_bench_default.json")).read().splitlines() if l.strip()]
+    lines = [l for l in open(os.path.join(ROOT, "profiles", "r05_bench_default.json")).read().splitlines() if l.strip()]
     assert len(lines) == 1, "bench.py prints exactly ONE line on stdout"
     return json.loads(lines[0])
 
@@ -40,6 +40,16 @@ def test_roofline_and_cpu_baseline_objects():
     assert 5 <= c["seconds"] <= 120                          # a bounded sample
     s = d["sdxl"]                                             # BASELINE config 4's per-GPU share rides in the same line
     assert s["value"] > 0 and s["roofline"]["kernel"] == "gemm_dense" and "workload" in s["config"]
+    # round 5: both traffic figures are measured in the run itself, and the edit legs carry a roofline object too
+    assert r["traffic_source"].startswith("live") and s["roofline"]["traffic_source"].startswith("live")
+    assert r["traffic_kernels_sha"] == r["kernels_sha"] and s["roofline"]["traffic_kernels_sha"] == s["roofline"]["kernels_sha"]
+    for key in ("edit", "sdxl_edit"):
+        e = d[key]["roofline"]
+        assert e["bound"] == "mfma" and 0 < e["frac"] < 1 and abs(e["frac"] - e["achieved"] / e["peak"]) < 1e-3
+        assert abs(e["achieved"] - e["algorithmic_per_launch"] / (e["avg_launch_us"] * 1e-6) / 1e12) / e["achieved"] < 2e-2
+    # algorithmic flops (the operator as the reference computes it) and the flops issued to the matrix cores are both on the line where
+    # they differ: the phase-form upsampler issues 4/9 of the 3 x 3 conv on the upsampled map
+    assert r["kernel"] == "gemm_conv" and 0 < r["executed_frac"] < r["frac"]
 
 
 def test_every_baseline_config_rides_on_the_default_line():
@@ -55,7 +65,13 @@ def test_every_baseline_config_rides_on_the_default_line():
     assert d["edit"]["attention_store_tensors_per_pass"] > 0                 # the controller really was in the loop
     # round 4: `value` is the pass with `in_flight_batches` independent batches in flight and no events; the sequential pass with
     # events around the dominant family (the roofline leg) rides beside it, and so does the plain-fp16-stream rate
-    assert d["config"]["in_flight_batches"] >= 1 and "residual_stream" in d["config"]
+    assert d["config"]["in_flight_batches"] >= 1
+    # round 5: the precision policy a user gets - plain generation on the error carry, the edit legs at the accurate level
+    assert d["config"]["precision"] == {"policy": "auto", "residual_stream": "fp16 + bf8 error carry"} == d["sdxl"]["config"]["precision"]
+    for key in ("edit", "sdxl_edit"):
+        pr = d[key]["config"]["precision"]
+        assert pr["policy"] == "auto" and pr["residual_stream"].endswith("split consumers") and pr["split_mask"] == 511, key
+    assert 0 < d["accurate_level"]["value"] < d["value"] and d["value_one_batch_at_a_time"] == d["one_batch_at_a_time"]["value"]
     if d["config"]["in_flight_batches"] > 1:
         seq = d["one_batch_at_a_time"]
         assert 0 < seq["value"] <= d["value"] * 1.02 and abs(seq["value"] - d["config"]["global_batch"] / (seq["ms_per_step"] * 1e-3)) / seq["value"] < 1e-3

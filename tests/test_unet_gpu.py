@@ -169,6 +169,8 @@ def test_unet_full_sd15_b8_64x64_on_the_benchmarked_tiles_and_layernorm_statisti
     seen = {}
 
     def check(name, plans):
+        if name == "accurate":                    # (the split-operand launches of the accurate level: checked against the oracle only)
+            return
         dense = [p for p in plans if p["family"] == "gemm_dense"]
         conv = [p for p in plans if p["family"] == "gemm_conv"]
         big_flops = sum(2.0 * p["M"] * p["N"] * p["K"] for p in dense + conv if p["big"])
@@ -185,7 +187,10 @@ def test_unet_full_sd15_b8_64x64_on_the_benchmarked_tiles_and_layernorm_statisti
         else:
             assert len(inline) == 0
 
-    r = _run_case(uc.SD15, B=8, H=64, W=64, t=779, seed=8, tol=1e-3, variants={"ln_pass": {"ln_inline_stats": 0}}, check_plans=check)
+    r = _run_case(uc.SD15, B=8, H=64, W=64, t=779, seed=8, tol=1e-3,
+                  variants={"ln_pass": {"ln_inline_stats": 0}, "accurate": {"ln_inline_stats": 1, "residual": 3, "split_mask": 511}}, check_plans=check)
+    print(f"[sd15 B=8 64x64] fast level {r[None][0]:.3e} -> accurate level {r['accurate'][0]:.3e}")
+    assert r["accurate"][0] < 0.6e-3 and r["accurate"][0] < 0.7 * r[None][0]     # what the inversion / edit loops run, on the benchmarked tiles
     d = rel_l2(r["ln_pass"][1], r[None][1])
     print(f"[LN statistics in the consuming GEMM vs a pass over the stream] vs oracle {r[None][0]:.3e} / {r['ln_pass'][0]:.3e}; "
           f"the two differ by {d:.3e}")
@@ -313,3 +318,44 @@ def test_executor_replicas_run_two_batches_in_flight_with_sequential_results():
     torch.cuda.synchronize()
     for g, w in zip(got, want):
         assert torch.equal(g, w)
+
+
+def test_precision_policy_selects_the_level_the_samplers_ask_for():
+    """UNet2DConditionModel.precision = "auto" (default): the error carry for a plain evaluation, the accurate level (residual 3, every
+    ICD_SPLIT_* bit) inside `with unet.editing():` and whenever an attention controller is attached; each level keeps its own arena; an
+    explicit set_option('residual') switches the policy off; a replica inherits it; the forced levels do what they say."""
+    from invertible_cd_amd import _lib, p2p
+    synthetic, unet, uc, _ = _mods()
+    cfg = uc.SD15.scaled((64, 128, 256, 256), cross_dim=64)
+    sd = {k: v.half().float() for k, v in synthetic.synthetic_state_dict(cfg, seed=1).items()}
+    inp = synthetic.synthetic_inputs(cfg, 2, 16, 16, seed=1)
+    m = unet.UNet2DConditionModel(cfg, sd)
+    x, kw = inp["latents"].half().cuda(), dict(encoder_hidden_states=inp["context"].half().cuda())
+    fast, acc = (_lib.ICD_RESIDUAL_CARRY, _lib.ICD_SPLIT_DEFAULT), (_lib.ICD_RESIDUAL_SPLIT, _lib.ICD_SPLIT_ALL)
+    assert m.precision == "auto"
+    e_fast = m(x, 500, **kw).sample
+    assert m._applied == fast
+    with m.editing():
+        e_acc = m(x, 500, **kw).sample
+        assert m._applied == acc
+    assert not torch.equal(e_fast, e_acc) and rel_l2(e_fast, e_acc) < 2e-3
+    assert torch.equal(m(x, 500, **kw).sample, e_fast) and m._applied == fast and len(m._ws_pool) == 2      # back, arenas of both levels kept
+    class _M:                                                  # register_attention_control wants a model with .unet
+        pass
+    holder = _M()
+    holder.unet = m
+    store = p2p.AttentionStore()
+    p2p.register_attention_control(holder, store)
+    m(x, 500, **kw)
+    assert m._applied == acc and store.cur_step == 1 and len(store.attention_store["down_cross"]) > 0      # a controller is an editing pipeline
+    p2p.register_attention_control(holder, None)
+    r = m.replica()
+    assert r.precision == "auto" and torch.equal(r(x, 500, **kw).sample, e_fast)
+    assert torch.equal(m.set_precision("accurate")(x, 500, **kw).sample, e_acc)
+    m.set_option("residual", 0)
+    assert m.precision is None
+    e16 = m(x, 500, **kw).sample
+    with m.editing():
+        assert torch.equal(m(x, 500, **kw).sample, e16)                                                    # the policy is off
+    with pytest.raises(ValueError):
+        m.set_precision("exact")

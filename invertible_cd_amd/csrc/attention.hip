@@ -577,7 +577,9 @@ __global__ __launch_bounds__(256, OCC) void attn_fused_kernel(AttnK p) {
 // arithmetic intensity ~ 77 flop/B): what matters is bytes in flight, so each wave prefetches the
 // next tile's Q fragments before it computes the current one.
 // ---------------------------------------------------------------------------------------------------------------
-template <int KS, int DT>
+// STL (round 5): live 16-key slots of the 96, ceil(keys / 16) - 5 for the 77 CLIP tokens: the dead slot's exponentials (8 of 48 per lane and
+// tile), conversions and P.V MFMAs (DT of 6 DT) are dropped at compile time.
+template <int KS, int DT, int STL = 6>
 __global__ __launch_bounds__(256, 2) void attn_cross_kernel(AttnK p, int tiles_per_wave) {
     constexpr int KT = 3;                             // 32-key tiles (96 key slots)
     constexpr int ST = 6;                             // 16-key steps of the PV product
@@ -611,7 +613,7 @@ __global__ __launch_bounds__(256, 2) void attn_cross_kernel(AttnK p, int tiles_p
     // V^T fragments (A operand of O^T = V^T.P^T): lane row = head-dim 32i + lr, keys 16st + 8lh .. +7
     f16x8 vf[ST][DT];
 #pragma unroll
-    for (int st = 0; st < ST; ++st)
+    for (int st = 0; st < STL; ++st)
 #pragma unroll
         for (int i = 0; i < DT; ++i) {
             const int row = i * 32 + lr, key = st * 16 + lh * 8;
@@ -660,7 +662,8 @@ __global__ __launch_bounds__(256, 2) void attn_cross_kernel(AttnK p, int tiles_p
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[kt][e]);
+            for (int e = 0; e < 16; ++e)
+                if (kt * 2 + (e >> 3) < STL) mx = fmaxf(mx, s[kt][e]);
         {
             const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
             mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
@@ -672,13 +675,14 @@ __global__ __launch_bounds__(256, 2) void attn_cross_kernel(AttnK p, int tiles_p
         for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
+                if (kt * 2 + (e >> 3) >= STL) continue;           // a slot no key lives in (compile time)
                 const float pv = __builtin_amdgcn_exp2f(fmaf(s[kt][e], c, nmc));
                 rs += pv;
                 pf[kt * 2 + (e >> 3)][e & 7] = (half_t)pv;
             }
         f32x16 o[DT];
 #pragma unroll
-        for (int st = 0; st < ST; ++st)
+        for (int st = 0; st < STL; ++st)
 #pragma unroll
             for (int i = 0; i < DT; ++i)
                 o[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[st][i], pf[st], st == 0 ? zero16 : o[i], 0, 0, 0);
@@ -933,7 +937,8 @@ int launch_attn_cross(AttnK k, hipStream_t st) {
     int tpw = 8;
     while (tpw > 1 && (long long)((k.Nq + 128 * tpw - 1) / (128 * tpw)) * k.B * k.H < 1024) tpw >>= 1;
     const int nchunk = (k.Nq + 128 * tpw - 1) / (128 * tpw);
-    hipLaunchKernelGGL((attn_cross_kernel<KS, DT>), dim3(nchunk * k.B * k.H), dim3(256), 0, st, k, tpw);
+    if (k.Nk <= 80) hipLaunchKernelGGL((attn_cross_kernel<KS, DT, 5>), dim3(nchunk * k.B * k.H), dim3(256), 0, st, k, tpw);
+    else hipLaunchKernelGGL((attn_cross_kernel<KS, DT, 6>), dim3(nchunk * k.B * k.H), dim3(256), 0, st, k, tpw);
     ICD_CHECK_LAUNCH("icd_attention_fused(cross)");
     return ICD_OK;
 }

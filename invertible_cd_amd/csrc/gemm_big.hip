@@ -32,10 +32,14 @@ constexpr int XA_K_OFF = 0, XA_K_LD = 520, XA_V_OFF = 96 * XA_K_LD, XA_V_LD = 20
 constexpr int XA_PATCH_OFF = XA_TABLE_OFF + 5 * 256 * 8, XA_SMEM = XA_PATCH_OFF + 8 * 32 * 72 * 2;     // 49920 + 53248 + 10240 + 36864
 static_assert(XA_SMEM <= 160 * 1024, "fused cross-attention: LDS budget");
 
-template <int TM>
+// STL (round 5): live 16-key slots, ceil(keys / 16) - 5 for the 77 CLIP tokens.  The sixth slot (keys 80..95) is masked for every lane, so
+// its 8 exponentials per lane and query tile (of 48), its conversions and its two P.V MFMAs (of 12) are dropped at compile time; as a
+// wave-uniform run-time branch the same skip made hipcc spill 54 registers (round 2).
+template <int TM, int STL = 6>
 __device__ __forceinline__ void xattn_epilogue_big(const GemmK& p, f32x16 (&acc)[TM][2], unsigned char* smem, int wv, int wm, int wn,
                                                    int l, int m0, int n0, const float* ln_lds) {
     constexpr int KT = 3, KS = 4, ST = 6, DT = 2;
+    static_assert(STL == 5 || STL == 6, "live key slots");
     const int lr = l & 31, lh = l >> 5, tid = threadIdx.x;
     const int key_lim = p.x_nk - 8 * lh;                   // key slot constant c of this lane is masked when c >= key_lim
     const int b = m0 / p.rps;                              // the 256 rows of a block lie inside one sample
@@ -133,6 +137,7 @@ __device__ __forceinline__ void xattn_epilogue_big(const GemmK& p, f32x16 (&acc)
                 for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
+                        if (kt * 2 + (e >> 3) >= STL) continue;          // a slot no key lives in (compile time)
                         // key = kt*32 + 16*(e>>3) + 8*lh + (e&7) >= x_nk, written as (compile-time constant) >= (one per-lane limit)
                         if (kt * 32 + 16 * (e >> 3) + (e & 7) >= kl) sc[kt][e] = -INFINITY;
                         mx = fmaxf(mx, sc[kt][e]);
@@ -146,6 +151,7 @@ __device__ __forceinline__ void xattn_epilogue_big(const GemmK& p, f32x16 (&acc)
                 for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
+                        if (kt * 2 + (e >> 3) >= STL) continue;
                         const float pv = __builtin_amdgcn_exp2f(sc[kt][e] - mx);
                         rs += pv;
                         pf[ii][kt * 2 + (e >> 3)][e & 7] = (half_t)pv;
@@ -161,7 +167,7 @@ __device__ __forceinline__ void xattn_epilogue_big(const GemmK& p, f32x16 (&acc)
             const int mrow = m0 + (wm * TM + i0 + ii) * 32;
             f32x16 o[DT];
 #pragma unroll
-            for (int st = 0; st < ST; ++st)
+            for (int st = 0; st < STL; ++st)
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt)
                 {
@@ -537,7 +543,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_big_kernel(GemmK p) {
     if constexpr (XATTN) {
         if (!stat_on) __syncthreads();           // (the statistics block above already synchronised) every wave is done with the stages
         if (tl && tid == 0) tl[2] = __builtin_amdgcn_s_memrealtime();
-        xattn_epilogue_big<TM>(p, acc, smem, wv, wm, wn, l, m0, n0, ln_lds);
+        // (XATTN kernels know no error carry: their CARRY flag selects the five-slot epilogue - one instantiation each, because both
+        //  epilogues in ONE kernel made hipcc spill 83 registers)
+        xattn_epilogue_big<TM, CARRY ? 5 : 6>(p, acc, smem, wv, wm, wn, l, m0, n0, ln_lds);
     } else {
         wave_epilogue<TM, TN, true, CARRY>(p, acc, smem, wv, wm, wn, l, m0, n0, split, tl, ln_lds);
     }
@@ -583,7 +591,7 @@ int launch_big(const GemmK& k, int cfg, hipStream_t st) {
     }
 #undef ICD_BIG
     if (cfg == 100)   // query projection + cross-attention in one launch (icd_gemm_desc.xattn_*): 256 x 256 = 256 queries x 4 heads
-        return launch_one<0, 2, 4, 4, 2, true>(k, st);
+        return k.x_nk <= 80 ? launch_one<0, 2, 4, 4, 2, true, true>(k, st) : launch_one<0, 2, 4, 4, 2, true, false>(k, st);   // 5 / 6 live key slots
     icd_set_error("icd_gemm: unknown big-tile configuration %d", cfg);
     return ICD_ERR_INVALID_ARG;
 }

@@ -213,6 +213,10 @@ def pack_vae_state_dict(cfg: VAEConfig, sd, device="cuda"):
         if i < len(ch) - 1:
             k = f"decoder.up_blocks.{i}.upsamplers.0.conv."
             P[k + "weight"], P[k + "bias"] = half(ops.pack_conv_weight(f32(k + "weight"))), full(f32(k + "bias"))
+            # the phase form of Upsample2D (four 2 x 2 convs on the input grid with tap-summed weights: 4/9 of the flops, unet.py)
+            from .unet import upsample_phase_weights
+            for ph, wp in enumerate(upsample_phase_weights(f32(k + "weight"))):
+                P[k + f"phase.{ph}"] = half(wp.reshape(wp.shape[0], -1).contiguous())
     P["decoder.conv_norm_out.weight"], P["decoder.conv_norm_out.bias"] = full(f32("decoder.conv_norm_out.weight")), full(f32("decoder.conv_norm_out.bias"))
     wo, bo = f32("decoder.conv_out.weight"), f32("decoder.conv_out.bias")
     w4 = torch.zeros(4, wo.shape[1], 3, 3); w4[:cfg.out_channels] = wo
@@ -236,6 +240,7 @@ class AutoencoderKL:
         self._ws = None                        # split3 weights of the fp32-fidelity path, packed on first use
         self.max_chunk = max_chunk            # samples per pass (bounds the 512x512x128-channel activations and the scores)
         self.fused_attention = fused_attention    # None: fused flash kernel when the head dim allows it (<= 160)
+        self.upsample_phases = True               # fp16 decoder: Upsample2D as four 2 x 2 convs on the input grid (4/9 of its flops); False: 3 x 3 form
 
     # -- diffusers plumbing the reference uses
     def to(self, *args, **kw):
@@ -458,7 +463,13 @@ class AutoencoderKL:
                 x = self._resnet(f"decoder.up_blocks.{i}.resnets.{j}.", x, B, H, W)
             if i < nb - 1:
                 k = f"decoder.up_blocks.{i}.upsamplers.0.conv."
-                x = ops.conv3x3(x, B, H, W, w[k + "weight"], w[k + "bias"], upsample=True)
+                if self.upsample_phases and W >= 2:
+                    up = torch.empty((B * 4 * H * W, x.shape[-1]), device=x.device, dtype=torch.float16)
+                    for ph in range(4):
+                        ops.conv3x3(x, B, H, W, w[k + f"phase.{ph}"], w[k + "bias"], phase=ph, out=up)
+                    x = up
+                else:
+                    x = ops.conv3x3(x, B, H, W, w[k + "weight"], w[k + "bias"], upsample=True)
                 H, W = 2 * H, 2 * W
         x = ops.groupnorm(x, B, H * W, w["decoder.conv_norm_out.weight"], w["decoder.conv_norm_out.bias"], EPS, True,
                           groups=cfg.norm_num_groups)

@@ -55,7 +55,7 @@ def test_gemm_big_tiles_keep_their_register_budget():
     ks = _descriptors("gemm_big.hip")
     asm = _descriptors("gemm_big.hip", main_loops=True)
     tiles = {n: v for n, v in ks.items() if "gemm_big_kernel" in n}
-    assert len(tiles) == 17                                     # 4 tiles x {dense, conv} x {plain, error carry} + the fused cross-attention host
+    assert len(tiles) == 18                                     # 4 tiles x {dense, conv} x {plain, error carry} + the fused cross-attention host (6 / 5 live key slots)
     for n, v in tiles.items():
         # whatever the epilogue variants spill, the MFMA loop of every tile touches no scratch (round 3's 256 x 320 conv tile reloaded two
         # loop invariants per k-tile pair; the buffer-descriptor loader of round 4 keeps two registers per chunk less)
@@ -87,6 +87,6 @@ def test_flash_attention_kernels_do_not_spill():
     hot = [v for n, v in flash.items() if re.search(r"ILi3ELi2ELi2ELi2ELi2ELi1ELb0E|ILi4ELi2ELi1ELi2ELi2ELi2ELb0E|ILi5ELi3ELi1ELi2ELi2ELi2ELb0E", n)]
     assert len(hot) == 3 and all(v["sgpr_spill_count"] == 0 for v in hot)       # d = 40 (QT 2, 16-row P.V tiles) / 64 / 80 with the MFMA-carried offset
     cross = {n: v for n, v in ks.items() if "attn_cross_kernel" in n}
-    assert len(cross) == 3 and all(v["sgpr_spill_count"] == 0 and v["vgpr_spill_count"] == 0 for v in cross.values()), cross
+    assert len(cross) == 6 and all(v["sgpr_spill_count"] == 0 and v["vgpr_spill_count"] == 0 for v in cross.values()), cross
     pv16 = [v for n, v in flash.items() if "ILi3ELi2ELi2ELi2ELi2ELi1ELb0ELi3E" in n]
     assert len(pv16) == 1 and pv16[0]["vgpr_count"] <= 224        # two blocks per CU need <= 256; 218 today

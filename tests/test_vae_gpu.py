@@ -37,6 +37,12 @@ def test_decode_matches_oracle(widths, fused):
     e = rel_l2(got, ref)
     print(f"[vae decode {widths} fused={fused}] rel-L2 = {e:.3e}")
     assert e < 3e-3
+    # round 5: the decoder's three Upsample2D convs run in phase form (four 2 x 2 convs on the input grid); the 3 x 3 form stays selectable
+    m.upsample_phases = False
+    old = m.decode(z.cuda())["sample"].float().cpu()
+    e_old = rel_l2(old, ref)
+    print(f"[vae decode {widths} fused={fused}] 3x3 upsampler form rel-L2 = {e_old:.3e}, distance between the forms {rel_l2(got, old):.3e}")
+    assert e_old < 3e-3 and abs(e - e_old) < 3e-4 and not torch.equal(got, old)
 
 
 @pytest.mark.parametrize("widths,fused", [((32, 64, 128, 128), True), ((32, 64, 128, 128), False)])

@@ -25,7 +25,8 @@ ICD_UNET_OPT_SPLIT_MASK = 6
 ICD_UNET_OPT_UPSAMPLE_PHASES = 7
 ICD_SPLIT_GN, ICD_SPLIT_CONV1, ICD_SPLIT_SHORTCUT, ICD_SPLIT_PROJ_OUT, ICD_SPLIT_DOWN, ICD_SPLIT_SAMPLER_OUT, ICD_SPLIT_UP, ICD_SPLIT_TEMB = 1, 2, 4, 8, 16, 32, 64, 128
 ICD_SPLIT_QK = 256
-ICD_SPLIT_DEFAULT, ICD_SPLIT_ALL = 447, 511
+ICD_SPLIT_UP_ALL = 512
+ICD_SPLIT_DEFAULT, ICD_SPLIT_ACCURATE, ICD_SPLIT_ALL = 447, 1023, 1023
 ICD_RESIDUAL_FP16, ICD_RESIDUAL_F32, ICD_RESIDUAL_CARRY, ICD_RESIDUAL_SPLIT = 0, 1, 2, 3
 ICD_ATTN_CAUSAL = 1
 ICD_ATTN_Q_PRESCALED = 2

@@ -775,7 +775,8 @@ struct Exec {
                 const std::string upn = "up_blocks." + std::to_string(i) + ".upsamplers.0.conv";
                 Act up{alloc<half_t>((long long)B * (Hh * 2) * (Ww * 2) * Cout), Cout};
                 if (split(ICD_SPLIT_SAMPLER_OUT)) up.aux = alloc_aux((long long)B * (Hh * 2) * (Ww * 2) * Cout);
-                const bool sup = split(ICD_SPLIT_UP);
+                // (the last upsampler - at the output resolution, damped by nothing downstream - or every one: ICD_SPLIT_UP_ALL)
+                const bool sup = split(ICD_SPLIT_UP) && (i == L - 2 || split(ICD_SPLIT_UP_ALL));
                 const long long hin = (long long)B * Hh * Ww;
                 half_t* lo = nullptr;                // the upsampling conv over [h | lo]
                 if (sup && u->up_phases) {           // ... in the phase form over [h | lo | h] against [W_hi | W_hi | W_lo] (the tap sums are not fp16 numbers)

@@ -284,14 +284,14 @@ class UNet2DConditionModel:
     # Numerical precision of the residual stream and of its consumers (icd_unet options residual / split_mask):
     #   "fast"      error carry (mode 2): one evaluation 0.70 - 0.85e-3 from an fp32 evaluation - enough for the REVERSE loops, which
     #               contract the per-step error (4-step generation: latents 3e-4, every attention-store tensor < 1e-3);
-    #   "accurate"  carry + split consumers incl. the upsampler convs (mode 3, every ICD_SPLIT_* bit): 0.40 - 0.44e-3, +10 % / +5 % time
+    #   "accurate"  carry + split consumers incl. the upsampler convs (mode 3, ICD_SPLIT_ACCURATE = every bit): 0.39 - 0.41e-3, +11 % / +5 % time
     #               (SD1.5 / SDXL) - what the FORWARD (inversion) loops, which amplify the per-step error by ~2.4 x over 3 - 4 steps, and
     #               the edit passes behind them need to stay inside 1e-3;
     #   "auto"      (default) accurate inside EDITING pipelines - the evaluations a sampler wraps in `with unet.editing():` (inversion
     #               loops, reverse passes under dynamic guidance: the reference uses both for editing only) and every evaluation with an
     #               attention controller attached (edit / store passes) - fast for plain text-to-image generation;
     #   None        leave the options alone (set_option('residual' | 'split_mask') switches to this).
-    PRECISION = {"fast": (_lib.ICD_RESIDUAL_CARRY, _lib.ICD_SPLIT_DEFAULT), "accurate": (_lib.ICD_RESIDUAL_SPLIT, _lib.ICD_SPLIT_ALL),
+    PRECISION = {"fast": (_lib.ICD_RESIDUAL_CARRY, _lib.ICD_SPLIT_DEFAULT), "accurate": (_lib.ICD_RESIDUAL_SPLIT, _lib.ICD_SPLIT_ACCURATE),
                  "split": (_lib.ICD_RESIDUAL_SPLIT, _lib.ICD_SPLIT_DEFAULT)}
 
     def set_precision(self, level):

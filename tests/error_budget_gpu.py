@@ -16,12 +16,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-BITS = [("gn", 1), ("conv1", 2), ("shortcut", 4), ("proj_out", 8), ("down", 16), ("sampler_out", 32), ("up", 64), ("temb", 128)]
+BITS = [("gn", 1), ("conv1", 2), ("shortcut", 4), ("proj_out", 8), ("down", 16), ("sampler_out", 32), ("up", 64), ("temb", 128), ("qk", 256)]
 DEFAULT = 447
 
 
 def variants():
-    v = [("carry only (mode 2)", 2, 0), ("default (mode 3)", 3, DEFAULT), ("everything", 3, 511)]
+    v = [("carry only (mode 2)", 2, 0), ("default (mode 3)", 3, DEFAULT), ("everything", 3, 1023)]
     for n, b in BITS:
         m = b | (1 if b == 4 else 0)                      # the split shortcut needs the GroupNorm that writes lo
         v.append((f"carry + {n} alone", 3, m))

@@ -210,6 +210,6 @@ def test_full_sdxl_forward_128x128_b2_on_the_benchmarked_tiles():
     # ... and the accurate level of the precision policy (residual = 3, every ICD_SPLIT_* bit: what the inversion / edit loops run) on the
     # same tiles: < 0.6e-3 (last variant: an explicit residual option switches the policy of the handle off)
     r = _run_case(SDXL, B=2, H=128, W=128, t=699, seed=9, tol=1e-3,
-                  variants={"xattn_everywhere": {"xattn_fusion": 1}, "accurate": {"xattn_fusion": 2, "residual": 3, "split_mask": 511}}, check_plans=check)
+                  variants={"xattn_everywhere": {"xattn_fusion": 1}, "accurate": {"xattn_fusion": 2, "residual": 3, "split_mask": 1023}}, check_plans=check)
     print(f"[sdxl B=2 128x128] fast level {r[None][0]:.3e} -> accurate level {r['accurate'][0]:.3e}")
     assert r["accurate"][0] < 0.6e-3 and r["accurate"][0] < 0.7 * r[None][0]

@@ -140,7 +140,7 @@ def test_carried_residual_stream_meets_the_north_star_tolerance(which):
     else:
         cfg, B, H = uc.SD15, 2, 32
     r = _run_case(cfg, B=B, H=H, W=H, t=779, seed=31, tol=1e-3,
-                  variants={"fp16": {"residual": 0}, "twin": {"residual": 1}, "split": {"residual": 3}, "accurate": {"residual": 3, "split_mask": 511},
+                  variants={"fp16": {"residual": 0}, "twin": {"residual": 1}, "split": {"residual": 3}, "accurate": {"residual": 3, "split_mask": 1023},
                             "back": {"residual": 2, "split_mask": 447}}, variant_tol=2e-3)
     e_c, e16, e32, e_s, e_a = r[None][0], r["fp16"][0], r["twin"][0], r["split"][0], r["accurate"][0]
     print(f"[{which}] fp16 residual stream {e16:.3e} -> error carry {e_c:.3e} (fp32 twin {e32:.3e}) -> carry + split consumers {e_s:.3e} "
@@ -188,7 +188,7 @@ def test_unet_full_sd15_b8_64x64_on_the_benchmarked_tiles_and_layernorm_statisti
             assert len(inline) == 0
 
     r = _run_case(uc.SD15, B=8, H=64, W=64, t=779, seed=8, tol=1e-3,
-                  variants={"ln_pass": {"ln_inline_stats": 0}, "accurate": {"ln_inline_stats": 1, "residual": 3, "split_mask": 511}}, check_plans=check)
+                  variants={"ln_pass": {"ln_inline_stats": 0}, "accurate": {"ln_inline_stats": 1, "residual": 3, "split_mask": 1023}}, check_plans=check)
     print(f"[sd15 B=8 64x64] fast level {r[None][0]:.3e} -> accurate level {r['accurate'][0]:.3e}")
     assert r["accurate"][0] < 0.6e-3 and r["accurate"][0] < 0.7 * r[None][0]     # what the inversion / edit loops run, on the benchmarked tiles
     d = rel_l2(r["ln_pass"][1], r[None][1])
@@ -331,7 +331,7 @@ def test_precision_policy_selects_the_level_the_samplers_ask_for():
     inp = synthetic.synthetic_inputs(cfg, 2, 16, 16, seed=1)
     m = unet.UNet2DConditionModel(cfg, sd)
     x, kw = inp["latents"].half().cuda(), dict(encoder_hidden_states=inp["context"].half().cuda())
-    fast, acc = (_lib.ICD_RESIDUAL_CARRY, _lib.ICD_SPLIT_DEFAULT), (_lib.ICD_RESIDUAL_SPLIT, _lib.ICD_SPLIT_ALL)
+    fast, acc = (_lib.ICD_RESIDUAL_CARRY, _lib.ICD_SPLIT_DEFAULT), (_lib.ICD_RESIDUAL_SPLIT, _lib.ICD_SPLIT_ACCURATE)
     assert m.precision == "auto"
     e_fast = m(x, 500, **kw).sample
     assert m._applied == fast

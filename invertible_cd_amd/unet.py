@@ -41,7 +41,7 @@ def upsample_phase_weights(w):
     followed by conv3x3 (pad 1) equals, at output pixel (2y + py, 2x + px), a 2 x 2 conv over input pixels (y + py - 1 + dy, x + px - 1 + dx)
     whose weights are the sums of the 3 x 3 taps that land on the same input pixel (ky -> input row y + floor((py + ky - 1) / 2))."""
     sets = {(0, 0): (0,), (0, 1): (1, 2), (1, 0): (0, 1), (1, 1): (2,)}          # (phase, d) -> 3 x 3 tap indices
-    w = w.float()
+    w = w if w.dtype == torch.float64 else w.float()
     out = []
     for py in (0, 1):
         for px in (0, 1):

@@ -80,3 +80,39 @@ def test_bench_spawn_command(monkeypatch):
         assert False
     except SystemExit as e:
         assert "GPU(s) visible" in str(e.code)
+
+
+def test_upsample_phase_weights_reproduce_the_upsampled_conv():
+    """unet.upsample_phase_weights: nearest-2x upsampling followed by conv3x3 (pad 1) equals, at output pixel (2y + py, 2x + px), a 2 x 2
+    conv over input pixels (y + py - 1 + dy, x + px - 1 + dx) with the 3 x 3 taps that land on the same input pixel summed - the identity the
+    executor's phase-form upsampler (icd_gemm_desc.conv_ktaps) and the packer rely on.  Checked in fp64 on the CPU, odd sizes included."""
+    import torch.nn.functional as F
+    from invertible_cd_amd.unet import upsample_phase_weights
+    g = torch.Generator().manual_seed(7)
+    for (B, C, O, H, W) in ((2, 5, 3, 4, 6), (1, 8, 8, 7, 5), (1, 3, 4, 1, 2)):
+        x = torch.randn(B, C, H, W, generator=g, dtype=torch.float64)
+        w = torch.randn(O, C, 3, 3, generator=g, dtype=torch.float64)
+        ref = F.conv2d(F.interpolate(x, scale_factor=2.0, mode="nearest"), w, padding=1)
+        out = torch.zeros_like(ref)
+        xp = F.pad(x, (1, 1, 1, 1))                                  # zero border: input pixel -1 / H reads as zero, like the conv's padding
+        for ph, wp in enumerate(upsample_phase_weights(w)):
+            py, px = ph >> 1, ph & 1
+            assert wp.shape == (O, 4, C)
+            k = wp.double().reshape(O, 2, 2, C).permute(0, 3, 1, 2)  # taps (dy, dx) row-major -> [O, C, 2, 2]
+            # output (y, x) of the phase reads padded pixels (y + py + dy, x + px + dx): a valid 2 x 2 conv of the padded map, shifted by (py, px)
+            full = F.conv2d(xp, k)                                   # [B, O, H + 1, W + 1]
+            out[:, :, py::2, px::2] = full[:, :, py:py + H, px:px + W]
+        assert torch.allclose(out, ref, rtol=1e-12, atol=1e-12)
+
+
+def test_error_carry_encoding_saturates():
+    """ops.carry_encode / carry_decode (the host mirror of gemm_common.h carry_of8 / carry_add8): value = fp16 + 2^-14 * bf8(e5m2); beyond
+    abs(v) = 2^13 the carry saturates at the largest finite e5m2 value instead of overflowing, and never makes the value worse than fp16."""
+    from invertible_cd_amd import ops
+    v = torch.cat([torch.randn(4096) * 3, torch.tensor([8191.7, -20000.3, 60000.9, 65000.0, 1e-7, 0.0])])
+    hi, c = ops.carry_encode(v)
+    full = ops.carry_decode(hi, c)
+    assert torch.isfinite(full).all()
+    assert ((full - v).abs() <= (hi.float() - v).abs() + 1e-12).all()
+    small = v.abs() < 8192
+    assert ((full - v).abs()[small] <= 0.126 * (hi.float() - v).abs()[small] + 1e-9).all()      # 2 mantissa bits of the error: <= 1/8 of it left

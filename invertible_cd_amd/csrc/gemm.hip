@@ -914,7 +914,7 @@ static int gemm_run(const icd_gemm_desc* d, void* stream, icd_gemm_plan_info* in
                 // 65.1 vs 65.7 us at 8192 x 2560 x 1280), dearer than the 8 us statistics launch on the 40 n-tiles of a GEGLU
                 // projection (243.9 vs 229.5 + 8)
                 const bool inline_ok = d->mode == 0 && k.ksplit == 1 && !trans && !(d->flags & (ICD_GEMM_OUT_F32 | ICD_GEMM_RESID_F32)) &&
-                                       !(d->flags & ICD_GEMM_TUNE_NO_LN_INLINE) && k.nbn <= 12;
+                                       !(d->flags & ICD_GEMM_TUNE_NO_LN_INLINE) && k.nbn <= 12 && !d->out_carry && !d->resid_carry;
                 if (inline_ok) k.ln_stats_w = const_cast<float*>(d->ln_stats);
                 else { const int rc0 = ln_stats_launch(); if (rc0 != ICD_OK) return rc0; }
             }

@@ -200,7 +200,11 @@ constexpr bool CONV_CHUNK_MAJOR = ICD_CONV_CHUNK_MAJOR != 0;       // K order of
 
 constexpr int enc_vmcnt(int n) { return ((n >> 4) << 14) | 0x0F70 | (n & 15); }
 
-template <int MODE, int WM, int WN, int TM, int TN, bool XATTN = false, bool CARRY = false>
+// LNS (round 5): the instantiation that may compute LayerNorm statistics in its main loop (p.ln_stats_w).  As a run-time flag in ONE kernel
+// the statistics code put a branch and a join into every k sub-step of every dense launch, and at each join the waitcnt pass drained ALL
+// outstanding ds_reads (s_waitcnt lgkmcnt(0)) - including the fragments just requested for the NEXT sub-step, i.e. the register double
+// buffering was dead in every dense GEMM (8 full drains per k-tile pair against 4 in the conv kernels, which never had the branch).
+template <int MODE, int WM, int WN, int TM, int TN, bool XATTN = false, bool CARRY = false, bool LNS = false>
 __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_big_kernel(GemmK p) {
     constexpr int NT = WM * WN * 64;
     constexpr int BM = WM * TM * 32, BNt = WN * TN * 32;
@@ -405,7 +409,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_big_kernel(GemmK p) {
     // by as MFMA operands (K = the LayerNorm width) and share the work - wave wn sums the k sub-steps s4 with s4 % WN == wn;
     // lane (lr, lh) covers the k-columns it holds, v_dot2_f32_f16 with fp32 accumulate.  (All of it on the waves of column 0 made
     // them the block's critical path: +10 % on a 40-n-tile GEGLU launch.)
-    const bool stat_on = MODE == 0 && p.ln_stats_w != nullptr;
+    const bool stat_on = LNS && MODE == 0 && p.ln_stats_w != nullptr;
     float st_s[TM], st_q[TM];
 #pragma unroll
     for (int i = 0; i < TM; ++i) { st_s[i] = 0.f; st_q[i] = 0.f; }
@@ -555,17 +559,21 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_big_kernel(GemmK p) {
     }
 }
 
-template <int MODE, int WM, int WN, int TM, int TN, bool XATTN = false, bool CARRY = false>
+// LNS (round 5): the instantiation that may compute LayerNorm statistics in its main loop (p.ln_stats_w).  As a run-time flag in ONE kernel
+// the statistics code put a branch and a join into every k sub-step of every dense launch, and at each join the waitcnt pass drained ALL
+// outstanding ds_reads (s_waitcnt lgkmcnt(0)) - including the fragments just requested for the NEXT sub-step, i.e. the register double
+// buffering was dead in every dense GEMM (8 full drains per k-tile pair against 4 in the conv kernels, which never had the branch).
+template <int MODE, int WM, int WN, int TM, int TN, bool XATTN = false, bool CARRY = false, bool LNS = false>
 int launch_one(const GemmK& k, hipStream_t st) {
     constexpr int smem0 = 2 * (WM * TM * 32 + WN * TN * 32) * 128;
     constexpr int smem = XATTN && XA_SMEM > smem0 ? XA_SMEM : smem0;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_big_kernel<MODE, WM, WN, TM, TN, XATTN, CARRY>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_big_kernel<MODE, WM, WN, TM, TN, XATTN, CARRY, LNS>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_big_kernel<MODE, WM, WN, TM, TN, XATTN, CARRY>), dim3(k.nbm * k.nbn, k.ksplit, 1), dim3(WM * WN * 64), smem, st, k);
+    hipLaunchKernelGGL((gemm_big_kernel<MODE, WM, WN, TM, TN, XATTN, CARRY, LNS>), dim3(k.nbm * k.nbn, k.ksplit, 1), dim3(WM * WN * 64), smem, st, k);
     ICD_CHECK_LAUNCH("icd_gemm(big tile)");
     return ICD_OK;
 }
@@ -582,7 +590,8 @@ int launch_big(const GemmK& k, int cfg, hipStream_t st) {
     const bool carry = (k.out_c || k.resid_c) && k.ksplit == 1;
 #define ICD_BIG(WM, WN, TM, TN)                                                                                                    \
     (carry ? (conv ? launch_one<1, WM, WN, TM, TN, false, true>(k, st) : launch_one<0, WM, WN, TM, TN, false, true>(k, st))        \
-           : (conv ? launch_one<1, WM, WN, TM, TN>(k, st) : launch_one<0, WM, WN, TM, TN>(k, st)))
+           : (conv ? launch_one<1, WM, WN, TM, TN>(k, st)                                                                          \
+                   : (k.ln_stats_w ? launch_one<0, WM, WN, TM, TN, false, false, true>(k, st) : launch_one<0, WM, WN, TM, TN>(k, st))))
     switch (cfg) {
     case 0: return ICD_BIG(2, 4, 4, 2);   // 256 x 256: 2 x 4 waves of 128 x 64 (GEGLU capable)
     case 1: return ICD_BIG(4, 2, 2, 5);   // 256 x 320: 4 x 2 waves of 64 x 160
@@ -591,7 +600,7 @@ int launch_big(const GemmK& k, int cfg, hipStream_t st) {
     }
 #undef ICD_BIG
     if (cfg == 100)   // query projection + cross-attention in one launch (icd_gemm_desc.xattn_*): 256 x 256 = 256 queries x 4 heads
-        return k.x_nk <= 80 ? launch_one<0, 2, 4, 4, 2, true, true>(k, st) : launch_one<0, 2, 4, 4, 2, true, false>(k, st);   // 5 / 6 live key slots
+        return k.x_nk <= 80 ? launch_one<0, 2, 4, 4, 2, true, true, true>(k, st) : launch_one<0, 2, 4, 4, 2, true, false, true>(k, st);   // 5 / 6 live key slots
     icd_set_error("icd_gemm: unknown big-tile configuration %d", cfg);
     return ICD_ERR_INVALID_ARG;
 }

@@ -121,10 +121,11 @@ def load_models(model_id, device, reverse_checkpoint, forward_checkpoint, r=64, 
 
     dtype: the reference's default 'fp32' runs diffusers in fp32 (utils/loading.py:34,38).  This executor multiplies fp16 x fp16
     into fp32 accumulators on the matrix cores either way; 'fp32' selects fp32 latents / eps at the UNet boundary and fp32
-    boundary-step arithmetic.  In both modes the residual stream carries its rounding error (UNet option residual = 2, the default
-    since round 4: every x <- x + f(x) chain keeps one bf8 byte per element beside the fp16 value, so the dominant error term of fp16
-    activation storage is gone) - DESIGN.md section 6 has the measured distance to an fp32 evaluation (eps rel-L2 0.7e-3; 1.1e-3 with
-    unet.set_option('residual', 0))."""
+    boundary-step arithmetic.  In both modes the residual stream carries its rounding error (every x <- x + f(x) chain keeps one bf8
+    byte per element beside the fp16 value, so the dominant error term of fp16 activation storage is gone), and the UNet's precision policy
+    (unet.UNet2DConditionModel.precision, default "auto") lets the consumers that matter read that byte too inside editing pipelines -
+    DESIGN.md section 6 has the measured distance to an fp32 evaluation (eps rel-L2 0.7e-3 for plain generation, 0.4e-3 at the accurate
+    level; 1.1e-3 with unet.set_option('residual', 0))."""
     tdtype = torch.float32 if dtype == 'fp32' else torch.float16
     cfg = dataclasses.replace(unet_config or SD15, time_cond_proj_dim=int(w_embed_dim))
     if w_embed_dim > 0:

@@ -300,7 +300,7 @@ def test_gemm_fp32_residual_stream_outputs(M, N, K, flags):
                                          (200, 320, 320, 0),                                         # 128-wide kernel, ragged M
                                          (512, 1280, 5120, 0)])                                      # split-K + reduce kernel
 def test_gemm_error_carry_of_the_residual_stream(M, N, K, flags):
-    """icd_gemm_desc.resid_carry / out_carry (UNet option residual = 2, the default): a stream tensor is an fp16 value plus one bf8 byte
+    """icd_gemm_desc.resid_carry / out_carry (UNet option residual = 2 and 3, every level of the precision policy): a stream tensor is an fp16 value plus one bf8 byte
     holding what the rounding lost.  h <- h + a w^T + bias in place on (hi, carry) like the executor; also the start of a chain."""
     ops = _ops()
     a, w = r16(M, K, seed=140), (r16(N, K, seed=141).float() * K ** -0.5).half()

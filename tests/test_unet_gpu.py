@@ -127,7 +127,7 @@ def test_unet_tiny_sdxl_topology():
 def test_carried_residual_stream_meets_the_north_star_tolerance(which):
     """UNet option residual (icd_unet_set_option ICD_UNET_OPT_RESIDUAL_MODE).  With fp16 activation storage the residual stream's own
     roundings (one per x <- x + f(x), 100-300 adds deep) put a single forward at 1.0 - 1.2e-3 from an fp32 evaluation; the north star's
-    bar is 1e-3.  Mode 2 (default since round 4) keeps what each rounding lost in one bf8 byte per element (icd_gemm_desc.resid_carry /
+    bar is 1e-3.  Mode 2 (the fast level of the precision policy) keeps what each rounding lost in one bf8 byte per element (icd_gemm_desc.resid_carry /
     out_carry), mode 1 (round 3) accumulated the chain in an fp32 twin.  Asserted: the default is < 1e-3 against the fp32 oracle and
     clearly better than the plain fp16 stream of the SAME handle; the carry is as good as the fp32 twin (within 5 %); switching back
     restores the default result bit for bit.  (A plain single evaluation runs at the 'fast' level of the precision policy - the error carry;

@@ -254,7 +254,9 @@ class UNet2DConditionModel:
         # every step, so steps 2..n skip the two context projections.  The cached context is kept referenced - its storage
         # cannot be recycled under the cache - and is recognised by (data_ptr, shape, version counter): an in-place update
         # of the tensor bumps the counter and refills the cache.
-        self.precision = getattr(self, "precision", "auto")
+        # (ICD_AMD_PRECISION=fast|split|accurate|auto: process-wide default of the policy, e.g. "accurate" for checkpoints whose residual stream
+        #  has large-magnitude channels, DESIGN.md section 6 "Streams that are not O(1)")
+        self.precision = getattr(self, "precision", None) or self._env_precision()
         self._inverting = 0
         self.kv_cache_enabled = True
         self._kv = None            # (ctx tensor, version, cache buffer, stream)
@@ -293,6 +295,14 @@ class UNet2DConditionModel:
     #   None        leave the options alone (set_option('residual' | 'split_mask') switches to this).
     PRECISION = {"fast": (_lib.ICD_RESIDUAL_CARRY, _lib.ICD_SPLIT_DEFAULT), "accurate": (_lib.ICD_RESIDUAL_SPLIT, _lib.ICD_SPLIT_ACCURATE),
                  "split": (_lib.ICD_RESIDUAL_SPLIT, _lib.ICD_SPLIT_DEFAULT)}
+
+    @classmethod
+    def _env_precision(cls):
+        import os
+        level = os.environ.get("ICD_AMD_PRECISION", "auto")
+        if level != "auto" and level not in cls.PRECISION:
+            raise ValueError(f"ICD_AMD_PRECISION must be one of auto, fast, split, accurate (got {level!r})")
+        return level
 
     def set_precision(self, level):
         if level not in (None, "auto") and level not in self.PRECISION:

@@ -245,6 +245,27 @@ int icd_attention_probs(const void* q, const void* k, void* probs, int32_t B, in
  * the fp16 rounding of q and k is an absolute error of the exponent, i.e. a relative error of every map a controller keeps. */
 int icd_attention_probs_split(const void* q, const void* q_carry, const void* k, const void* k_carry, void* probs, int32_t B, int32_t H,
                               int32_t Nq, int32_t Nk, int32_t d, int32_t ldq, int32_t ldk, int32_t ldp, float scale, void* stream);
+/* What the reference's shipped controllers do to the probabilities of a layer (utils/p2p.py:138-221), in the probability kernel's epilogue
+ * instead of in passes of their own over P.  The samples of the launch are [first_cond_sample unrelated samples (the unconditional half of a
+ * CFG-doubled batch) | base prompt | edited prompts ...]; everything below applies to the samples from first_cond_sample on.
+ *   acc             fp16 [(B - first_cond_sample) * H, Nq, ldp] or NULL: acc += P_final with torch's fp16 in-place-add rounding
+ *                   (AttentionStore.between_steps, utils/p2p.py:164-170);
+ *   self_from_base  != 0: the edited prompts take the base prompt's probabilities (AttentionControlEdit.replace_self_attention inside its
+ *                   step window, utils/p2p.py:183-188) - their blocks read the base sample's q and k: the same bits as the copy;
+ *   edit_At, edit_D the cross-attention edit of AttentionReplace / Refine / Reweight with the cross_replace_alpha blend as one linear
+ *                   operator per step, new_row[e] = base_row . A_e + D_e (*) cur_row[e]: fp16 [nedit][96][80] / fp32 [nedit][96] exactly as
+ *                   icd_p2p_cross_edit takes them (nedit = B - first_cond_sample - 1; <= 80 keys), or NULL.  Bit-identical to
+ *                   icd_attention_probs followed by icd_p2p_cross_edit. */
+typedef struct {
+    void* acc;
+    const void* edit_At;
+    const float* edit_D;
+    int32_t first_cond_sample, self_from_base;
+    int64_t first_cond_row;       /* alternative to first_cond_sample for callers that know rows, not heads: first_cond_sample = first_cond_row / H */
+} icd_probs_epilogue;
+int icd_attention_probs_ex(const void* q, const void* q_carry, const void* k, const void* k_carry, void* probs, int32_t B, int32_t H,
+                           int32_t Nq, int32_t Nk, int32_t d, int32_t ldq, int32_t ldk, int32_t ldp, float scale,
+                           const icd_probs_epilogue* epilogue, void* stream);
 
 /* Sinusoidal embeddings.  kind 0: diffusers Timesteps(dim, flip_sin_to_cos=True, shift=0) -> [cos || sin];
  * kind 1: guidance_scale_embedding (utils/generation.py:96-122) -> [sin || cos] of 1000*w, denominator half-1.
@@ -352,6 +373,12 @@ typedef struct icd_unet icd_unet;
  * place: 0 down, 1 mid, 2 up.  P layout: [bh = B*heads (row b*heads+h), nq, ld] with nk valid columns. */
 #define ICD_HOOK_QUERY 0
 #define ICD_HOOK_PROBS 1
+/*   phase 0 may also return 2: materialise P as for 1, AND the hook has an epilogue for the probability kernel (round 5).  The executor then
+ *            calls phase 2 (ICD_HOOK_EPILOGUE) once: the hook stores in *probs a pointer to an icd_probs_epilogue that stays valid until
+ *            its phase-1 call of this layer returns (first_cond_row in rows of P; first_cond_sample ignored), and returns 1 (0: none after
+ *            all).  What the epilogue did - store accumulation, self-attention replacement, the cross-attention edit - the hook must
+ *            not repeat in phase 1.  Hooks that never return 2 never see phase 2. */
+#define ICD_HOOK_EPILOGUE 2
 typedef int (*icd_attn_hook)(void* user, int32_t phase, int32_t layer, int32_t is_cross, int32_t place, int64_t bh,
                              int64_t nq, int64_t nk, int64_t ld, void** probs);
 

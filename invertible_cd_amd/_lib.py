@@ -33,6 +33,7 @@ ICD_ATTN_Q_PRESCALED = 2
 ICD_ATTN_TUNE_MODE0 = 4
 ICD_HOOK_QUERY = 0
 ICD_HOOK_PROBS = 1
+ICD_HOOK_EPILOGUE = 2
 
 
 class GemmDesc(C.Structure):
@@ -55,6 +56,12 @@ class GemmDesc(C.Structure):
         ("resid_carry", C.c_void_p), ("out_carry", C.c_void_p),
         ("conv_tap_base", C.c_int32), ("conv_ktaps", C.c_int32), ("out_remap_w", C.c_int32), ("out_remap_c", C.c_int32),
     ]
+
+
+class ProbsEpilogue(C.Structure):
+    """icd_probs_epilogue: what the shipped controllers do to P, done in the probability kernel's epilogue."""
+    _fields_ = [("acc", C.c_void_p), ("edit_At", C.c_void_p), ("edit_D", C.c_void_p), ("first_cond_sample", C.c_int32),
+                ("self_from_base", C.c_int32), ("first_cond_row", C.c_int64)]
 
 
 class GemmPlanInfo(C.Structure):
@@ -129,6 +136,7 @@ SIGNATURES = {
                                       C.c_float, C.c_void_p]),
     "icd_attention_probs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int32] * 8 + [C.c_float, C.c_void_p]),
     "icd_attention_probs_split": (C.c_int, [C.c_void_p] * 5 + [C.c_int32] * 8 + [C.c_float, C.c_void_p]),
+    "icd_attention_probs_ex": (C.c_int, [C.c_void_p] * 5 + [C.c_int32] * 8 + [C.c_float, C.POINTER(ProbsEpilogue), C.c_void_p]),
     "icd_sinusoid": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "icd_silu": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "icd_conv_in": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,

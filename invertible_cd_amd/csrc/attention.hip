@@ -747,8 +747,27 @@ __device__ __forceinline__ f16x8 carry8_as_f16(const u32x2 w) {
 // of their fp16 rounding (icd_gemm_desc.out_carry) and the scores are q.k = qh.kh + 2^-14 (ql.kh + qh.kl) - three MFMAs per k-step on
 // two accumulators (the lo products in their own, unscaled).  A stored probability map is exp of these scores: its relative error IS the
 // absolute error of the score, and the fp16 rounding of q and k is 12 % of the attention-store error budget (tests/error_budget_sim.py).
-template <int KS, bool SPLIT = false>
-__global__ __launch_bounds__(256, 2) void attn_probs_kernel(ProbsK a) {
+//
+// EPI (round 5): what the reference's shipped controllers do to the probabilities of a layer (utils/p2p.py:138-221) in this kernel's
+// epilogue instead of in passes of their own over P (icd_probs_epilogue):
+//   * AttentionStore.between_steps: acc += P on the final probabilities (torch's fp16 add: fp16(float(acc) + float(P)));
+//   * AttentionControlEdit.replace_self_attention inside its step window: the edited prompts take the base prompt's probabilities - their
+//     blocks simply read the base sample's q and k (the same arithmetic, hence the same bits as the copy);
+//   * the cross-attention edit of AttentionReplace / Refine / Reweight with its cross_replace_alpha blend, one linear operator per step,
+//     new_row[e] = base_row . A_e + D_e (*) cur_row[e] (csrc/p2p.hip): the block of an edited prompt recomputes the base prompt's
+//     probabilities of its query tile (<= 96 keys: a few MFMAs), uses them - rounded to fp16 as the two-pass form reads them from memory -
+//     as the MFMA B operand straight from the accumulator layout, and combines with its own probabilities through the LDS patch that
+//     already stages the rows for the store.  Same operands in the same order as icd_p2p_cross_edit: the same bits.
+// The samples of the launch are [b0 unrelated samples (the unconditional half of a CFG-doubled batch) | base prompt | edited prompts ...].
+struct ProbsEpi {
+    half_t* acc;            // [ (B - b0) * H, Nq, ldp ] or null
+    const half_t* At;       // [nedit][96][80] fp16 (ops.p2p_pack_operator) or null
+    const float* D;         // [nedit][96]
+    int b0, self_base;
+};
+
+template <int KS, bool SPLIT = false, bool EPI = false>
+__global__ __launch_bounds__(256, 2) void attn_probs_kernel(ProbsK a, ProbsEpi ep) {
     __shared__ __attribute__((aligned(16))) half_t patch_all[4][32 * 72];
     const int tid = threadIdx.x, l = tid & 63, lr = l & 31, lh = l >> 5;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -761,21 +780,24 @@ __global__ __launch_bounds__(256, 2) void attn_probs_kernel(ProbsK a) {
     for (int e = 0; e < 8; ++e) z8[e] = (half_t)0.f;
     constexpr int KF = SPLIT ? 2 * KS : KS;            // fragments per operand: [hi (KS) | lo (KS)]
     const u32x2 zc = {0u, 0u};
-    f16x8 qf[KF];
-    {
+    const int jp = EPI && b >= ep.b0 ? b - ep.b0 : 0;  // prompt index among the conditional samples (0 = the base prompt)
+    const int bq = EPI && ep.self_base && jp > 0 ? ep.b0 : b;       // the sample whose q and k this block reads
+    auto load_q = [&](f16x8 (&qq)[KF], int bs) {
         const int qrow = q0 + lr;
-        const long long qoff = ((long long)b * a.Nq + qrow) * a.ldq + h * a.d;
+        const long long qoff = ((long long)bs * a.Nq + qrow) * a.ldq + h * a.d;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const int dd = ks * 16 + lh * 8;
             const bool okq = qrow < a.Nq && dd < a.d;
-            qf[ks] = okq ? *reinterpret_cast<const f16x8*>(a.q + qoff + dd) : z8;
-            if (SPLIT) qf[KS + ks] = carry8_as_f16((okq && a.qc) ? *reinterpret_cast<const u32x2*>(a.qc + qoff + dd) : zc);
+            qq[ks] = okq ? *reinterpret_cast<const f16x8*>(a.q + qoff + dd) : z8;
+            if (SPLIT) qq[KS + ks] = carry8_as_f16((okq && a.qc) ? *reinterpret_cast<const u32x2*>(a.qc + qoff + dd) : zc);
         }
-    }
-    const long long koff0 = (long long)b * a.Nk * a.ldk + h * a.d;
+    };
+    f16x8 qf[KF];
+    load_q(qf, bq);
     const int prow = (lr & 0x13) | ((lr & 4) << 1) | ((lr & 8) >> 1);
-    auto load_k = [&](f16x8 (&kf)[KF], int kt) {
+    auto load_k_of = [&](f16x8 (&kf)[KF], int kt, int bs) {
+        const long long koff0 = (long long)bs * a.Nk * a.ldk + h * a.d;
         const int key = kt * 32 + prow;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
@@ -786,17 +808,18 @@ __global__ __launch_bounds__(256, 2) void attn_probs_kernel(ProbsK a) {
             if (SPLIT) kf[KS + ks] = carry8_as_f16((okk && a.kc) ? *reinterpret_cast<const u32x2*>(a.kc + off) : zc);
         }
     };
+    auto load_k = [&](f16x8 (&kf)[KF], int kt) { load_k_of(kf, kt, bq); };
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const float c = a.scale_log2;
-    auto scores = [&](f32x16& s, const f16x8 (&kf)[KF], int kt) {            // s = log2(e) * scale * q.k, keys past Nk -> -inf
+    auto scores_of = [&](f32x16& s, const f16x8 (&kf)[KF], const f16x8 (&qq)[KF], int kt) {     // s = log2(e) * scale * q.k, keys past Nk -> -inf
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[ks], qf[ks], ks == 0 ? zero16 : s, 0, 0, 0);
+        for (int ks = 0; ks < KS; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[ks], qq[ks], ks == 0 ? zero16 : s, 0, 0, 0);
         if (SPLIT) {                                                           // + 2^-14 (kl.qh + kh.ql)
             f32x16 t;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                t = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[KS + ks], qf[ks], ks == 0 ? zero16 : t, 0, 0, 0);
-                t = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[ks], qf[KS + ks], t, 0, 0, 0);
+                t = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[KS + ks], qq[ks], ks == 0 ? zero16 : t, 0, 0, 0);
+                t = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[ks], qq[KS + ks], t, 0, 0, 0);
             }
 #pragma unroll
             for (int e = 0; e < 16; ++e) s[e] = __builtin_fmaf(t[e], 1.f / 16384.f, s[e]);
@@ -806,6 +829,7 @@ __global__ __launch_bounds__(256, 2) void attn_probs_kernel(ProbsK a) {
             s[e] = 16 * (e >> 3) + (e & 7) < a.Nk - kt * 32 - 8 * lh ? s[e] * c : -INFINITY;      // key < Nk
         }
     };
+    auto scores = [&](f32x16& s, const f16x8 (&kf)[KF], int kt) { scores_of(s, kf, qf, kt); };
     auto half_swap_max = [&](float v) {
         const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
         return fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
@@ -815,6 +839,7 @@ __global__ __launch_bounds__(256, 2) void attn_probs_kernel(ProbsK a) {
         return __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
     };
     half_t* Pb = a.p + ((long long)bh * a.Nq + q0) * a.ldp;
+    half_t* Ab = EPI && ep.acc && b >= ep.b0 ? ep.acc + ((long long)(jp * a.H + h) * a.Nq + q0) * a.ldp : nullptr;
     // one k-tile of probabilities (this lane: query lr, keys 32kt + 16j + 8lh .. +7, j = 0, 1) -> patch -> global rows
     auto emit = [&](const f32x16& pv, int kt) {
 #pragma unroll
@@ -830,39 +855,91 @@ __global__ __launch_bounds__(256, 2) void attn_probs_kernel(ProbsK a) {
         for (int pass = 0; pass < 4; ++pass) {
             const int r = pass * 8 + (l >> 3), c8 = (l & 7) * 8;
             const int col = kt_first * 32 + c8;
-            if (c8 < ncols && col < a.ldp && q0 + r < a.Nq)
-                *reinterpret_cast<f16x8*>(Pb + (long long)r * a.ldp + col) = *reinterpret_cast<const f16x8*>(patch + r * 72 + c8);
+            if (c8 < ncols && col < a.ldp && q0 + r < a.Nq) {
+                const f16x8 v = *reinterpret_cast<const f16x8*>(patch + r * 72 + c8);
+                *reinterpret_cast<f16x8*>(Pb + (long long)r * a.ldp + col) = v;
+                if (EPI && Ab) {                                               // store += P (torch's fp16 in-place add)
+                    half_t* ap = Ab + (long long)r * a.ldp + col;
+                    const f16x8 t = *reinterpret_cast<const f16x8*>(ap);
+                    f16x8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)t[e] + (float)v[e]);
+                    *reinterpret_cast<f16x8*>(ap) = o;
+                }
+            }
         }
     };
     const int nt = (a.ldp + 31) >> 5;                      // k-tiles incl. the pad columns (they are written as zeros)
     if (nt <= 3) {
         // ---- few keys (cross-attention): all S^T tiles in registers, exact softmax ----
-        f32x16 s[3];
-        float mx = -INFINITY;
+        auto probs3 = [&](f32x16 (&s)[3], const f16x8 (&qq)[KF], int bs) {
+            float mx = -INFINITY;
 #pragma unroll
-        for (int kt = 0; kt < 3; ++kt) {
-            if (kt < nt) {
-                f16x8 kf[KF];
-                load_k(kf, kt);
-                scores(s[kt], kf, kt);
+            for (int kt = 0; kt < 3; ++kt) {
+                if (kt < nt) {
+                    f16x8 kf[KF];
+                    load_k_of(kf, kt, bs);
+                    scores_of(s[kt], kf, qq, kt);
 #pragma unroll
-                for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[kt][e]);
+                    for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[kt][e]);
+                }
             }
+            mx = half_swap_max(mx);
+            float rs = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 3; ++kt)
+                if (kt < nt)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) { s[kt][e] = __builtin_amdgcn_exp2f(s[kt][e] - mx); rs += s[kt][e]; }
+            const float inv = 1.0f / half_swap_sum(rs);
+#pragma unroll
+            for (int kt = 0; kt < 3; ++kt)
+                if (kt < nt)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) s[kt][e] *= inv;
+        };
+        f32x16 s[3];
+        probs3(s, qf, bq);
+        const bool edit = EPI && ep.At != nullptr && jp > 0;
+        f16x8 pb[5];                                       // the base prompt's probabilities of this query tile as the MFMA B operand
+        if (EPI && edit) {
+            f16x8 qb[KF];
+            load_q(qb, ep.b0);
+            f32x16 sb[3];
+            probs3(sb, qb, ep.b0);
+#pragma unroll
+            for (int ks = 0; ks < 5; ++ks)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pb[ks][e] = (ks >> 1) < nt ? (half_t)sb[ks >> 1][8 * (ks & 1) + e] : (half_t)0.f;
         }
-        mx = half_swap_max(mx);
-        float rs = 0.f;
-#pragma unroll
-        for (int kt = 0; kt < 3; ++kt)
-            if (kt < nt)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) { s[kt][e] = __builtin_amdgcn_exp2f(s[kt][e] - mx); rs += s[kt][e]; }
-        const float inv = 1.0f / half_swap_sum(rs);
 #pragma unroll
         for (int kt = 0; kt < 3; ++kt) {
             if (kt < nt) {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) s[kt][e] *= inv;
                 emit(s[kt], kt);
+                if (EPI && edit) {
+                    // new[n] = sum_w At[n][w] base[w] + D[n] cur[n] for the 32 tokens of this tile; cur comes back from the patch in
+                    // the accumulator layout (row lr, tokens 8g + 4lh .. +3)
+                    const half_t* Ae = ep.At + (long long)(jp - 1) * (96 * 80);
+                    f32x16 acc;
+#pragma unroll
+                    for (int ks = 0; ks < 5; ++ks) {
+                        const f16x8 af = *reinterpret_cast<const f16x8*>(Ae + (kt * 32 + lr) * 80 + ks * 16 + lh * 8);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, pb[ks], ks == 0 ? zero16 : acc, 0, 0, 0);
+                    }
+                    const float* De = ep.D + (long long)(jp - 1) * 96 + kt * 32;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int n = 8 * g + 4 * lh;
+                        if (kt * 32 + n + 4 > a.ldp) continue;                 // token slots past the row (pad columns stay zero)
+                        half_t* pp = patch + lr * 72 + (kt & 1) * 32 + n;
+                        const f16x4 cur = *reinterpret_cast<const f16x4*>(pp);
+                        const f32x4 d = *reinterpret_cast<const f32x4*>(De + n);
+                        f16x4 o;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) o[i] = (half_t)fmaf(d[i], (float)cur[i], acc[4 * g + i]);
+                        *reinterpret_cast<f16x4*>(pp) = o;
+                    }
+                }
                 if ((kt & 1) || kt == nt - 1) flush(kt & ~1, (kt & 1) ? 64 : 32);
             }
         }
@@ -974,7 +1051,8 @@ extern "C" int icd_attention_fused_ex(const void* q, const void* k, const void* 
                                       int64_t vt_batch_stride, float scale, int32_t flags, void* stream);
 
 static int attention_probs_run(const void* q, const void* qc, const void* k, const void* kc, void* probs, int32_t B, int32_t H, int32_t Nq,
-                               int32_t Nk, int32_t d, int32_t ldq, int32_t ldk, int32_t ldp, float scale, void* stream) {
+                               int32_t Nk, int32_t d, int32_t ldq, int32_t ldk, int32_t ldp, float scale, void* stream,
+                               const icd_probs_epilogue* epi = nullptr) {
     ICD_CHECK_ARG(q && k && probs, "icd_attention_probs: null pointer");
     ICD_CHECK_ARG(B > 0 && H > 0 && Nq > 0 && Nk > 0, "icd_attention_probs: empty shape");
     ICD_CHECK_ARG(d > 0 && d % 8 == 0 && d <= 160, "icd_attention_probs: head dim must be a multiple of 8, <= 160 (got %d)", d);
@@ -986,19 +1064,28 @@ static int attention_probs_run(const void* q, const void* qc, const void* k, con
     a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.d = d; a.ldq = ldq; a.ldk = ldk; a.ldp = ldp;
     a.scale_log2 = scale * 1.4426950408889634f;
     a.qc = (const unsigned char*)qc; a.kc = (const unsigned char*)kc;
+    ProbsEpi ep{nullptr, nullptr, nullptr, 0, 0};
+    if (epi) {
+        ICD_CHECK_ARG(epi->first_cond_sample >= 0 && epi->first_cond_sample < B, "icd_attention_probs_ex: first_cond_sample out of range");
+        ICD_CHECK_ARG(!epi->edit_At || (epi->edit_D && Nk <= 80 && ldp <= 96),
+                      "icd_attention_probs_ex: the cross-attention edit needs edit_D, <= 80 keys and a base + >= 1 edited prompt");
+        ep.acc = (half_t*)epi->acc; ep.At = (const half_t*)epi->edit_At; ep.D = epi->edit_D;
+        ep.b0 = epi->first_cond_row > 0 ? (int)(epi->first_cond_row / H) : epi->first_cond_sample; ep.self_base = epi->self_from_base != 0;
+        ICD_CHECK_ARG(epi->first_cond_row % H == 0 && ep.b0 < B, "icd_attention_probs_ex: first_cond_row must be a multiple of H inside the batch");
+    }
+    const bool use_epi = ep.acc || ep.At || ep.self_base;
     const dim3 grid((unsigned)((Nq + 127) / 128), (unsigned)(B * H));
     hipStream_t st = (hipStream_t)stream;
-    if (qc || kc) {
-        if (d <= 48) hipLaunchKernelGGL((attn_probs_kernel<3, true>), grid, dim3(256), 0, st, a);
-        else if (d <= 80) hipLaunchKernelGGL((attn_probs_kernel<5, true>), grid, dim3(256), 0, st, a);
-        else if (d <= 128) hipLaunchKernelGGL((attn_probs_kernel<8, true>), grid, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((attn_probs_kernel<10, true>), grid, dim3(256), 0, st, a);
-    } else {
-        if (d <= 48) hipLaunchKernelGGL((attn_probs_kernel<3, false>), grid, dim3(256), 0, st, a);
-        else if (d <= 80) hipLaunchKernelGGL((attn_probs_kernel<5, false>), grid, dim3(256), 0, st, a);
-        else if (d <= 128) hipLaunchKernelGGL((attn_probs_kernel<8, false>), grid, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((attn_probs_kernel<10, false>), grid, dim3(256), 0, st, a);
-    }
+#define ICD_PROBS(SP, EP)                                                                                     \
+    do {                                                                                                      \
+        if (d <= 48) hipLaunchKernelGGL((attn_probs_kernel<3, SP, EP>), grid, dim3(256), 0, st, a, ep);       \
+        else if (d <= 80) hipLaunchKernelGGL((attn_probs_kernel<5, SP, EP>), grid, dim3(256), 0, st, a, ep);  \
+        else if (d <= 128) hipLaunchKernelGGL((attn_probs_kernel<8, SP, EP>), grid, dim3(256), 0, st, a, ep); \
+        else hipLaunchKernelGGL((attn_probs_kernel<10, SP, EP>), grid, dim3(256), 0, st, a, ep);              \
+    } while (0)
+    if (qc || kc) { if (use_epi) ICD_PROBS(true, true); else ICD_PROBS(true, false); }
+    else { if (use_epi) ICD_PROBS(false, true); else ICD_PROBS(false, false); }
+#undef ICD_PROBS
     ICD_CHECK_LAUNCH("icd_attention_probs");
     return ICD_OK;
 }
@@ -1012,6 +1099,12 @@ extern "C" int icd_attention_probs_split(const void* q, const void* q_carry, con
                                          int32_t H, int32_t Nq, int32_t Nk, int32_t d, int32_t ldq, int32_t ldk, int32_t ldp, float scale,
                                          void* stream) {
     return attention_probs_run(q, q_carry, k, k_carry, probs, B, H, Nq, Nk, d, ldq, ldk, ldp, scale, stream);
+}
+
+extern "C" int icd_attention_probs_ex(const void* q, const void* q_carry, const void* k, const void* k_carry, void* probs, int32_t B,
+                                      int32_t H, int32_t Nq, int32_t Nk, int32_t d, int32_t ldq, int32_t ldk, int32_t ldp, float scale,
+                                      const icd_probs_epilogue* epilogue, void* stream) {
+    return attention_probs_run(q, q_carry, k, k_carry, probs, B, H, Nq, Nk, d, ldq, ldk, ldp, scale, stream, epilogue);
 }
 
 extern "C" int icd_attention_fused(const void* q, const void* k, const void* vt, void* out, int32_t B, int32_t H,

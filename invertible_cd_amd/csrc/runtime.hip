@@ -375,15 +375,21 @@ struct Exec {
     // Phase 0 of the plugin protocol for the next Attention module (module-execution order): does the controller want its
     // probabilities?  Asked BEFORE the query projection is enqueued, because a cross-attention layer that is not
     // materialised runs as the epilogue of that projection (icd_gemm xattn_*).
-    struct AttnPlan { int layer; bool mat; void* probs; };
+    struct AttnPlan { int layer; bool mat; void* probs; bool has_epi; icd_probs_epilogue epi; };
     AttnPlan attn_query(bool is_cross, int place, int heads, int Nq, int Nk) {
-        AttnPlan a{layer++, false, nullptr};
+        AttnPlan a{layer++, false, nullptr, false, {}};
         const long long ldp = (Nk + 7) / 8 * 8;
         if (dry) a.mat = probs_mode == 2 || (probs_mode == 1 && (is_cross || Nq <= 1024));
         else if (io->hook && ok()) {
             const int r = io->hook(io->hook_user, ICD_HOOK_QUERY, a.layer, is_cross, place, (long long)B * heads, Nq, Nk, ldp, &a.probs);
             if (r < 0) { icd_set_error("attention hook (query) failed at layer %d", a.layer); status = ICD_ERR_HOOK; return a; }
-            a.mat = r == 1;
+            a.mat = r >= 1;
+            if (r == 2) {                            // the hook has an epilogue for the probability kernel (icd_probs_epilogue)
+                void* e = nullptr;
+                const int r2 = io->hook(io->hook_user, ICD_HOOK_EPILOGUE, a.layer, is_cross, place, (long long)B * heads, Nq, Nk, ldp, &e);
+                if (r2 < 0) { icd_set_error("attention hook (epilogue) failed at layer %d", a.layer); status = ICD_ERR_HOOK; return a; }
+                if (r2 == 1 && e) { a.epi = *(const icd_probs_epilogue*)e; a.has_epi = true; }
+            }
             if (a.mat && !a.probs) { icd_set_error("attention hook returned 1 without a probability buffer (layer %d)", a.layer); status = ICD_ERR_HOOK; }
         }
         return a;
@@ -417,7 +423,7 @@ struct Exec {
         const long long per_b = (long long)heads * Nq * ldp;            // elements of P per sample
         if (!dry && ok()) {
             ProfScope ps(true, st, ICD_PROF_SOFTMAX, 2.0 * B * heads * (double)Nq * Nk * d, (double)B * per_b * 2.0);
-            run(icd_attention_probs_split(q, q_c, k, k_c, probs, B, heads, Nq, Nk, d, ldq, ldk, (int)ldp, scale, st));
+            run(icd_attention_probs_ex(q, q_c, k, k_c, probs, B, heads, Nq, Nk, d, ldq, ldk, (int)ldp, scale, plan.has_epi ? &plan.epi : nullptr, st));
         }
         if (!dry && ok()) {
             const int r = io->hook(io->hook_user, ICD_HOOK_PROBS, my_layer, is_cross, place, (long long)B * heads, Nq, Nk, ldp, &probs);

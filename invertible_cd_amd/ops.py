@@ -345,13 +345,27 @@ def attention_fused(q, k, vt, B, H, Nq, Nk, d, scale, causal=False, prescaled=Fa
     return out
 
 
-def attention_probs(q, k, B, H, Nq, Nk, d, scale, ld=None, out=None, q_carry=None, k_carry=None):
+def attention_probs(q, k, B, H, Nq, Nk, d, scale, ld=None, out=None, q_carry=None, k_carry=None, acc=None, edit=None, self_from_base=False,
+                    first_cond_sample=0):
     """P[b*H+h, n, :Nk] = softmax(scale * q.k) as fp16 [B*H, Nq, ld] in one pass (no fp32 score tensor); pad columns zero.
     q_carry / k_carry: uint8 error carries of q / k (icd_attention_probs_split: scores from hi + lo operands)."""
     _chk_rows(q, "q"); _chk_rows(k, "k")
     ld = ld or (Nk + 7) // 8 * 8
     if out is None:
         out = torch.empty((B * H, Nq, ld), device=q.device, dtype=torch.float16)
+    if acc is not None or edit is not None or self_from_base:
+        # icd_attention_probs_ex: the shipped controllers' work on P in the kernel's epilogue - acc [(B - first) * H, Nq, ld] += P,
+        # edit = (At, Dp) of p2p_pack_operator, self_from_base: the edited prompts take the base prompt's rows
+        epi = _lib.ProbsEpilogue()
+        epi.first_cond_sample, epi.self_from_base = first_cond_sample, int(self_from_base)
+        if acc is not None:
+            assert acc.dtype == torch.float16 and acc.is_cuda and acc.stride() == (Nq * ld, ld, 1) and acc.shape[0] == (B - first_cond_sample) * H
+            epi.acc = acc.data_ptr()
+        if edit is not None:
+            epi.edit_At, epi.edit_D = edit[0].data_ptr(), edit[1].data_ptr()
+        _lib.check(_lib.load().icd_attention_probs_ex(_p(q), _p(q_carry), _p(k), _p(k_carry), _p(out), B, H, Nq, Nk, d, q.stride(0),
+                                                      k.stride(0), ld, scale, C.byref(epi), _stream()), "icd_attention_probs_ex")
+        return out
     if q_carry is None and k_carry is None:
         _lib.check(_lib.load().icd_attention_probs(_p(q), _p(k), _p(out), B, H, Nq, Nk, d, q.stride(0), k.stride(0), ld, scale, _stream()),
                    "icd_attention_probs")

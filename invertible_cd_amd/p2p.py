@@ -195,6 +195,7 @@ class AttentionStore(AttentionControl):
         super().__init__()
         self.step_store = self.get_empty_store()
         self.attention_store = {}
+        self._fused_acc = set()        # (key, index) of this step's maps the probability kernel has already added to attention_store
 
     @staticmethod
     def get_empty_store():
@@ -212,7 +213,9 @@ class AttentionStore(AttentionControl):
         if not self.attention_store:
             self.attention_store = self.step_store
         else:
-            pairs = [(t, self.step_store[key][i]) for key, acc in self.attention_store.items() for i, t in enumerate(acc)]
+            fused = self._fused_acc            # added by the probability kernel's epilogue (HookAdapter, icd_probs_epilogue.acc)
+            pairs = [(t, self.step_store[key][i]) for key, acc in self.attention_store.items() for i, t in enumerate(acc)
+                     if (key, i) not in fused]
             if pairs and all(t.is_cuda and t.dtype == torch.float16 and t.is_contiguous() and s.is_cuda and s.dtype == torch.float16
                              and s.is_contiguous() and t.shape == s.shape and t.data_ptr() % 16 == 0 and s.data_ptr() % 16 == 0
                              for t, s in pairs):
@@ -222,6 +225,7 @@ class AttentionStore(AttentionControl):
                 for t, s in pairs:
                     t += s
         self.step_store = self.get_empty_store()
+        self._fused_acc = set()
 
     def get_average_attention(self):
         return {key: [t / self.cur_step for t in ts] for key, ts in self.attention_store.items()}
@@ -230,6 +234,7 @@ class AttentionStore(AttentionControl):
         super().reset()
         self.step_store = self.get_empty_store()
         self.attention_store = {}
+        self._fused_acc = set()
 
 
 class AttentionControlEdit(AttentionStore, abc.ABC):
@@ -278,6 +283,8 @@ class AttentionControlEdit(AttentionStore, abc.ABC):
 
     def forward(self, attn, is_cross: bool, place_in_unet: str):
         super().forward(attn, is_cross, place_in_unet)          # stores a VIEW: the stored tensor sees the edit below
+        if getattr(self, "_kernel_edit", False):                # the probability kernel's epilogue has applied this layer's edit already
+            return attn
         in_self_window = self.num_self_replace[0] <= self.cur_step < self.num_self_replace[1]
         if not (is_cross or in_self_window):
             return attn
@@ -409,6 +416,15 @@ class HookAdapter:
         # arena sizing hint for the executor (icd_unet_workspace_bytes_ex): 1 = the shipped controllers' rule, 2 = any layer
         self.probs_mode = 1 if self.native else 2
         self.pending = None
+        # round 5: for the shipped controllers (exactly these classes) what they do to P - accumulate into the store, copy the base prompt's
+        # self-attention rows, the cross-attention edit operator - rides in the probability kernel's epilogue (icd_probs_epilogue): one pass
+        # over P instead of three.  `controller.fused_epilogue = False` keeps the separate passes (A/B; bit-identical results).
+        self.fuse = (self.native and type(controller) in (AttentionStore, AttentionReplace, AttentionRefine, AttentionReweight)
+                     and getattr(controller, "fused_epilogue", True) and not LOW_RESOURCE and str(dev).startswith("cuda"))
+        self.epilogue = None
+        self._epi_refs = None
+        self._epi_acc_key = None
+        self._epi_edit = False
 
     @staticmethod
     def _trusts_needs_probs(c):
@@ -435,17 +451,66 @@ class HookAdapter:
         # a FRESH buffer per layer call: AttentionStore keeps views of it alive across steps (utils/p2p.py:148,153-157)
         buf = torch.empty((bh, nq, ld), dtype=torch.float16, device=self.dev)
         self.pending = buf[:, :, :nk]
+        self.epilogue = self._plan_epilogue(is_cross, place, bh, nq, nk, ld) if self.fuse else None
         return buf
+
+    def _plan_epilogue(self, is_cross, place, bh, nq, nk, ld):
+        """icd_probs_epilogue of this layer call, or None: which of the controller's operations on P the kernel performs itself."""
+        from . import _lib, ops
+        c = self.c
+        self._epi_refs, self._epi_acc_key, self._epi_edit = None, None, False
+        first = 0 if self.cond_only else bh // 2
+        rows = bh - first
+        epi = _lib.ProbsEpilogue()
+        epi.first_cond_row = first
+        refs = []
+        if isinstance(c, AttentionControlEdit):
+            if rows % c.batch_size != 0 or c.batch_size < 2:
+                return None
+            if is_cross:
+                if not (nk <= 80 and ld >= 80 and ld % 8 == 0):
+                    return None                      # the torch / icd_p2p_cross_edit path handles it (and then the store add must follow it)
+                At, Dp = c.cross_edit_operator(c.cur_step, self.dev)
+                epi.edit_At, epi.edit_D = At.data_ptr(), Dp.data_ptr()
+                refs += [At, Dp]
+                self._epi_edit = True
+            elif c.num_self_replace[0] <= c.cur_step < c.num_self_replace[1]:
+                epi.self_from_base = 1               # (materialised self-attention layers are the <= 32^2-query ones: always replaced)
+                self._epi_edit = True
+        if nq <= c.STORE_MAX_QUERIES and c.attention_store:
+            key = f"{place}_{'cross' if is_cross else 'self'}"
+            idx = len(c.step_store[key])
+            acc = c.attention_store.get(key, [])
+            if idx < len(acc):
+                t = acc[idx]
+                if (t.is_cuda and t.dtype == torch.float16 and tuple(t.shape) == (rows, nq, nk) and t.stride() == (nq * ld, ld, 1)
+                        and t.data_ptr() % 16 == 0):
+                    epi.acc = t.data_ptr()
+                    refs.append(t)
+                    self._epi_acc_key = (key, idx)
+        if not (self._epi_edit or self._epi_acc_key):
+            return None
+        self._epi_refs = refs
+        return epi
 
     def probs_ready(self, layer, is_cross, place):
         view, self.pending = self.pending, None
         c = self.c
-        if self.cond_only and isinstance(c, AttentionControl):
-            c.call_cond_only(view, is_cross, place)
-            return
-        out = c(view, is_cross, place)
-        if out is not None and out is not view:
-            view.copy_(out)
+        fused, self.epilogue = self.epilogue is not None, None
+        if fused:                                    # tell the controller what the kernel has done to this layer's P
+            c._kernel_edit = self._epi_edit
+            if self._epi_acc_key is not None:
+                c._fused_acc.add(self._epi_acc_key)
+        try:
+            if self.cond_only and isinstance(c, AttentionControl):
+                c.call_cond_only(view, is_cross, place)
+                return
+            out = c(view, is_cross, place)
+            if out is not None and out is not view:
+                view.copy_(out)
+        finally:
+            if fused:
+                c._kernel_edit = False
 
 
 # ------------------------------------------------------------------------------------------- word / schedule helpers

@@ -939,6 +939,53 @@ def test_attention_probs_from_split_operands(B, H, Nq, Nk, d):
     assert rel_l2(P1[:, :, :Nk], ref) < e_p
 
 
+@pytest.mark.parametrize("split", [False, True])
+def test_probability_kernel_epilogue_does_the_controllers_work_bit_for_bit(split):
+    """icd_attention_probs_ex (icd_probs_epilogue): the store accumulation, the self-attention replacement and the cross-attention edit of the
+    reference's controllers in the probability kernel's epilogue - one pass over P - against the separate passes they replace: the same
+    kernels' P, icd_p2p_cross_edit, torch's fp16 in-place add, a row copy.  Same bits, with and without split q / k, with a CFG-doubled
+    batch (the unconditional half untouched)."""
+    ops = _ops()
+    P, H, d, Nk = 3, 8, 40, 77                         # prompts (base + 2 edits), heads
+    B, first = 2 * P, P                                # CFG-doubled: [uncond x 3 | cond x 3]
+    g = torch.Generator().manual_seed(180)
+    for Nq in (1024, 200):
+        q32, k32 = torch.randn(B * Nq, H * d, generator=g) * 2, torch.randn(B * Nk, H * d, generator=g) * 2
+        qh, qc = ops.carry_encode(q32); kh, kc = ops.carry_encode(k32)
+        kw = dict(q_carry=qc.cuda(), k_carry=kc.cuda()) if split else {}
+        scale, ld = d ** -0.5, 80
+        T = Nk
+        A = torch.rand(P - 1, T, T, generator=g) * (torch.rand(P - 1, T, T, generator=g) < 0.05)
+        D = torch.rand(P - 1, T, generator=g)
+        At, Dp = ops.p2p_pack_operator(A.cuda(), D.cuda())
+        acc0 = (torch.rand(P * H, Nq, ld, generator=g) * 0.1).half()
+        # reference: separate passes
+        ref = ops.attention_probs(qh.cuda(), kh.cuda(), B, H, Nq, Nk, d, scale, ld, **kw)
+        cond = ref[first * H:]
+        ops.p2p_cross_edit(cond[:, :, :Nk], P, At, Dp)
+        acc_ref = acc0.cuda().clone()
+        acc_ref += cond
+        # fused
+        acc = acc0.cuda().clone()
+        got = ops.attention_probs(qh.cuda(), kh.cuda(), B, H, Nq, Nk, d, scale, ld, acc=acc, edit=(At, Dp), first_cond_sample=first, **kw)
+        assert torch.equal(got, ref) and torch.equal(acc, acc_ref), (Nq, split)
+        assert not torch.equal(got[first * H + H:], ops.attention_probs(qh.cuda(), kh.cuda(), B, H, Nq, Nk, d, scale, ld, **kw)[first * H + H:])
+    # self-attention (long rows, two sweeps): replacement by the base prompt's rows + accumulation
+    Nq = Nk2 = 256
+    q32, k32 = torch.randn(B * Nq, H * d, generator=g) * 2, torch.randn(B * Nk2, H * d, generator=g) * 2
+    qh, qc = ops.carry_encode(q32); kh, kc = ops.carry_encode(k32)
+    kw = dict(q_carry=qc.cuda(), k_carry=kc.cuda()) if split else {}
+    ref = ops.attention_probs(qh.cuda(), kh.cuda(), B, H, Nq, Nk2, d, d ** -0.5, **kw)
+    base = ref[first * H:(first + 1) * H]
+    for e in range(1, P):
+        ref[(first + e) * H:(first + e + 1) * H] = base
+    acc0 = (torch.rand(P * H, Nq, Nk2, generator=g) * 0.1).half().cuda()
+    acc_ref = acc0.clone(); acc_ref += ref[first * H:]
+    acc = acc0.clone()
+    got = ops.attention_probs(qh.cuda(), kh.cuda(), B, H, Nq, Nk2, d, d ** -0.5, acc=acc, self_from_base=True, first_cond_sample=first, **kw)
+    assert torch.equal(got, ref) and torch.equal(acc, acc_ref)
+
+
 def test_flash_attention_ring_is_bit_identical_to_a_fully_fenced_build():
     """The flash kernels hand tiles over with a counted s_waitcnt vmcnt(N) + a bare s_barrier (attention.hip wait_landed); a miscounted
     ring would read LDS rows that have not landed.  tools/attn_ring_check.py builds attention.hip again with a full fence at every tile

@@ -390,3 +390,63 @@ def test_ddim_baseline_loops_match_oracle():
     print(f"[sd15 DDIM baseline] reverse (CFG 7.5, 3 steps) rel-L2 = {e_rev:.3e}  forward (3 steps) = {e_fwd:.3e}")
     assert len(outs) == len(outs_f) == 4
     assert e_rev < 3e-3 and e_fwd < 2e-3
+
+
+@pytest.mark.parametrize("kind", ["store", "replace", "refine_reweight_blend"])
+def test_fused_probability_epilogue_matches_the_separate_passes_bit_for_bit(kind):
+    """Section 8(f) rank 2 as written: for the reference's shipped controllers the edit operator, the self-attention replacement and
+    store += P ride in the probability kernel's epilogue (icd_probs_epilogue via the hook's phase 2; p2p.HookAdapter) - one pass over P on
+    hooked layers.  The same loop with `controller.fused_epilogue = False` (probabilities -> icd_p2p_cross_edit / row copy -> P.V, one
+    accumulate launch per step) must give the same bits: latents of every step and every stored tensor.  The executor's launch records show
+    that the fused run issued no accumulate / edit pass of its own."""
+    E = _env()
+    p2p = E["p2p"]
+    from invertible_cd_amd import p2p as P
+    B, H, W = (3, 32, 32) if kind == "store" else (2, 32, 32)
+    cfg, sd, lat, ctx, model, solver = _sd15_setup(E, B, H, W, seed=23)
+    p2p.tokenizer = E["synthetic"].SyntheticTokenizer()
+    p2p.NUM_DDIM_STEPS = 4
+    prompts = ["a cat sitting on a bench", "a dog sitting on a bench"]
+
+    def make():
+        if kind == "store":
+            return p2p.AttentionStore()
+        p2p.device = "cuda"
+        try:
+            if kind == "replace":
+                return p2p.make_controller(prompts, True, 0.5, 0.5)
+            return p2p.make_controller(prompts, False, {"default_": 0.6, "dog": (0.0, 0.3)}, 0.4, blend_words=(("cat",), ("dog",)),
+                                       equilizer_params={"words": ("dog",), "values": (2.0,)})
+        finally:
+            p2p.device = "cpu"
+
+    results = []
+    for fused in (True, False):
+        ctrl = make()
+        ctrl.fused_epilogue = fused
+        p2p.register_attention_control(model, ctrl)
+        seen = {"epi": 0}
+        orig = P.HookAdapter._plan_epilogue
+
+        def counting(self, *a, **k):
+            e = orig(self, *a, **k)
+            seen["epi"] += e is not None
+            return e
+        P.HookAdapter._plan_epilogue = counting
+        try:
+            outs = solver.cons_generation(lat.cuda(), guidance_scale=19.0 if kind != "store" else 7.0, w_embed_dim=512,
+                                          dynamic_guidance=kind != "store", tau1=0.8, tau2=0.8, controller=ctrl)
+        finally:
+            P.HookAdapter._plan_epilogue = orig
+        torch.cuda.synchronize()
+        results.append((outs, {k: [t.clone() for t in v] for k, v in ctrl.attention_store.items()}, seen["epi"], ctrl.cur_step))
+        p2p.register_attention_control(model, None)
+    (o1, s1, n1, c1), (o0, s0, n0, c0) = results
+    print(f"[fused epilogue, {kind}] layers with an epilogue: fused run {n1}, separate passes {n0}")
+    assert c1 == c0 == 4 and n0 == 0
+    assert n1 >= (3 * 32 if kind == "store" else 4 * 16)          # store: every layer of steps 2-4; edits: at least every cross layer
+    for a, b in zip(o1, o0):
+        assert torch.equal(a, b)
+    assert s1.keys() == s0.keys()
+    for k in s1:
+        assert len(s1[k]) == len(s0[k]) and all(torch.equal(a, b) for a, b in zip(s1[k], s0[k])), k

@@ -80,6 +80,9 @@ def parse():
     ap.add_argument("--residual", type=int, default=None, choices=[0, 1, 2, 3],
                     help="override the policy with a fixed UNet option residual: 0 = plain fp16 stream (rounds 1-3); 1 = fp32 twin; 2 = fp16 + bf8 "
                          "error carry; 3 = carry + split consumers")
+    ap.add_argument("--no-fused-epilogue", action="store_true",
+                    help="edit leg: accumulate the attention store with a launch of its own per hooked layer instead of in the probability "
+                         "kernel's epilogue (A/B of icd_probs_epilogue)")
     ap.add_argument("--attn-valu-scale", type=int, default=0, choices=[0, 1],
                     help="A/B switch (UNet option attn_valu_scale): 1 = flash attention applies the softmax offset with an FMA per score "
                          "on the VALU, 0 (default) = the MFMA subtracts it")
@@ -119,6 +122,7 @@ def spawn_ranks(a, argv):
 class SD15Workload:
     """Full-width SD1.5 + fused LoRA behind generation.Generator: BASELINE configs[1] (reverse, B = 32) and configs[2] (inversion +
     reverse with p2p.AttentionStore, B = 8) share one set of weights."""
+    fused_epilogue = True            # --no-fused-epilogue clears it: store += P as launches of its own
 
     def __init__(self, device, net=None):
         from invertible_cd_amd import generation, synthetic, unet
@@ -172,6 +176,7 @@ class SD15Workload:
             self.solver.context = ctx
             start = self.solver.cons_inversion(latents, guidance_scale=0.0, w_embed_dim=512, seed=5)[1][0]
             ctrl = p2p.AttentionStore()
+            ctrl.fused_epilogue = self.fused_epilogue
             p2p.register_attention_control(self.model, ctrl)
             try:
                 out = self.solver.cons_generation(start, guidance_scale=19.0, w_embed_dim=512, dynamic_guidance=True, tau1=0.8, tau2=0.8,
@@ -654,6 +659,8 @@ def run_edit(a, wl, arch, batch, steps, warmup, device, world, rank):
     """BASELINE configs[2] (SD1.5: 4-step inversion + 4-step reverse with p2p.AttentionStore, 8 images / GPU) and configs[4]'s per-GPU
     share (SDXL: 3 + 3 steps, dynamic guidance tau 0.7, 16 images / GPU): edited images / s, no events in the timed region."""
     set_precision(a, wl.net)
+    if a.no_fused_epilogue:
+        type(wl).fused_epilogue = False
     step = wl.edit_step(batch)
     n_fl = a.in_flight_edit if arch == "sd15" else a.in_flight
     group = workload_group(wl, n_fl)
@@ -695,7 +702,9 @@ def run_edit(a, wl, arch, batch, steps, warmup, device, world, rank):
                                    "128x128 latents, timesteps fwd [19,339,699] rev [999,699,339]"),
                       "per_gpu_batch": batch, "global_batch": batch * world, "unet_evals_per_step": evals, "parallelism": f"dp{world}",
                       "in_flight_batches": len(flight),
-                      "precision": precision_of(a, wl.net)},
+                      "precision": precision_of(a, wl.net),
+                      **({"attention_store_accumulate": "probability kernel epilogue" if getattr(wl, "fused_epilogue", False) else
+                          "one accumulate launch per hooked layer"} if arch == "sd15" else {})},
            "end_to_end_algorithmic_tflops_per_gpu": round(value / world * algo / 1e12, 1),
            "end_to_end_frac_of_mfma_peak": round(value / world * algo / PEAK_MFMA_F16, 4)}
     if arch == "sd15":

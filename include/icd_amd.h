@@ -373,12 +373,11 @@ typedef struct icd_unet icd_unet;
  * place: 0 down, 1 mid, 2 up.  P layout: [bh = B*heads (row b*heads+h), nq, ld] with nk valid columns. */
 #define ICD_HOOK_QUERY 0
 #define ICD_HOOK_PROBS 1
-/*   phase 0 may also return 2: materialise P as for 1, AND the hook has an epilogue for the probability kernel (round 5).  The executor then
- *            calls phase 2 (ICD_HOOK_EPILOGUE) once: the hook stores in *probs a pointer to an icd_probs_epilogue that stays valid until
- *            its phase-1 call of this layer returns (first_cond_row in rows of P; first_cond_sample ignored), and returns 1 (0: none after
- *            all).  What the epilogue did - store accumulation, self-attention replacement, the cross-attention edit - the hook must
- *            not repeat in phase 1.  Hooks that never return 2 never see phase 2. */
-#define ICD_HOOK_EPILOGUE 2
+/*   In phase 0 `probs` points at TWO slots (round 5): [0] the P buffer as above, [1] optionally a pointer to an icd_probs_epilogue for this
+ *            layer call (copied before the call returns; first_cond_row in rows of P, first_cond_sample ignored) - the controller's work
+ *            on P that the probability kernel performs in its epilogue: store accumulation, self-attention replacement, the
+ *            cross-attention edit.  The hook must not repeat that work in phase 1.  Hooks that leave slot 1 alone get the plain kernel;
+ *            in phase 1 `probs` points at one slot. */
 typedef int (*icd_attn_hook)(void* user, int32_t phase, int32_t layer, int32_t is_cross, int32_t place, int64_t bh,
                              int64_t nq, int64_t nk, int64_t ld, void** probs);
 

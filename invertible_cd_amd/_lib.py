@@ -33,7 +33,6 @@ ICD_ATTN_Q_PRESCALED = 2
 ICD_ATTN_TUNE_MODE0 = 4
 ICD_HOOK_QUERY = 0
 ICD_HOOK_PROBS = 1
-ICD_HOOK_EPILOGUE = 2
 
 
 class GemmDesc(C.Structure):

@@ -766,7 +766,7 @@ struct ProbsEpi {
     int b0, self_base;
 };
 
-template <int KS, bool SPLIT = false, bool EPI = false>
+template <int KS, bool SPLIT = false, int EPI = 0, bool FEW = false>     // EPI: 0 none, 1 store += P / self replacement, 2 also the cross edit
 __global__ __launch_bounds__(256, 2) void attn_probs_kernel(ProbsK a, ProbsEpi ep) {
     __shared__ __attribute__((aligned(16))) half_t patch_all[4][32 * 72];
     const int tid = threadIdx.x, l = tid & 63, lr = l & 31, lh = l >> 5;
@@ -850,7 +850,19 @@ __global__ __launch_bounds__(256, 2) void attn_probs_kernel(ProbsK a, ProbsEpi e
             *reinterpret_cast<f16x8*>(patch + lr * 72 + (kt & 1) * 32 + 16 * j + 8 * lh) = o;
         }
     };
-    auto flush = [&](int kt_first, int ncols) {                                // patch columns [0, ncols) are keys 32*kt_first ...
+    // store += P rides in the flush; its read of the accumulator is requested a k-tile pair ahead (acc_fetch), so the round trip to HBM
+    // sits under the scores / exponentials of the pair and not between the patch read and the two stores
+    struct AccRows { f16x8 t[4]; };
+    auto acc_fetch = [&](AccRows& ar, int kt_first, int ncols) {
+        if (!(EPI && Ab)) return;
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            const int r = pass * 8 + (l >> 3), c8 = (l & 7) * 8;
+            const int col = kt_first * 32 + c8;
+            if (c8 < ncols && col < a.ldp && q0 + r < a.Nq) ar.t[pass] = *reinterpret_cast<const f16x8*>(Ab + (long long)r * a.ldp + col);
+        }
+    };
+    auto flush = [&](int kt_first, int ncols, const AccRows& ar) {             // patch columns [0, ncols) are keys 32*kt_first ...
 #pragma unroll
         for (int pass = 0; pass < 4; ++pass) {
             const int r = pass * 8 + (l >> 3), c8 = (l & 7) * 8;
@@ -859,19 +871,17 @@ __global__ __launch_bounds__(256, 2) void attn_probs_kernel(ProbsK a, ProbsEpi e
                 const f16x8 v = *reinterpret_cast<const f16x8*>(patch + r * 72 + c8);
                 *reinterpret_cast<f16x8*>(Pb + (long long)r * a.ldp + col) = v;
                 if (EPI && Ab) {                                               // store += P (torch's fp16 in-place add)
-                    half_t* ap = Ab + (long long)r * a.ldp + col;
-                    const f16x8 t = *reinterpret_cast<const f16x8*>(ap);
                     f16x8 o;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)t[e] + (float)v[e]);
-                    *reinterpret_cast<f16x8*>(ap) = o;
+                    for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)ar.t[pass][e] + (float)v[e]);
+                    *reinterpret_cast<f16x8*>(Ab + (long long)r * a.ldp + col) = o;
                 }
             }
         }
     };
     const int nt = (a.ldp + 31) >> 5;                      // k-tiles incl. the pad columns (they are written as zeros)
-    if (nt <= 3) {
-        // ---- few keys (cross-attention): all S^T tiles in registers, exact softmax ----
+    if constexpr (FEW) {
+        // ---- few keys (cross-attention, <= 96 key slots; the host picks the instantiation): all S^T tiles in registers, exact softmax ----
         auto probs3 = [&](f32x16 (&s)[3], const f16x8 (&qq)[KF], int bs) {
             float mx = -INFINITY;
 #pragma unroll
@@ -900,9 +910,11 @@ __global__ __launch_bounds__(256, 2) void attn_probs_kernel(ProbsK a, ProbsEpi e
         };
         f32x16 s[3];
         probs3(s, qf, bq);
-        const bool edit = EPI && ep.At != nullptr && jp > 0;
+        AccRows ar;
+        acc_fetch(ar, 0, nt >= 2 ? 64 : 32);
+        const bool edit = EPI == 2 && ep.At != nullptr && jp > 0;
         f16x8 pb[5];                                       // the base prompt's probabilities of this query tile as the MFMA B operand
-        if (EPI && edit) {
+        if (EPI == 2 && edit) {
             f16x8 qb[KF];
             load_q(qb, ep.b0);
             f32x16 sb[3];
@@ -916,7 +928,7 @@ __global__ __launch_bounds__(256, 2) void attn_probs_kernel(ProbsK a, ProbsEpi e
         for (int kt = 0; kt < 3; ++kt) {
             if (kt < nt) {
                 emit(s[kt], kt);
-                if (EPI && edit) {
+                if (EPI == 2 && edit) {
                     // new[n] = sum_w At[n][w] base[w] + D[n] cur[n] for the 32 tokens of this tile; cur comes back from the patch in
                     // the accumulator layout (row lr, tokens 8g + 4lh .. +3)
                     const half_t* Ae = ep.At + (long long)(jp - 1) * (96 * 80);
@@ -940,11 +952,13 @@ __global__ __launch_bounds__(256, 2) void attn_probs_kernel(ProbsK a, ProbsEpi e
                         *reinterpret_cast<f16x4*>(pp) = o;
                     }
                 }
-                if ((kt & 1) || kt == nt - 1) flush(kt & ~1, (kt & 1) ? 64 : 32);
+                if ((kt & 1) || kt == nt - 1) {
+                    flush(kt & ~1, (kt & 1) ? 64 : 32, ar);
+                    if (kt == 1 && nt == 3) acc_fetch(ar, 2, 32);
+                }
             }
         }
-        return;
-    }
+    } else {
     // ---- many keys: sweep 1 = running row maximum and sum, sweep 2 = probabilities ----
     float m_run = -INFINITY, l_run = 0.f;
     {
@@ -990,6 +1004,8 @@ __global__ __launch_bounds__(256, 2) void attn_probs_kernel(ProbsK a, ProbsEpi e
         load_k(ka, 0);
         for (int kt = 0; kt < nt; kt += 2) {
             if (kt + 1 < nt) load_k(kb, kt + 1);
+            AccRows ar;
+            acc_fetch(ar, kt, kt + 1 < nt ? 64 : 32);
             f32x16 s;
             scores(s, ka, kt);
 #pragma unroll
@@ -1001,9 +1017,10 @@ __global__ __launch_bounds__(256, 2) void attn_probs_kernel(ProbsK a, ProbsEpi e
 #pragma unroll
                 for (int e = 0; e < 16; ++e) s[e] = __builtin_amdgcn_exp2f(s[e] - m_run) * inv;
                 emit(s, kt + 1);
-                flush(kt, 64);
-            } else flush(kt, 32);
+                flush(kt, 64, ar);
+            } else flush(kt, 32, ar);
         }
+    }
     }
 }
 
@@ -1076,15 +1093,17 @@ static int attention_probs_run(const void* q, const void* qc, const void* k, con
     const bool use_epi = ep.acc || ep.At || ep.self_base;
     const dim3 grid((unsigned)((Nq + 127) / 128), (unsigned)(B * H));
     hipStream_t st = (hipStream_t)stream;
-#define ICD_PROBS(SP, EP)                                                                                     \
+#define ICD_PROBS(SP, EP, FW)                                                                                  \
     do {                                                                                                      \
-        if (d <= 48) hipLaunchKernelGGL((attn_probs_kernel<3, SP, EP>), grid, dim3(256), 0, st, a, ep);       \
-        else if (d <= 80) hipLaunchKernelGGL((attn_probs_kernel<5, SP, EP>), grid, dim3(256), 0, st, a, ep);  \
-        else if (d <= 128) hipLaunchKernelGGL((attn_probs_kernel<8, SP, EP>), grid, dim3(256), 0, st, a, ep); \
-        else hipLaunchKernelGGL((attn_probs_kernel<10, SP, EP>), grid, dim3(256), 0, st, a, ep);              \
+        if (d <= 48) hipLaunchKernelGGL((attn_probs_kernel<3, SP, EP, FW>), grid, dim3(256), 0, st, a, ep);       \
+        else if (d <= 80) hipLaunchKernelGGL((attn_probs_kernel<5, SP, EP, FW>), grid, dim3(256), 0, st, a, ep);  \
+        else if (d <= 128) hipLaunchKernelGGL((attn_probs_kernel<8, SP, EP, FW>), grid, dim3(256), 0, st, a, ep); \
+        else hipLaunchKernelGGL((attn_probs_kernel<10, SP, EP, FW>), grid, dim3(256), 0, st, a, ep);              \
     } while (0)
-    if (qc || kc) { if (use_epi) ICD_PROBS(true, true); else ICD_PROBS(true, false); }
-    else { if (use_epi) ICD_PROBS(false, true); else ICD_PROBS(false, false); }
+#define ICD_PROBS2(SP, EP) do { if (ldp <= 96) ICD_PROBS(SP, EP, true); else ICD_PROBS(SP, EP, false); } while (0)
+    if (qc || kc) { if (ep.At) ICD_PROBS(true, 2, true); else if (use_epi) ICD_PROBS2(true, 1); else ICD_PROBS2(true, 0); }
+    else { if (ep.At) ICD_PROBS(false, 2, true); else if (use_epi) ICD_PROBS2(false, 1); else ICD_PROBS2(false, 0); }
+#undef ICD_PROBS2
 #undef ICD_PROBS
     ICD_CHECK_LAUNCH("icd_attention_probs");
     return ICD_OK;

@@ -381,15 +381,12 @@ struct Exec {
         const long long ldp = (Nk + 7) / 8 * 8;
         if (dry) a.mat = probs_mode == 2 || (probs_mode == 1 && (is_cross || Nq <= 1024));
         else if (io->hook && ok()) {
-            const int r = io->hook(io->hook_user, ICD_HOOK_QUERY, a.layer, is_cross, place, (long long)B * heads, Nq, Nk, ldp, &a.probs);
+            void* slots[2] = {nullptr, nullptr};     // [0] the P buffer, [1] an icd_probs_epilogue of this layer call (optional)
+            const int r = io->hook(io->hook_user, ICD_HOOK_QUERY, a.layer, is_cross, place, (long long)B * heads, Nq, Nk, ldp, slots);
             if (r < 0) { icd_set_error("attention hook (query) failed at layer %d", a.layer); status = ICD_ERR_HOOK; return a; }
             a.mat = r >= 1;
-            if (r == 2) {                            // the hook has an epilogue for the probability kernel (icd_probs_epilogue)
-                void* e = nullptr;
-                const int r2 = io->hook(io->hook_user, ICD_HOOK_EPILOGUE, a.layer, is_cross, place, (long long)B * heads, Nq, Nk, ldp, &e);
-                if (r2 < 0) { icd_set_error("attention hook (epilogue) failed at layer %d", a.layer); status = ICD_ERR_HOOK; return a; }
-                if (r2 == 1 && e) { a.epi = *(const icd_probs_epilogue*)e; a.has_epi = true; }
-            }
+            a.probs = slots[0];
+            if (a.mat && slots[1]) { a.epi = *(const icd_probs_epilogue*)slots[1]; a.has_epi = true; }
             if (a.mat && !a.probs) { icd_set_error("attention hook returned 1 without a probability buffer (layer %d)", a.layer); status = ICD_ERR_HOOK; }
         }
         return a;

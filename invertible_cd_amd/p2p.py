@@ -235,6 +235,7 @@ class AttentionStore(AttentionControl):
         self.step_store = self.get_empty_store()
         self.attention_store = {}
         self._fused_acc = set()
+        self._epi_acc_ok = {}
 
 
 class AttentionControlEdit(AttentionStore, abc.ABC):
@@ -456,7 +457,7 @@ class HookAdapter:
 
     def _plan_epilogue(self, is_cross, place, bh, nq, nk, ld):
         """icd_probs_epilogue of this layer call, or None: which of the controller's operations on P the kernel performs itself."""
-        from . import _lib, ops
+        from . import _lib
         c = self.c
         self._epi_refs, self._epi_acc_key, self._epi_edit = None, None, False
         first = 0 if self.cond_only else bh // 2
@@ -483,9 +484,14 @@ class HookAdapter:
             acc = c.attention_store.get(key, [])
             if idx < len(acc):
                 t = acc[idx]
-                if (t.is_cuda and t.dtype == torch.float16 and tuple(t.shape) == (rows, nq, nk) and t.stride() == (nq * ld, ld, 1)
-                        and t.data_ptr() % 16 == 0):
-                    epi.acc = t.data_ptr()
+                seen = c.__dict__.setdefault("_epi_acc_ok", {})      # geometry checked once per stored tensor, not once per step
+                ok = seen.get((key, idx))
+                if ok is None or ok[0] is not t:
+                    ok = (t, t.is_cuda and t.dtype == torch.float16 and tuple(t.shape) == (rows, nq, nk) and t.stride() == (nq * ld, ld, 1)
+                          and t.data_ptr() % 16 == 0, t.data_ptr() if t.is_cuda else 0)
+                    seen[(key, idx)] = ok
+                if ok[1]:
+                    epi.acc = ok[2]
                     refs.append(t)
                     self._epi_acc_key = (key, idx)
         if not (self._epi_edit or self._epi_acc_key):

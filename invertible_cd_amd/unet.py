@@ -414,11 +414,8 @@ class UNet2DConditionModel:
                         return 0
                     live.append(buf)
                     probs_pp[0] = buf.data_ptr()
-                    return 2 if adapter.epilogue is not None else 1        # 2: the controller's work on P rides in the kernel's epilogue
-                if phase == _lib.ICD_HOOK_EPILOGUE:
-                    if adapter.epilogue is None:
-                        return 0
-                    probs_pp[0] = C.addressof(adapter.epilogue)
+                    if adapter.epilogue is not None:         # the controller's work on P rides in the kernel's epilogue
+                        probs_pp[1] = C.addressof(adapter.epilogue)
                     return 1
                 adapter.probs_ready(layer, bool(is_cross), PLACES[place])
                 return 0

@@ -61,6 +61,8 @@ def parse():
     ap.add_argument("--xattn-fusion", type=int, default=2, choices=[0, 1, 2],
                     help="A/B switch (UNet option xattn_fusion): 2 = fused query-projection + cross-attention launch where it measured "
                          "faster (default), 0 = never, 1 = wherever eligible")
+    ap.add_argument("--xattn-tile", type=int, default=0, choices=[0, 2, 4, 5, 6],
+                    help="A/B: host tile of the fused cross-attention launch (0 planner, 5 = 256 x 256, 6 = 192 x 256 per sample)")
     ap.add_argument("--ln-inline-stats", type=int, default=1, choices=[0, 1],
                     help="A/B switch (UNet option ln_inline_stats): 1 = the GEMM behind a LayerNorm computes its statistics (default), "
                          "0 = a separate statistics pass over the residual stream")
@@ -470,7 +472,7 @@ def run_reverse(a, wl, arch, batch, steps, warmup, device, world, rank, primary)
     import torch.distributed as dist
     from invertible_cd_amd import dist_utils
     wl.net.set_option("ln_inline_stats", a.ln_inline_stats).set_option("xattn_fusion", a.xattn_fusion)     # per-handle A/B switches
-    wl.net.set_option("attn_valu_scale", a.attn_valu_scale)
+    wl.net.set_option("attn_valu_scale", a.attn_valu_scale).set_option("xattn_tile", a.xattn_tile)
     set_precision(a, wl.net)
     step = wl.reverse_step(batch)
     group = workload_group(wl, a.in_flight)              # this workload + its replicas (same weights, own handle / arena / stream)

@@ -122,7 +122,7 @@ typedef struct {
     /* Tuning and diagnostics travel with the call - the library keeps no process-wide GEMM state.  Zero / NULL: defaults.
      * None of them changes a result beyond fp32 summation order. */
     int32_t tune_group_m;     /* m-tiles per L2 group of the block -> tile map (0: the planner's choice) */
-    int32_t tune_xattn_tile;  /* host tile of the fused query-projection + cross-attention launch: 0 planner, 2 = 128 x 128, 4 = 256 x 128 */
+    int32_t tune_xattn_tile;  /* host tile of the fused query-projection + cross-attention launch: 0 planner, 2 = 128 x 128, 4 = 256 x 128, 5 = 256 x 256, 6 = 192 x 256 */
     void* debug_timeline;     /* device buffer of 8 x uint64 per block: every block of this launch stamps s_memrealtime (100 MHz) at */
                               /* start, first k-tile landed, main loop done, epilogue done (+ s_memtime ticks of the main loop)     */
     /* Second output for the fp32 twin of the residual stream (icd_unet option ICD_UNET_OPT_RESIDUAL_MODE = ICD_RESIDUAL_F32): the SAME values as `out` before the
@@ -396,7 +396,7 @@ int32_t icd_unet_num_attention_layers(const icd_unet* u);
  *   ICD_UNET_OPT_LN_INLINE_STATS  1 (default): the first GEMM behind every LayerNorm computes the statistics itself
  *       (ICD_GEMM_LN_COMPUTE); 0: a separate icd_layernorm_stats pass over the residual stream.  Statistics agree to ~1e-6.
  *   ICD_UNET_OPT_XATTN_TILE     A/B tuning of the fused launch's host tile (icd_gemm_desc.tune_xattn_tile): 0 (default) planner,
- *       2 = 128 x 128, 4 = 256 x 128.
+ *       2 = 128 x 128, 4 = 256 x 128, 5 = 256 x 256, 6 = 192 x 256 (six m-tiles per 1024-query sample).
  *   ICD_UNET_OPT_ATTN_VALU_SCALE  A/B: 1 = the flash attention kernels apply the softmax offset with one FMA per score on the VALU
  *       (ICD_ATTN_TUNE_MODE0), 0 (default) = the MFMA subtracts it (head dims 40 / 64 / 80).  Same arithmetic up to fp32 rounding.
  *   ICD_UNET_OPT_RESIDUAL_MODE  precision of the residual stream.  Every chain x <- x + f(x) of the UNet (ResnetBlock2D conv2 + input /

@@ -826,12 +826,20 @@ static int gemm_run(const icd_gemm_desc* d, void* stream, icd_gemm_plan_info* in
         // 67.3 / 109.9 us); the 256-row tile stays available for tuning
         // ... and since the 256 x 256 tile of gemm_big.hip hosts it (a block = 256 queries x 4 heads, K / V^T staged once in the
         // idle operand stages): the fast GEMM tile under the same epilogue, LayerNorm statistics from its own main loop
-        if (g_xattn_tile == 0 && d->N % 256 == 0 && (long long)(d->M / 256) * (d->N / 256) >= 32) {
-            k.nbm = d->M / 256; k.nbn = d->N / 256;
+        if ((g_xattn_tile == 0 || g_xattn_tile == 5 || g_xattn_tile == 6) && d->N % 256 == 0 && (long long)(d->M / 256) * (d->N / 256) >= 32) {
+            // 256 or 192 query rows per block: the 192-row tile lays ceil(rps / 192) m-tiles over every sample (the last one partial), which
+            // turns the 160 blocks of SDXL's 1024-token layers at 8 images per GPU into 240 - one round on 256 CUs either way, of blocks
+            // with 3/4 of the work.  Whichever needs less (rounds x rows per block); tune_xattn_tile 5 / 6 force 256 / 192 (A/B)
+            const long long nb = d->N / 256, b256 = (long long)(d->M / 256) * nb;
+            const int bps192 = (d->rows_per_sample + 191) / 192;
+            const long long b192 = (long long)(d->M / d->rows_per_sample) * bps192 * nb;
+            const long long t256 = (b256 + 255) / 256 * 256, t192 = (b192 + 255) / 256 * 192;
+            const bool t192_wins = g_xattn_tile == 6 || (g_xattn_tile == 0 && t192 < t256);
+            k.nbm = t192_wins ? (d->M / d->rows_per_sample) * bps192 : d->M / 256; k.nbn = d->N / 256;
             if (ln_compute && k.nbn <= 12 && !(d->flags & ICD_GEMM_TUNE_NO_LN_INLINE)) k.ln_stats_w = const_cast<float*>(d->ln_stats);
             else { const int rc = ln_stats_launch(); if (rc != ICD_OK) return rc; }
-            if (plan_is(1, 256, 256, 1)) return ICD_OK;
-            return launch_big(k, 100, (hipStream_t)stream);
+            if (plan_is(1, t192_wins ? 192 : 256, 256, 1)) return ICD_OK;
+            return launch_big(k, t192_wins ? 101 : 100, (hipStream_t)stream);
         }
         const bool big = g_xattn_tile == 4;
         k.nbm = d->M / (big ? 256 : 128); k.nbn = d->N / 128;

@@ -37,12 +37,12 @@ static_assert(XA_SMEM <= 160 * 1024, "fused cross-attention: LDS budget");
 // wave-uniform run-time branch the same skip made hipcc spill 54 registers (round 2).
 template <int TM, int STL = 6>
 __device__ __forceinline__ void xattn_epilogue_big(const GemmK& p, f32x16 (&acc)[TM][2], unsigned char* smem, int wv, int wm, int wn,
-                                                   int l, int m0, int n0, const float* ln_lds) {
+                                                   int l, int m0, int m_lim, int n0, const float* ln_lds) {
     constexpr int KT = 3, KS = 4, ST = 6, DT = 2;
     static_assert(STL == 5 || STL == 6, "live key slots");
     const int lr = l & 31, lh = l >> 5, tid = threadIdx.x;
     const int key_lim = p.x_nk - 8 * lh;                   // key slot constant c of this lane is masked when c >= key_lim
-    const int b = m0 / p.rps;                              // the 256 rows of a block lie inside one sample
+    const int b = m0 / p.rps;                              // the rows [m0, m_lim) of a block lie inside one sample
     // ---- stage K [96 keys][256 dims] and V^T [256 dims][96 keys] of the block's 4 heads (the caller's barrier freed the stages)
     {
         const half_t* Kb = p.xk + (long long)b * p.x_nk * p.x_ldk + n0;
@@ -82,7 +82,7 @@ __device__ __forceinline__ void xattn_epilogue_big(const GemmK& p, f32x16 (&acc)
             lst[i] = (f32x2){0.f, 1.f};
             if (p.ln_stats) {
                 if (ln_lds) lst[i] = *reinterpret_cast<const f32x2*>(ln_lds + 2 * (mrow + lr - m0));
-                else lst[i] = *reinterpret_cast<const f32x2*>(p.ln_stats + 2 * (long long)(mrow + lr));
+                else if (TM == 4 || mrow + lr < m_lim) lst[i] = *reinterpret_cast<const f32x2*>(p.ln_stats + 2 * (long long)(mrow + lr));
             }
         }
 #pragma unroll
@@ -103,13 +103,13 @@ __device__ __forceinline__ void xattn_epilogue_big(const GemmK& p, f32x16 (&acc)
                     }
             }
     }
-    static_assert(TM % 2 == 0, "query tiles are processed in pairs");
-#pragma unroll
-    for (int i0 = 0; i0 < TM; i0 += 2) {
+    // NI query tiles (two, or the odd one left of a 96-query wave) from tile I0 on
+    auto tiles = [&](auto ni_tag, auto i0_tag) {
+        constexpr int NI = decltype(ni_tag)::value, i0 = decltype(i0_tag)::value;
         // ---- 2. S^T = K q^T for two query tiles on ONE set of K fragments (24 reads in flight instead of 24 exposed latencies
         //         per tile), exact softmax over the <= 96 key slots ----
-        f16x8 pf[2][ST];
-        float inv[2];
+        f16x8 pf[NI][ST];
+        float inv[NI];
         {
             f16x8 kf[KT][KS];
 #pragma unroll
@@ -121,7 +121,7 @@ __device__ __forceinline__ void xattn_epilogue_big(const GemmK& p, f32x16 (&acc)
                     kf[kt][ks] = (f16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                 }
 #pragma unroll
-            for (int ii = 0; ii < 2; ++ii) {
+            for (int ii = 0; ii < NI; ++ii) {
                 f32x16 sc[KT];
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks)
@@ -163,7 +163,7 @@ __device__ __forceinline__ void xattn_epilogue_big(const GemmK& p, f32x16 (&acc)
         // ---- 3. O^T = V^T P^T (V^T fragments from LDS as they are used: holding them too makes hipcc spill); O leaves through the
         //         wave's LDS patch ----
 #pragma unroll
-        for (int ii = 0; ii < 2; ++ii) {
+        for (int ii = 0; ii < NI; ++ii) {
             const int mrow = m0 + (wm * TM + i0 + ii) * 32;
             f32x16 o[DT];
 #pragma unroll
@@ -187,10 +187,16 @@ __device__ __forceinline__ void xattn_epilogue_big(const GemmK& p, f32x16 (&acc)
             for (int pass = 0; pass < 4; ++pass) {
                 const int r = pass * 8 + (l >> 3), c8 = (l & 7) * 8;
                 const f16x8 v = *reinterpret_cast<const f16x8*>(patch + r * 72 + c8);
-                *reinterpret_cast<f16x8*>(out + (long long)(mrow + r) * p.ldo + ncol + c8) = v;
+                if (TM == 4 || mrow + r < m_lim) *reinterpret_cast<f16x8*>(out + (long long)(mrow + r) * p.ldo + ncol + c8) = v;
             }
         }
-    }
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    tiles(I2{}, I0{});
+    if constexpr (TM == 4) tiles(I2{}, I2{});
+    if constexpr (TM == 3) tiles(I1{}, I2{});
 }
 
 #ifndef ICD_CONV_CHUNK_MAJOR
@@ -214,7 +220,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_big_kernel(GemmK p) {
     // past the epilogue's staging patches (8 x 9 KiB), inside the stage buffers; the fused cross-attention epilogue has its own map
     constexpr int LN_TABLE_OFF = XATTN ? XA_TABLE_OFF : 96 * 1024;
     static_assert(XATTN || LN_TABLE_OFF + (1 + WN) * BM * 8 <= 2 * STAGE_BYTES, "LayerNorm table does not fit");
-    static_assert(!XATTN || (MODE == 0 && WM == 2 && WN == 4 && TN == 2), "fused cross-attention: 256 x 256 tile, a wave per head");
+    static_assert(!XATTN || (MODE == 0 && WM == 2 && WN == 4 && TN == 2 && (TM == 4 || TM == 3)), "fused cross-attention: 256 / 192 x 256 tile, a wave per head");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, wv = tid >> 6, l = tid & 63;
     const int wm = wv / WN, wn = wv - wm * WN;
@@ -223,7 +229,13 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_big_kernel(GemmK p) {
 
     int mt, nt;
     tile_of_block(blockIdx.x, p.nbm, p.nbn, p.gm, mt, nt);
-    const int m0 = mt * BM, n0 = nt * BNt;
+    int m0 = mt * BM, m_lim = p.M;
+    const int n0 = nt * BNt;
+    if constexpr (XATTN) {                       // m-tiles are laid out per sample: ceil(rps / BM) of them, the last one possibly partial
+        const int bps = (p.rps + BM - 1) / BM, smp = mt / bps;
+        m0 = smp * p.rps + (mt - smp * bps) * BM;
+        m_lim = (smp + 1) * p.rps;
+    }
     const int split = blockIdx.y;
     const int nk_total = (p.K + BK - 1) / BK;
     const int kt_begin = split * p.kt_per_split;
@@ -262,7 +274,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_big_kernel(GemmK p) {
         const int m = m0 + r;
         const int boff = (j & 3) * 512;          // bias for the instruction's immediate offset (halves)
         a_ptr[j] = zero - boff; a_inc[j] = 0; a_pix[j] = 0; a_nmsk[j] = 0x1ff; a_off[j] = 0; a_voff[j] = 0x80000000u;
-        if (m < p.M) {
+        if (m < m_lim) {
             if (MODE == 0) {
                 a_ptr[j] = p.a0 + (long long)m * p.lda + k_begin + lc * 8 - boff; a_inc[j] = BK;
             } else {
@@ -524,7 +536,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_big_kernel(GemmK p) {
                 // One-pass variance: E[x^2] - mean^2 loses ~ (1 + mean^2 / var) x 1e-6 of relative accuracy.  Rows whose offset
                 // dominates their spread (|mean| > 4 sigma: not seen on zero-centred transformer activations, but a row is a row)
                 // take the exact second pass instead - sum (x - mean)^2 in fp32 over the row, which the tile just streamed through L2.
-                if (mean * mean > 16.f * var && m0 + row < p.M) {
+                if (mean * mean > 16.f * var && m0 + row < m_lim) {
                     const half_t* ar = p.a0 + (long long)(m0 + row) * p.lda;
                     float acc2 = 0.f;
                     for (int kk = 0; kk < p.K; kk += 8) {
@@ -536,7 +548,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_big_kernel(GemmK p) {
                 }
                 const float rstd = rsqrtf(var + p.ln_eps);
                 *reinterpret_cast<f32x2*>(table + 2 * row) = (f32x2){mean, rstd};
-                if (nt == 0 && m0 + row < p.M) *reinterpret_cast<f32x2*>(p.ln_stats_w + 2 * (long long)(m0 + row)) = (f32x2){mean, rstd};
+                if (nt == 0 && m0 + row < m_lim) *reinterpret_cast<f32x2*>(p.ln_stats_w + 2 * (long long)(m0 + row)) = (f32x2){mean, rstd};
             }
         }
         ln_lds = table;                          // indexed by row - m0 (the epilogue's own barrier publishes it)
@@ -549,7 +561,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_big_kernel(GemmK p) {
         if (tl && tid == 0) tl[2] = __builtin_amdgcn_s_memrealtime();
         // (XATTN kernels know no error carry: their CARRY flag selects the five-slot epilogue - one instantiation each, because both
         //  epilogues in ONE kernel made hipcc spill 83 registers)
-        xattn_epilogue_big<TM, CARRY ? 5 : 6>(p, acc, smem, wv, wm, wn, l, m0, n0, ln_lds);
+        xattn_epilogue_big<TM, CARRY ? 5 : 6>(p, acc, smem, wv, wm, wn, l, m0, m_lim, n0, ln_lds);
     } else {
         wave_epilogue<TM, TN, true, CARRY>(p, acc, smem, wv, wm, wn, l, m0, n0, split, tl, ln_lds);
     }
@@ -601,6 +613,8 @@ int launch_big(const GemmK& k, int cfg, hipStream_t st) {
 #undef ICD_BIG
     if (cfg == 100)   // query projection + cross-attention in one launch (icd_gemm_desc.xattn_*): 256 x 256 = 256 queries x 4 heads
         return k.x_nk <= 80 ? launch_one<0, 2, 4, 4, 2, true, true, true>(k, st) : launch_one<0, 2, 4, 4, 2, true, false, true>(k, st);   // 5 / 6 live key slots
+    if (cfg == 101)   // the same on 192 x 256: six m-tiles per 1024-query sample (the last one 64 rows) - 240 blocks where 160 leave 96 CUs idle
+        return k.x_nk <= 80 ? launch_one<0, 2, 4, 3, 2, true, true, true>(k, st) : launch_one<0, 2, 4, 3, 2, true, false, true>(k, st);
     icd_set_error("icd_gemm: unknown big-tile configuration %d", cfg);
     return ICD_ERR_INVALID_ARG;
 }

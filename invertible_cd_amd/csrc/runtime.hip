@@ -113,10 +113,10 @@ struct icd_unet {
     int kv_total = 0;               // sum of C over every transformer block (cross-attention K / V columns)
     // per-handle execution options (icd_unet_set_option)
     // xattn_mode: run LN2 -> to_q -> cross-attention as ONE launch (icd_gemm xattn_*).  0 never, 1 wherever the kernel is eligible,
-    // 2 (default) where it measured faster than projection + attention: hosted on the 256 x 256 tile (C % 256 == 0) with one
-    // round of 128..256 blocks - SDXL's 1024-token layers at 8 images per GPU: 59.4 us against 62.7 us.  With more than one
-    // round, or on the 128-wide host (C = 640), its softmax epilogue (17 us per block, VALU bound, serial behind the main loop)
-    // costs more than the q round trip it saves; DESIGN.md section 4.
+    // 2 (default) where it measured faster than projection + attention: hosted on the 256-wide tiles (C % 256 == 0), from 4 images per
+    // GPU on SDXL's 1024-token layers up to two rounds of 192 x 256 blocks (round 5, profiles/r05_xattn_bench.txt: B = 4 40.5 us against
+    // 46.1, B = 8 47.7 against 62.9, B = 16 89.6 against 92.2; the 256 x 256 host alone won at B = 8 only).  On the 128-wide host
+    // (C = 640) its softmax epilogue (VALU bound, serial behind the main loop) costs more than the q round trip it saves; DESIGN.md section 4.
     int xattn_mode = 2;
     bool ln_inline = true;          // the GEMM behind a LayerNorm computes its statistics (ICD_GEMM_LN_COMPUTE)
     int xattn_tile = 0;             // A/B: host tile of the fused launch (icd_gemm_desc.tune_xattn_tile)
@@ -484,8 +484,8 @@ struct Exec {
             const half_t* wq = Wh(b + ".attn2.to_q.weight", (long long)C * C);
             const float* bq = Wf(b + ".attn2.to_q.lnbias", C);
             const float* sq = Wf(b + ".attn2.to_q.lnsum", C);
-            const long long xa_blocks = (M / 256) * (C / 256);
-            const bool xa_auto = C % 256 == 0 && xa_blocks >= 128 && xa_blocks <= 256;
+            const long long xa_blocks = (M / 256) * (C / 256), xa_b192 = (long long)B * ((HW + 191) / 192) * (C / 256);
+            const bool xa_auto = C % 256 == 0 && xa_blocks >= 64 && xa_b192 <= 512;
             if (!cross_plan.mat && d == 64 && C % 128 == 0 && HW % 256 == 0 && nctx <= 96 && (u->xattn_mode == 1 || (u->xattn_mode == 2 && xa_auto))) {
                 // the north-star kernel: LN2 -> to_q -> softmax(q K^T / 8) V in ONE launch, q stays in the accumulators
                 if (ok() && !dry) {
@@ -853,7 +853,8 @@ extern "C" int icd_unet_set_option(icd_unet* u, int32_t option, int32_t value) {
         ICD_CHECK_ARG(value >= 0 && value <= 2, "icd_unet_set_option: ICD_UNET_OPT_XATTN_FUSION takes 0, 1 or 2 (got %d)", value);
         u->xattn_mode = value; return ICD_OK;
     case ICD_UNET_OPT_XATTN_TILE:
-        ICD_CHECK_ARG(value == 0 || value == 2 || value == 4, "icd_unet_set_option: ICD_UNET_OPT_XATTN_TILE takes 0, 2 or 4 (got %d)", value);
+        ICD_CHECK_ARG(value == 0 || value == 2 || value == 4 || value == 5 || value == 6,
+                      "icd_unet_set_option: ICD_UNET_OPT_XATTN_TILE takes 0, 2, 4, 5 or 6 (got %d)", value);
         u->xattn_tile = value; return ICD_OK;
     case ICD_UNET_OPT_ATTN_VALU_SCALE:
         ICD_CHECK_ARG(value == 0 || value == 1, "icd_unet_set_option: ICD_UNET_OPT_ATTN_VALU_SCALE takes 0 or 1 (got %d)", value);

@@ -325,7 +325,7 @@ def query_cross_attention(a, w, k, vt, B, n_tokens, nk, scale, bias=None, ln_sta
             d.flags |= _lib.ICD_GEMM_LN_COMPUTE
     d.xattn_k, d.xattn_vt = k.data_ptr(), vt.data_ptr()
     d.xattn_nk, d.xattn_ldk, d.xattn_ldvt, d.xattn_vt_bs, d.xattn_scale = nk, k.stride(0), vt.stride(1), vt.stride(0), scale
-    d.tune_xattn_tile = xattn_tile            # 0 planner, 2 / 4: force the 128 x 128 / 256 x 128 host tile (A/B)
+    d.tune_xattn_tile = xattn_tile            # 0 planner; 2 / 4: force the 128 x 128 / 256 x 128 host tile, 5 / 6: 256 x 256 / 192 x 256 (A/B)
     d.debug_timeline = timeline.data_ptr() if timeline is not None else None
     _lib.check(_lib.load().icd_gemm(C.byref(d), _stream()), "icd_gemm(xattn)")
     return out

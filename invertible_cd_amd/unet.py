@@ -338,7 +338,7 @@ class UNet2DConditionModel:
             self._kv = None                      # (the cached context projections carry their error byte only at the split levels)
 
     def set_option(self, name, value):
-        """Per-handle execution option (icd_unet_set_option): 'xattn_fusion' 0 / 1 / 2, 'ln_inline_stats' 0 / 1, 'xattn_tile' 0 / 2 / 4,
+        """Per-handle execution option (icd_unet_set_option): 'xattn_fusion' 0 / 1 / 2, 'ln_inline_stats' 0 / 1, 'xattn_tile' 0 / 2 / 4 / 5 / 6,
         'residual' 0 fp16 stream / 1 fp32 twin / 2 error carry / 3 carry + split consumers (default; 'residual_f32' is the round-3
         name of the same option).  A/B
         tuning and tests; nothing is process-wide."""

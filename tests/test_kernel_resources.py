@@ -55,7 +55,7 @@ def test_gemm_big_tiles_keep_their_register_budget():
     ks = _descriptors("gemm_big.hip")
     asm = _descriptors("gemm_big.hip", main_loops=True)
     tiles = {n: v for n, v in ks.items() if "gemm_big_kernel" in n}
-    assert len(tiles) == 22                                     # 4 tiles x {dense, conv} x {plain, error carry} + the 4 dense tiles that may compute LayerNorm statistics in their loop + the fused cross-attention host (6 / 5 live key slots)
+    assert len(tiles) == 24                                     # 4 tiles x {dense, conv} x {plain, error carry} + the 4 dense tiles that may compute LayerNorm statistics in their loop + the fused cross-attention hosts (256 / 192 rows x 6 / 5 live key slots)
     for n, v in tiles.items():
         # whatever the epilogue variants spill, the MFMA loop of every tile touches no scratch (round 3's 256 x 320 conv tile reloaded two
         # loop invariants per k-tile pair; the buffer-descriptor loader of round 4 keeps two registers per chunk less)
@@ -65,7 +65,8 @@ def test_gemm_big_tiles_keep_their_register_budget():
         assert v["vgpr_count"] <= 256
         if xattn:
             # (until round 3 the 48 loop-invariant key-mask predicates of its softmax epilogue sat in scalar registers: 181 spilt)
-            assert v["vgpr_spill_count"] == 0 and v["sgpr_spill_count"] == 0, (n, v)
+            # (the 192-row host masks its stores by row - the last m-tile of a sample is partial: 4 registers spilt in its epilogue)
+            assert v["vgpr_spill_count"] <= (0 if tm == 4 else 6) and v["sgpr_spill_count"] == 0, (n, v)
         elif tm * tn <= 8:
             assert v["vgpr_spill_count"] == 0 and v["sgpr_spill_count"] == 0, (n, v)      # 256 x 256, 192 x 256, 128 x 320
         else:

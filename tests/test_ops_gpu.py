@@ -890,6 +890,39 @@ def test_query_projection_with_fused_cross_attention(B, n_tok, C, X, nk, ln):
     assert rel_l2(out, un) < 2e-3
 
 
+@pytest.mark.parametrize("B,n_tok,C,nk,ln", [(8, 1024, 1280, 77, True), (2, 1024, 1280, 77, False), (3, 768, 1280, 96, True), (2, 2048, 768, 77, True),
+                                             (5, 256, 1280, 13, True)])
+def test_fused_cross_attention_on_the_192_row_tile_gives_the_bits_of_the_256_row_tile(B, n_tok, C, nk, ln):
+    """Round 5: the fused launch on 192 x 256 blocks laid out per sample - ceil(n_tok / 192) m-tiles, the last one partial (1024 = 5 x 192 +
+    64, 2048 = 10 x 192 + 128, 256 = 192 + 64; 768 = 4 x 192 exactly) - so that SDXL's 1024-token layers at 8 images per GPU make 240 blocks
+    instead of 160.  Same k order, same MFMAs, same epilogue per query row: the output and the LayerNorm statistics the launch stores are
+    bit-identical to the 256 x 256 host tile; nothing outside a sample's rows is read into a block or written by it (NaN canaries behind
+    the output and in the statistics buffer of the 256-row run are irrelevant here: the outputs are fresh allocations of exactly M rows,
+    and the op test above covers the values)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(321)
+    h = (torch.randn(B * n_tok, C, generator=g) * 1.1 + 0.5 * torch.randn(B * n_tok, 1, generator=g)).half().cuda()
+    gamma, beta = 1 + 0.2 * torch.randn(C, generator=g), 0.3 * torch.randn(C, generator=g)
+    wq = r16(C, C, seed=322, scale=C ** -0.5 * 3.0)
+    ctx = r16(B * nk, 64, seed=323).cuda()
+    k_dev = ops.gemm(ctx, r16(C, 64, seed=324, scale=0.25).cuda())
+    vt_dev = ops.project_vt(ctx, r16(C, 64, seed=325, scale=0.125).cuda(), B, nk, (nk + 7) // 8 * 8)
+    outs, stats = {}, {}
+    for tile in (5, 6, 0):
+        if ln:
+            w16, s, t = ops.fold_layernorm(wq, gamma, beta)
+            st = torch.full((B * n_tok, 2), float("nan"), device="cuda")
+            outs[tile] = ops.query_cross_attention(h, w16.cuda(), k_dev, vt_dev, B, n_tok, nk, 0.125, bias=t.cuda(), ln_stats=st, ln_colsum=s.cuda(),
+                                                   ln_compute=True, xattn_tile=tile)
+            stats[tile] = st
+        else:
+            outs[tile] = ops.query_cross_attention(h, wq.cuda(), k_dev, vt_dev, B, n_tok, nk, 0.125, xattn_tile=tile)
+    assert torch.isfinite(outs[6].float()).all()
+    assert torch.equal(outs[5], outs[6]) and torch.equal(outs[0], outs[6])
+    if ln:
+        assert torch.isfinite(stats[6]).all() and torch.equal(stats[5], stats[6])
+
+
 @pytest.mark.parametrize("B,H,Nq,Nk,d", [(2, 8, 256, 77, 40), (1, 8, 1024, 77, 80), (2, 4, 64, 13, 160), (2, 8, 1024, 1024, 80),
                                          (1, 8, 256, 256, 160), (3, 2, 100, 90, 64), (1, 2, 200, 333, 48)])
 def test_attention_probs_one_pass(B, H, Nq, Nk, d):

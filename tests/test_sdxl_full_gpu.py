@@ -178,7 +178,7 @@ def test_full_sdxl_forward_128x128_b2_on_the_benchmarked_tiles():
     """The code path bench.py times for SDXL, against the oracle: full width, B = 2 at 128x128 latents (13.5 TFLOP of CPU oracle).
     From the planner records: the GEMM flops run on the 256-wide tiles of gemm_big.hip, the first GEMM behind every LayerNorm
     takes the statistics from its main loop, and - under option xattn_fusion = 1 - the sixty 1024-token C = 1280 cross-attention
-    layers run as the epilogue of the 256 x 256 query-projection tile (xattn_epilogue_big; 8 x 5 = 40 blocks each), the ten
+    layers run as the epilogue of the 192 x 256 query-projection tile (xattn_epilogue_big; six m-tiles per sample x 5 = 60 blocks each), the ten
     4096-token C = 640 layers on the 128-wide host.  Default options (mode 2 fuses nothing at B = 2) and the fused variant are both
     compared with the fp32 oracle and with the fp16-torch floor."""
     from test_unet_gpu import _run_case
@@ -202,7 +202,7 @@ def test_full_sdxl_forward_128x128_b2_on_the_benchmarked_tiles():
         if name is None:
             assert len(xa) == 0
         else:
-            on_big = [p for p in xa if p["big"] and p["tile"] == (256, 256) and p["N"] == 1280 and p["M"] == 2048]
+            on_big = [p for p in xa if p["big"] and p["tile"] == (192, 256) and p["N"] == 1280 and p["M"] == 2048]
             on_128 = [p for p in xa if not p["big"] and p["N"] == 640 and p["M"] == 8192]
             assert len(xa) == 70 and len(on_big) == 60 and len(on_128) == 10 and all(p["xattn"] for p in xa)
             assert all(p["ln_inline"] for p in on_big)            # ... with the LayerNorm statistics from the same main loop

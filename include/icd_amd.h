@@ -367,7 +367,10 @@ typedef struct icd_unet icd_unet;
  * Called on the host, in module-execution order, once per Attention module per forward with phase 0:
  *   phase 0 (ICD_HOOK_QUERY): return 0 -> run this layer fused (no P); return 1 -> materialise P: the hook must have
  *            stored in *probs a device buffer of bh*nq*ld fp16 elements (a FRESH allocation if it intends to keep
- *            it, cf. AttentionStore's views utils/p2p.py:148).
+ *            it, cf. AttentionStore's views utils/p2p.py:148).  Return 2 (round 5; even batch) -> materialise P for the SECOND HALF of
+ *            the batch only - the conditional samples of a [uncond; cond] batch, all the reference's controllers touch
+ *            (utils/p2p.py:153-155): the buffer holds bh/2 rows, phase 1 is called with bh/2, an icd_probs_epilogue counts its rows
+ *            from the first materialised one, and the first half of the batch runs the fused kernel.
  *   phase 1 (ICD_HOOK_PROBS): P has been enqueued on `stream`; the hook may enqueue in-place edits on the same
  *            stream.  Return 0; negative aborts the forward with ICD_ERR_HOOK.
  * place: 0 down, 1 mid, 2 up.  P layout: [bh = B*heads (row b*heads+h), nq, ld] with nk valid columns. */

@@ -375,9 +375,9 @@ struct Exec {
     // Phase 0 of the plugin protocol for the next Attention module (module-execution order): does the controller want its
     // probabilities?  Asked BEFORE the query projection is enqueued, because a cross-attention layer that is not
     // materialised runs as the epilogue of that projection (icd_gemm xattn_*).
-    struct AttnPlan { int layer; bool mat; void* probs; bool has_epi; icd_probs_epilogue epi; };
+    struct AttnPlan { int layer; bool mat; void* probs; bool has_epi; icd_probs_epilogue epi; bool half; };
     AttnPlan attn_query(bool is_cross, int place, int heads, int Nq, int Nk) {
-        AttnPlan a{layer++, false, nullptr, false, {}};
+        AttnPlan a{layer++, false, nullptr, false, {}, false};
         const long long ldp = (Nk + 7) / 8 * 8;
         if (dry) a.mat = probs_mode == 2 || (probs_mode == 1 && (is_cross || Nq <= 1024));
         else if (io->hook && ok()) {
@@ -385,6 +385,8 @@ struct Exec {
             const int r = io->hook(io->hook_user, ICD_HOOK_QUERY, a.layer, is_cross, place, (long long)B * heads, Nq, Nk, ldp, slots);
             if (r < 0) { icd_set_error("attention hook (query) failed at layer %d", a.layer); status = ICD_ERR_HOOK; return a; }
             a.mat = r >= 1;
+            a.half = r == 2;                         // P of the second half of the batch only (the conditional rows of a CFG batch)
+            if (a.half && (B & 1)) { icd_set_error("attention hook asked for half of an odd batch (layer %d)", a.layer); status = ICD_ERR_HOOK; return a; }
             a.probs = slots[0];
             if (a.mat && slots[1]) { a.epi = *(const icd_probs_epilogue*)slots[1]; a.has_epi = true; }
             if (a.mat && !a.probs) { icd_set_error("attention hook returned 1 without a probability buffer (layer %d)", a.layer); status = ICD_ERR_HOOK; }
@@ -416,20 +418,33 @@ struct Exec {
             return;
         }
         // materialised path (utils/p2p.py:335-338): P = softmax(scale q.k^T) as fp16 in ONE pass (icd_attention_probs: no
-        // fp32 score tensor) -> hook (the controller edits / keeps P) -> P.V
+        // fp32 score tensor) -> hook (the controller edits / keeps P) -> P.V.  plan.half (round 5): the controller works on the second half
+        // of the batch only (utils/p2p.py:153-155: attn[h // 2:] of a [uncond; cond] batch) - the first half runs the fused kernel, P is
+        // written and read back for the conditional samples alone
+        const int b0 = plan.half ? B / 2 : 0, Bm = B - b0;
+        if (b0 && !dry) {
+            ProfScope ps(true, st, ICD_PROF_ATTN_FUSED, 4.0 * b0 * heads * (double)Nq * Nk * d, 0.0, Nq, Nk, d, heads);
+            run(icd_attention_fused_ex(q, k, vt, out, b0, heads, Nq, Nk, d, ldq, ldk, ldv, C, vt_bs, scale,
+                                       ICD_ATTN_Q_PRESCALED | (u->attn_mode0 ? ICD_ATTN_TUNE_MODE0 : 0), st));
+        }
+        const long long qo = (long long)b0 * Nq * ldq, ko = (long long)b0 * Nk * ldk;
+        const half_t* qm = q + qo;
+        const half_t* km = k + ko;
+        const void* qcm = q_c ? (const unsigned char*)q_c + qo : nullptr;
+        const void* kcm = k_c ? (const unsigned char*)k_c + ko : nullptr;
         const long long per_b = (long long)heads * Nq * ldp;            // elements of P per sample
         if (!dry && ok()) {
-            ProfScope ps(true, st, ICD_PROF_SOFTMAX, 2.0 * B * heads * (double)Nq * Nk * d, (double)B * per_b * 2.0);
-            run(icd_attention_probs_ex(q, q_c, k, k_c, probs, B, heads, Nq, Nk, d, ldq, ldk, (int)ldp, scale, plan.has_epi ? &plan.epi : nullptr, st));
+            ProfScope ps(true, st, ICD_PROF_SOFTMAX, 2.0 * Bm * heads * (double)Nq * Nk * d, (double)Bm * per_b * 2.0);
+            run(icd_attention_probs_ex(qm, qcm, km, kcm, probs, Bm, heads, Nq, Nk, d, ldq, ldk, (int)ldp, scale, plan.has_epi ? &plan.epi : nullptr, st));
         }
         if (!dry && ok()) {
-            const int r = io->hook(io->hook_user, ICD_HOOK_PROBS, my_layer, is_cross, place, (long long)B * heads, Nq, Nk, ldp, &probs);
+            const int r = io->hook(io->hook_user, ICD_HOOK_PROBS, my_layer, is_cross, place, (long long)Bm * heads, Nq, Nk, ldp, &probs);
             if (r < 0) { icd_set_error("attention hook (probs) failed at layer %d", my_layer); status = ICD_ERR_HOOK; return; }
         }
         icd_gemm_desc g; memset(&g, 0, sizeof(g));
-        g.a0 = probs; g.w = vt; g.out = out;
+        g.a0 = probs; g.w = vt + (long long)b0 * vt_bs; g.out = out + (long long)b0 * Nq * C;
         g.M = Nq; g.N = d; g.K = (int)ldp; g.Nw = d; g.lda = (int)ldp; g.ldw = ldv; g.ldo = C;
-        g.mode = 0; g.batch = B * heads; g.zdiv = heads;
+        g.mode = 0; g.batch = Bm * heads; g.zdiv = heads;
         g.a_bs0 = per_b; g.a_bs1 = (long long)Nq * ldp; g.w_bs0 = vt_bs; g.w_bs1 = (long long)d * ldv;
         g.o_bs0 = (long long)Nq * C; g.o_bs1 = d;
         g.alpha = 1.f;

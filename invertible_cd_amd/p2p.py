@@ -409,7 +409,7 @@ class HookAdapter:
     softmax rows, utils/p2p.py:183-188; Reweight only touches cross-attention, whose V carries no LayerNorm).  Cross-attention
     probabilities are unconstrained."""
 
-    def __init__(self, controller, cond_only: bool, dev):
+    def __init__(self, controller, cond_only: bool, dev, batch: int = 0):
         self.c = controller
         self.cond_only = cond_only
         self.dev = dev
@@ -426,6 +426,14 @@ class HookAdapter:
         self._epi_refs = None
         self._epi_acc_key = None
         self._epi_edit = False
+        # round 5: a controller with the reference's __call__ touches the second half of a [uncond; cond] batch only (utils/p2p.py:153-155).
+        # The executor then writes P for those samples alone and runs the unconditional half through the fused kernel (hook return 2):
+        # half the probabilities written, read back by P.V and held by the caching allocator.  `controller.cond_rows_only = False` keeps
+        # the whole batch materialised (A/B; the conditional rows and every stored tensor are the same bits either way).
+        self.half_ok = (self.native and not cond_only and not LOW_RESOURCE and isinstance(controller, AttentionControl)
+                        and type(controller).__call__ is AttentionControl.__call__ and batch > 0 and batch % 2 == 0
+                        and getattr(controller, "cond_rows_only", True) and str(dev).startswith("cuda"))
+        self.half = False
 
     @staticmethod
     def _trusts_needs_probs(c):
@@ -450,9 +458,11 @@ class HookAdapter:
                 c.tick()
             return None
         # a FRESH buffer per layer call: AttentionStore keeps views of it alive across steps (utils/p2p.py:148,153-157)
-        buf = torch.empty((bh, nq, ld), dtype=torch.float16, device=self.dev)
+        self.half = self.half_ok and bh % 2 == 0
+        rows = bh // 2 if self.half else bh
+        buf = torch.empty((rows, nq, ld), dtype=torch.float16, device=self.dev)
         self.pending = buf[:, :, :nk]
-        self.epilogue = self._plan_epilogue(is_cross, place, bh, nq, nk, ld) if self.fuse else None
+        self.epilogue = self._plan_epilogue(is_cross, place, rows, nq, nk, ld) if self.fuse else None
         return buf
 
     def _plan_epilogue(self, is_cross, place, bh, nq, nk, ld):
@@ -460,7 +470,7 @@ class HookAdapter:
         from . import _lib
         c = self.c
         self._epi_refs, self._epi_acc_key, self._epi_edit = None, None, False
-        first = 0 if self.cond_only else bh // 2
+        first = 0 if (self.cond_only or self.half) else bh // 2
         rows = bh - first
         epi = _lib.ProbsEpilogue()
         epi.first_cond_row = first
@@ -508,7 +518,7 @@ class HookAdapter:
             if self._epi_acc_key is not None:
                 c._fused_acc.add(self._epi_acc_key)
         try:
-            if self.cond_only and isinstance(c, AttentionControl):
+            if (self.cond_only or self.half) and isinstance(c, AttentionControl):
                 c.call_cond_only(view, is_cross, place)
                 return
             out = c(view, is_cross, place)

@@ -398,12 +398,12 @@ class UNet2DConditionModel:
             self._ws_key = key
         return self._ws
 
-    def _make_hook(self, errors):
+    def _make_hook(self, errors, batch=0):
         ctrl = self.attn_controller
         if ctrl is None:
             return _lib.ATTN_HOOK(0), 0
         from . import p2p
-        adapter = p2p.HookAdapter(ctrl, self.attn_cond_only, self.device)
+        adapter = p2p.HookAdapter(ctrl, self.attn_cond_only, self.device, batch=batch)
         live = self._live
 
         def hook(user, phase, layer, is_cross, place, bh, nq, nk, ld, probs_pp):
@@ -416,7 +416,7 @@ class UNet2DConditionModel:
                     probs_pp[0] = buf.data_ptr()
                     if adapter.epilogue is not None:         # the controller's work on P rides in the kernel's epilogue
                         probs_pp[1] = C.addressof(adapter.epilogue)
-                    return 1
+                    return 2 if adapter.half else 1          # 2: `buf` holds the second half of the batch only (the conditional rows)
                 adapter.probs_ready(layer, bool(is_cross), PLACES[place])
                 return 0
             except BaseException as e:       # never let an exception cross the C boundary
@@ -492,7 +492,7 @@ class UNet2DConditionModel:
         self._apply_precision()
         errors = []
         self._live.clear()
-        hook, probs_mode = self._make_hook(errors)
+        hook, probs_mode = self._make_hook(errors, B)
         ws = self._workspace(B, H, W, n_ctx, probs_mode)
         io.sample, io.timesteps, io.context, io.eps = x.data_ptr(), t.data_ptr(), ctx.data_ptr(), eps.data_ptr()
         io.workspace, io.workspace_bytes = ws.data_ptr(), ws.numel()

@@ -450,3 +450,42 @@ def test_fused_probability_epilogue_matches_the_separate_passes_bit_for_bit(kind
     assert s1.keys() == s0.keys()
     for k in s1:
         assert len(s1[k]) == len(s0[k]) and all(torch.equal(a, b) for a, b in zip(s1[k], s0[k])), k
+
+
+def test_probabilities_are_materialised_for_the_conditional_half_of_a_cfg_batch_only():
+    """Round 5: the reference's controllers work on attn[h // 2:] of a [uncond; cond] batch (utils/p2p.py:153-155), so the executor writes P
+    for the conditional samples alone (hook return 2) and the unconditional half takes the fused kernel.  Against the same loop with
+    `controller.cond_rows_only = False` (the whole batch materialised): every stored tensor and every latent has the same bits - the
+    conditional rows go through the same kernels, and the guidance-distilled loop discards the unconditional outputs, the only ones that
+    changed kernels - while the probability kernels move half the bytes (the executor's launch records)."""
+    E = _env()
+    p2p = E["p2p"]
+    from invertible_cd_amd import _lib
+    cfg, sd, lat, ctx, model, solver = _sd15_setup(E, 2, 32, 32, seed=29)
+    p2p.tokenizer = E["synthetic"].SyntheticTokenizer()
+    p2p.NUM_DDIM_STEPS = 4
+    solver.eliminate_dead_uncond = False       # the reference's batching: every evaluation sees the [uncond; cond] batch (the default of this
+    res = []                                   # package never computes the dead unconditional rows of the guidance-distilled loops at all)
+    for half in (True, False):
+        ctrl = p2p.AttentionStore()
+        ctrl.cond_rows_only = half
+        p2p.register_attention_control(model, ctrl)
+        _lib.profile_enable(True)
+        try:
+            outs = solver.cons_generation(lat.cuda(), guidance_scale=7.0, w_embed_dim=512, dynamic_guidance=False, tau1=1.0, tau2=1.0, controller=ctrl)
+            torch.cuda.synchronize()
+            fam = _lib.profile_read()
+        finally:
+            _lib.profile_enable(False)
+            p2p.register_attention_control(model, None)
+        res.append((outs, {k: [t.clone() for t in v] for k, v in ctrl.attention_store.items()}, fam))
+    (o1, s1, f1), (o0, s0, f0) = res
+    assert s1.keys() == s0.keys() and sum(len(v) for v in s1.values()) > 0
+    for k in s1:
+        assert all(torch.equal(a, b) for a, b in zip(s1[k], s0[k])), k
+    e = max(rel_l2(a, b.float().cpu()) for a, b in zip(o1, o0))
+    print(f"[conditional half only] latents vs whole-batch materialisation rel-L2 = {e:.2e}; probability kernel bytes "
+          f"{f1['softmax']['bytes'] / 1e6:.1f} MB vs {f0['softmax']['bytes'] / 1e6:.1f} MB")
+    assert e == 0.0
+    assert abs(f1["softmax"]["bytes"] / f0["softmax"]["bytes"] - 0.5) < 0.02
+    assert f1["attn_fused"]["launches"] > f0["attn_fused"]["launches"]

@@ -794,7 +794,7 @@ __global__ __launch_bounds__(256, 2) void attn_probs_kernel(ProbsK a, ProbsEpi e
         }
     };
     f16x8 qf[KF];
-    load_q(qf, bq);
+    if constexpr (!FEW) load_q(qf, bq);                  // (the few-keys path loads it after the base prompt's probabilities: registers)
     const int prow = (lr & 0x13) | ((lr & 4) << 1) | ((lr & 8) >> 1);
     auto load_k_of = [&](f16x8 (&kf)[KF], int kt, int bs) {
         const long long koff0 = (long long)bs * a.Nk * a.ldk + h * a.d;
@@ -908,13 +908,9 @@ __global__ __launch_bounds__(256, 2) void attn_probs_kernel(ProbsK a, ProbsEpi e
 #pragma unroll
                     for (int e = 0; e < 16; ++e) s[kt][e] *= inv;
         };
-        f32x16 s[3];
-        probs3(s, qf, bq);
-        AccRows ar;
-        acc_fetch(ar, 0, nt >= 2 ? 64 : 32);
         const bool edit = EPI == 2 && ep.At != nullptr && jp > 0;
         f16x8 pb[5];                                       // the base prompt's probabilities of this query tile as the MFMA B operand
-        if (EPI == 2 && edit) {
+        if (EPI == 2 && edit) {                            // (before this block's own q is loaded: one set of q fragments live at a time)
             f16x8 qb[KF];
             load_q(qb, ep.b0);
             f32x16 sb[3];
@@ -924,6 +920,11 @@ __global__ __launch_bounds__(256, 2) void attn_probs_kernel(ProbsK a, ProbsEpi e
 #pragma unroll
                 for (int e = 0; e < 8; ++e) pb[ks][e] = (ks >> 1) < nt ? (half_t)sb[ks >> 1][8 * (ks & 1) + e] : (half_t)0.f;
         }
+        load_q(qf, bq);
+        f32x16 s[3];
+        probs3(s, qf, bq);
+        AccRows ar;
+        acc_fetch(ar, 0, nt >= 2 ? 64 : 32);
 #pragma unroll
         for (int kt = 0; kt < 3; ++kt) {
             if (kt < nt) {
@@ -960,36 +961,40 @@ __global__ __launch_bounds__(256, 2) void attn_probs_kernel(ProbsK a, ProbsEpi e
         }
     } else {
     // ---- many keys: sweep 1 = running row maximum and sum, sweep 2 = probabilities ----
+    // (DB: the next key tile's fragments are requested while this one is scored - two sets of KF fragments.  Past 10 fragments per set
+    //  - split operands at head dims > 80 - the second set does not fit beside q: 300 - 460 spilt registers made the 256 x 256, d = 160
+    //  layers of SD1.5 cost 120 us for 8 MB of P; those take one set and the other waves of the SIMD hide the latency)
+    constexpr bool DB = KF <= 10;
     float m_run = -INFINITY, l_run = 0.f;
-    {
+    auto sweep1_tile = [&](const f16x8 (&kf)[KF], int kt) {
+        f32x16 s;
+        scores(s, kf, kt);
+        float tm = -INFINITY;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) tm = fmaxf(tm, s[e]);
+        const float mn = fmaxf(m_run, tm);                   // this half-wave's view; the halves are merged after the sweep
+        float acc = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc += __builtin_amdgcn_exp2f(s[e] - mn);
+        l_run = l_run * __builtin_amdgcn_exp2f(m_run - mn) + acc;
+        m_run = mn;
+    };
+    if constexpr (DB) {
         f16x8 ka[KF], kb[KF];
         load_k(ka, 0);
         for (int kt = 0; kt < nt; kt += 2) {
             if (kt + 1 < nt) load_k(kb, kt + 1);
-            f32x16 s;
-            scores(s, ka, kt);
-            float tm = -INFINITY;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) tm = fmaxf(tm, s[e]);
-            float mn = fmaxf(m_run, tm);                     // this half-wave's view; the halves are merged after the sweep
-            float acc = 0.f;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc += __builtin_amdgcn_exp2f(s[e] - mn);
-            l_run = l_run * __builtin_amdgcn_exp2f(m_run - mn) + acc;
-            m_run = mn;
+            sweep1_tile(ka, kt);
             if (kt + 1 < nt) {
                 if (kt + 2 < nt) load_k(ka, kt + 2);
-                scores(s, kb, kt + 1);
-                tm = -INFINITY;
-#pragma unroll
-                for (int e = 0; e < 16; ++e) tm = fmaxf(tm, s[e]);
-                mn = fmaxf(m_run, tm);
-                acc = 0.f;
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc += __builtin_amdgcn_exp2f(s[e] - mn);
-                l_run = l_run * __builtin_amdgcn_exp2f(m_run - mn) + acc;
-                m_run = mn;
+                sweep1_tile(kb, kt + 1);
             }
+        }
+    } else {
+        f16x8 ka[KF];
+        for (int kt = 0; kt < nt; ++kt) {
+            load_k(ka, kt);
+            sweep1_tile(ka, kt);
         }
     }
     {   // merge the two half-waves (each saw 16 of every 32 keys); a half that saw only masked keys has m = -inf, l = 0
@@ -999,26 +1004,35 @@ __global__ __launch_bounds__(256, 2) void attn_probs_kernel(ProbsK a, ProbsEpi e
         m_run = m_all;
     }
     const float inv = 1.0f / l_run;
-    {
+    auto sweep2_tile = [&](const f16x8 (&kf)[KF], int kt) {
+        f32x16 s;
+        scores(s, kf, kt);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s[e] = __builtin_amdgcn_exp2f(s[e] - m_run) * inv;
+        emit(s, kt);
+    };
+    if constexpr (DB) {
         f16x8 ka[KF], kb[KF];
         load_k(ka, 0);
         for (int kt = 0; kt < nt; kt += 2) {
             if (kt + 1 < nt) load_k(kb, kt + 1);
             AccRows ar;
             acc_fetch(ar, kt, kt + 1 < nt ? 64 : 32);
-            f32x16 s;
-            scores(s, ka, kt);
-#pragma unroll
-            for (int e = 0; e < 16; ++e) s[e] = __builtin_amdgcn_exp2f(s[e] - m_run) * inv;
-            emit(s, kt);
+            sweep2_tile(ka, kt);
             if (kt + 1 < nt) {
                 if (kt + 2 < nt) load_k(ka, kt + 2);
-                scores(s, kb, kt + 1);
-#pragma unroll
-                for (int e = 0; e < 16; ++e) s[e] = __builtin_amdgcn_exp2f(s[e] - m_run) * inv;
-                emit(s, kt + 1);
+                sweep2_tile(kb, kt + 1);
                 flush(kt, 64, ar);
             } else flush(kt, 32, ar);
+        }
+    } else {
+        f16x8 ka[KF];
+        AccRows ar;
+        for (int kt = 0; kt < nt; ++kt) {
+            load_k(ka, kt);
+            if (!(kt & 1)) acc_fetch(ar, kt, kt + 1 < nt ? 64 : 32);
+            sweep2_tile(ka, kt);
+            if ((kt & 1) || kt == nt - 1) flush(kt & ~1, (kt & 1) ? 64 : 32, ar);
         }
     }
     }

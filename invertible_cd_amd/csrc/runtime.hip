@@ -434,7 +434,8 @@ struct Exec {
         const void* kcm = k_c ? (const unsigned char*)k_c + ko : nullptr;
         const long long per_b = (long long)heads * Nq * ldp;            // elements of P per sample
         if (!dry && ok()) {
-            ProfScope ps(true, st, ICD_PROF_SOFTMAX, 2.0 * Bm * heads * (double)Nq * Nk * d, (double)Bm * per_b * 2.0);
+            ProfScope ps(true, st, ICD_PROF_SOFTMAX, 2.0 * Bm * heads * (double)Nq * Nk * d, (double)Bm * per_b * 2.0, Nq, Nk, d,
+                         heads | (q_c ? 256 : 0) | (plan.has_epi ? 512 : 0));
             run(icd_attention_probs_ex(qm, qcm, km, kcm, probs, Bm, heads, Nq, Nk, d, ldq, ldk, (int)ldp, scale, plan.has_epi ? &plan.epi : nullptr, st));
         }
         if (!dry && ok()) {

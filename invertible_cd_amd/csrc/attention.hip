@@ -767,13 +767,14 @@ struct ProbsEpi {
 };
 
 template <int KS, bool SPLIT = false, int EPI = 0, bool FEW = false>     // EPI: 0 none, 1 store += P / self replacement, 2 also the cross edit
-__global__ __launch_bounds__(256, 2) void attn_probs_kernel(ProbsK a, ProbsEpi ep) {
+__global__ __launch_bounds__(256, (KS <= 5 && !FEW && EPI == 0) ? 3 : 2) void attn_probs_kernel(ProbsK a, ProbsEpi ep) {
     __shared__ __attribute__((aligned(16))) half_t patch_all[4][32 * 72];
     const int tid = threadIdx.x, l = tid & 63, lr = l & 31, lh = l >> 5;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
     const int q0 = (blockIdx.x * 4 + wv) * 32;
-    if (q0 >= a.Nq) return;
+    const bool live = q0 < a.Nq;                           // (the many-keys path stages K per BLOCK: a wave without queries still loads and syncs)
+    if (FEW && !live) return;
     half_t* patch = patch_all[wv];
     f16x8 z8;
 #pragma unroll
@@ -782,18 +783,20 @@ __global__ __launch_bounds__(256, 2) void attn_probs_kernel(ProbsK a, ProbsEpi e
     const u32x2 zc = {0u, 0u};
     const int jp = EPI && b >= ep.b0 ? b - ep.b0 : 0;  // prompt index among the conditional samples (0 = the base prompt)
     const int bq = EPI && ep.self_base && jp > 0 ? ep.b0 : b;       // the sample whose q and k this block reads
-    auto load_q = [&](f16x8 (&qq)[KF], int bs) {
+    // q fragments: the carry stays packed (two registers per fragment, widened to fp16 where an MFMA takes it: two v_perm per use)
+    struct QFrags { f16x8 hi[KS]; u32x2 lo[SPLIT ? KS : 1]; };
+    auto load_q = [&](QFrags& qq, int bs) {
         const int qrow = q0 + lr;
         const long long qoff = ((long long)bs * a.Nq + qrow) * a.ldq + h * a.d;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const int dd = ks * 16 + lh * 8;
             const bool okq = qrow < a.Nq && dd < a.d;
-            qq[ks] = okq ? *reinterpret_cast<const f16x8*>(a.q + qoff + dd) : z8;
-            if (SPLIT) qq[KS + ks] = carry8_as_f16((okq && a.qc) ? *reinterpret_cast<const u32x2*>(a.qc + qoff + dd) : zc);
+            qq.hi[ks] = okq ? *reinterpret_cast<const f16x8*>(a.q + qoff + dd) : z8;
+            if (SPLIT) qq.lo[ks] = (okq && a.qc) ? *reinterpret_cast<const u32x2*>(a.qc + qoff + dd) : zc;
         }
     };
-    f16x8 qf[KF];
+    QFrags qf;
     if constexpr (!FEW) load_q(qf, bq);                  // (the few-keys path loads it after the base prompt's probabilities: registers)
     const int prow = (lr & 0x13) | ((lr & 4) << 1) | ((lr & 8) >> 1);
     auto load_k_of = [&](f16x8 (&kf)[KF], int kt, int bs) {
@@ -811,15 +814,15 @@ __global__ __launch_bounds__(256, 2) void attn_probs_kernel(ProbsK a, ProbsEpi e
     auto load_k = [&](f16x8 (&kf)[KF], int kt) { load_k_of(kf, kt, bq); };
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const float c = a.scale_log2;
-    auto scores_of = [&](f32x16& s, const f16x8 (&kf)[KF], const f16x8 (&qq)[KF], int kt) {     // s = log2(e) * scale * q.k, keys past Nk -> -inf
+    auto scores_of = [&](f32x16& s, const f16x8 (&kf)[KF], const QFrags& qq, int kt) {     // s = log2(e) * scale * q.k, keys past Nk -> -inf
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[ks], qq[ks], ks == 0 ? zero16 : s, 0, 0, 0);
+        for (int ks = 0; ks < KS; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[ks], qq.hi[ks], ks == 0 ? zero16 : s, 0, 0, 0);
         if (SPLIT) {                                                           // + 2^-14 (kl.qh + kh.ql)
             f32x16 t;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                t = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[KS + ks], qq[ks], ks == 0 ? zero16 : t, 0, 0, 0);
-                t = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[ks], qq[KS + ks], t, 0, 0, 0);
+                t = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[KS + ks], qq.hi[ks], ks == 0 ? zero16 : t, 0, 0, 0);
+                t = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[ks], carry8_as_f16(qq.lo[ks]), t, 0, 0, 0);
             }
 #pragma unroll
             for (int e = 0; e < 16; ++e) s[e] = __builtin_fmaf(t[e], 1.f / 16384.f, s[e]);
@@ -882,7 +885,7 @@ __global__ __launch_bounds__(256, 2) void attn_probs_kernel(ProbsK a, ProbsEpi e
     const int nt = (a.ldp + 31) >> 5;                      // k-tiles incl. the pad columns (they are written as zeros)
     if constexpr (FEW) {
         // ---- few keys (cross-attention, <= 96 key slots; the host picks the instantiation): all S^T tiles in registers, exact softmax ----
-        auto probs3 = [&](f32x16 (&s)[3], const f16x8 (&qq)[KF], int bs) {
+        auto probs3 = [&](f32x16 (&s)[3], const QFrags& qq, int bs) {
             float mx = -INFINITY;
 #pragma unroll
             for (int kt = 0; kt < 3; ++kt) {
@@ -911,7 +914,7 @@ __global__ __launch_bounds__(256, 2) void attn_probs_kernel(ProbsK a, ProbsEpi e
         const bool edit = EPI == 2 && ep.At != nullptr && jp > 0;
         f16x8 pb[5];                                       // the base prompt's probabilities of this query tile as the MFMA B operand
         if (EPI == 2 && edit) {                            // (before this block's own q is loaded: one set of q fragments live at a time)
-            f16x8 qb[KF];
+            QFrags qb;
             load_q(qb, ep.b0);
             f32x16 sb[3];
             probs3(sb, qb, ep.b0);
@@ -961,41 +964,87 @@ __global__ __launch_bounds__(256, 2) void attn_probs_kernel(ProbsK a, ProbsEpi e
         }
     } else {
     // ---- many keys: sweep 1 = running row maximum and sum, sweep 2 = probabilities ----
-    // (DB: the next key tile's fragments are requested while this one is scored - two sets of KF fragments.  Past 10 fragments per set
-    //  - split operands at head dims > 80 - the second set does not fit beside q: 300 - 460 spilt registers made the 256 x 256, d = 160
-    //  layers of SD1.5 cost 120 us for 8 MB of P; those take one set and the other waves of the SIMD hide the latency)
-    constexpr bool DB = KF <= 10;
-    float m_run = -INFINITY, l_run = 0.f;
-    auto sweep1_tile = [&](const f16x8 (&kf)[KF], int kt) {
-        f32x16 s;
-        scores(s, kf, kt);
-        float tm = -INFINITY;
+    // K is staged through LDS once per BLOCK and sweep (round 5): the four waves of a block score the same keys, and with every wave
+    // fetching its own fragments from global memory one tile ahead the 1024 x 1024 layers of SD1.5 sat at 99 us (fp16 operands) / 178 us
+    // (split operands, two waves per SIMD) for 134 MB of P - one exposed L2 round trip per key tile.  Now 256 threads copy SK keys (hi
+    // rows, and the raw carry bytes when SPLIT) global -> registers -> LDS one stage ahead of the MFMAs, one barrier per stage; fragments
+    // come from LDS (row pitches of an odd number of 16-B / 8-B units: conflict-free b128 / b64 reads).
+    constexpr int SK = KS <= 5 ? 64 : 32, TPS = SK / 32;          // keys / key tiles per stage
+    constexpr int HS = KS * 32 + 16, LS = KS * 16 + 8;            // row pitch of the hi / carry image (bytes)
+    constexpr int HI_ITEMS = SK * KS * 2, LO_ITEMS = SPLIT ? SK * KS * 2 : 0;      // 16-B / 8-B items per stage
+    constexpr int NHI = (HI_ITEMS + 255) / 256, NLO = SPLIT ? (LO_ITEMS + 255) / 256 : 1;
+    constexpr int LO_OFF = SK * HS, STAGE = SK * HS + (SPLIT ? SK * LS : 0);
+    __shared__ __attribute__((aligned(16))) unsigned char kst[2][STAGE];
+    const long long kbase = (long long)bq * a.Nk * a.ldk + h * a.d;
+    f16x8 ph[NHI];
+    u32x2 pl[NLO];
+    auto fetch = [&](int stage) {                                  // global -> registers
+        const int key0 = stage * SK;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) tm = fmaxf(tm, s[e]);
-        const float mn = fmaxf(m_run, tm);                   // this half-wave's view; the halves are merged after the sweep
-        float acc = 0.f;
+        for (int j = 0; j < NHI; ++j) {
+            const int item = j * 256 + tid, key = item / (2 * KS), c = item - key * (2 * KS);
+            const bool okk = item < HI_ITEMS && key0 + key < a.Nk && c * 8 < a.d;
+            ph[j] = okk ? *reinterpret_cast<const f16x8*>(a.k + kbase + (long long)(key0 + key) * a.ldk + c * 8) : z8;
+        }
+        if (SPLIT) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc += __builtin_amdgcn_exp2f(s[e] - mn);
-        l_run = l_run * __builtin_amdgcn_exp2f(m_run - mn) + acc;
-        m_run = mn;
-    };
-    if constexpr (DB) {
-        f16x8 ka[KF], kb[KF];
-        load_k(ka, 0);
-        for (int kt = 0; kt < nt; kt += 2) {
-            if (kt + 1 < nt) load_k(kb, kt + 1);
-            sweep1_tile(ka, kt);
-            if (kt + 1 < nt) {
-                if (kt + 2 < nt) load_k(ka, kt + 2);
-                sweep1_tile(kb, kt + 1);
+            for (int j = 0; j < NLO; ++j) {
+                const int item = j * 256 + tid, key = item / (2 * KS), c = item - key * (2 * KS);
+                const bool okk = a.kc && item < LO_ITEMS && key0 + key < a.Nk && c * 8 < a.d;
+                pl[j] = okk ? *reinterpret_cast<const u32x2*>(a.kc + kbase + (long long)(key0 + key) * a.ldk + c * 8) : zc;
             }
         }
-    } else {
-        f16x8 ka[KF];
-        for (int kt = 0; kt < nt; ++kt) {
-            load_k(ka, kt);
-            sweep1_tile(ka, kt);
+    };
+    auto stash = [&](int buf) {                                    // registers -> LDS
+#pragma unroll
+        for (int j = 0; j < NHI; ++j) {
+            const int item = j * 256 + tid, key = item / (2 * KS), c = item - key * (2 * KS);
+            if (item < HI_ITEMS) *reinterpret_cast<f16x8*>(kst[buf] + key * HS + c * 16) = ph[j];
         }
+        if (SPLIT) {
+#pragma unroll
+            for (int j = 0; j < NLO; ++j) {
+                const int item = j * 256 + tid, key = item / (2 * KS), c = item - key * (2 * KS);
+                if (item < LO_ITEMS) *reinterpret_cast<u32x2*>(kst[buf] + LO_OFF + key * LS + c * 8) = pl[j];
+            }
+        }
+    };
+    auto frags = [&](f16x8 (&kf)[KF], int buf, int t2) {           // this lane's A-operand fragments of key tile t2 of the stage
+        const int key = t2 * 32 + prow;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            kf[ks] = *reinterpret_cast<const f16x8*>(kst[buf] + key * HS + ks * 32 + lh * 16);
+            if (SPLIT) kf[KS + ks] = carry8_as_f16(*reinterpret_cast<const u32x2*>(kst[buf] + LO_OFF + key * LS + (ks * 2 + lh) * 8));
+        }
+    };
+    const int nst = (nt + TPS - 1) / TPS;
+    float m_run = -INFINITY, l_run = 0.f;
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    for (int sg = 0; sg < nst; ++sg) {
+        if (sg + 1 < nst) fetch(sg + 1);
+#pragma unroll 1
+        for (int t2 = 0; t2 < TPS; ++t2) {       // (not unrolled: one tile's fragments live at a time)
+            const int kt = sg * TPS + t2;
+            if (live && kt < nt) {
+                f16x8 kf[KF];
+                frags(kf, sg & 1, t2);
+                f32x16 s;
+                scores(s, kf, kt);
+                float tm = -INFINITY;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) tm = fmaxf(tm, s[e]);
+                const float mn = fmaxf(m_run, tm);               // this half-wave's view; the halves are merged after the sweep
+                float acc = 0.f;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc += __builtin_amdgcn_exp2f(s[e] - mn);
+                l_run = l_run * __builtin_amdgcn_exp2f(m_run - mn) + acc;
+                m_run = mn;
+            }
+        }
+        if (sg + 1 < nst) stash((sg + 1) & 1);
+        __syncthreads();
     }
     {   // merge the two half-waves (each saw 16 of every 32 keys); a half that saw only masked keys has m = -inf, l = 0
         const float m_all = half_swap_max(m_run);
@@ -1004,36 +1053,29 @@ __global__ __launch_bounds__(256, 2) void attn_probs_kernel(ProbsK a, ProbsEpi e
         m_run = m_all;
     }
     const float inv = 1.0f / l_run;
-    auto sweep2_tile = [&](const f16x8 (&kf)[KF], int kt) {
-        f32x16 s;
-        scores(s, kf, kt);
+    AccRows ar;
+    fetch(0);
+    stash(0);                                                    // (every wave is past the last barrier of sweep 1: both buffers are free)
+    __syncthreads();
+    for (int sg = 0; sg < nst; ++sg) {
+        if (sg + 1 < nst) fetch(sg + 1);
+#pragma unroll 1
+        for (int t2 = 0; t2 < TPS; ++t2) {       // (not unrolled: one tile's fragments live at a time)
+            const int kt = sg * TPS + t2;
+            if (live && kt < nt) {
+                if (!(kt & 1)) acc_fetch(ar, kt, kt + 1 < nt ? 64 : 32);
+                f16x8 kf[KF];
+                frags(kf, sg & 1, t2);
+                f32x16 s;
+                scores(s, kf, kt);
 #pragma unroll
-        for (int e = 0; e < 16; ++e) s[e] = __builtin_amdgcn_exp2f(s[e] - m_run) * inv;
-        emit(s, kt);
-    };
-    if constexpr (DB) {
-        f16x8 ka[KF], kb[KF];
-        load_k(ka, 0);
-        for (int kt = 0; kt < nt; kt += 2) {
-            if (kt + 1 < nt) load_k(kb, kt + 1);
-            AccRows ar;
-            acc_fetch(ar, kt, kt + 1 < nt ? 64 : 32);
-            sweep2_tile(ka, kt);
-            if (kt + 1 < nt) {
-                if (kt + 2 < nt) load_k(ka, kt + 2);
-                sweep2_tile(kb, kt + 1);
-                flush(kt, 64, ar);
-            } else flush(kt, 32, ar);
+                for (int e = 0; e < 16; ++e) s[e] = __builtin_amdgcn_exp2f(s[e] - m_run) * inv;
+                emit(s, kt);
+                if ((kt & 1) || kt == nt - 1) flush(kt & ~1, (kt & 1) ? 64 : 32, ar);
+            }
         }
-    } else {
-        f16x8 ka[KF];
-        AccRows ar;
-        for (int kt = 0; kt < nt; ++kt) {
-            load_k(ka, kt);
-            if (!(kt & 1)) acc_fetch(ar, kt, kt + 1 < nt ? 64 : 32);
-            sweep2_tile(ka, kt);
-            if ((kt & 1) || kt == nt - 1) flush(kt & ~1, (kt & 1) ? 64 : 32, ar);
-        }
+        if (sg + 1 < nst) stash((sg + 1) & 1);
+        __syncthreads();
     }
     }
 }

@@ -63,6 +63,7 @@ def test_every_baseline_config_rides_on_the_default_line():
         assert abs(o["value"] - o["config"]["global_batch"] / (o["ms_per_step"] * 1e-3)) / o["value"] < 1e-3, key
         assert o["ms_per_step_per_rank"]["ranks"] == d["n_gpus"] and o["ms_per_step_per_rank"]["min"] <= o["ms_per_step_per_rank"]["max"], key
     assert d["edit"]["attention_store_tensors_per_pass"] > 0                 # the controller really was in the loop
+    assert d["edit"]["config"]["attention_store_accumulate"] == "probability kernel epilogue"      # ... with its work on P inside the kernel
     # round 4: `value` is the pass with `in_flight_batches` independent batches in flight and no events; the sequential pass with
     # events around the dominant family (the roofline leg) rides beside it, and so does the plain-fp16-stream rate
     assert d["config"]["in_flight_batches"] >= 1

@@ -1003,20 +1003,23 @@ def test_probability_kernel_epilogue_does_the_controllers_work_bit_for_bit(split
         got = ops.attention_probs(qh.cuda(), kh.cuda(), B, H, Nq, Nk, d, scale, ld, acc=acc, edit=(At, Dp), first_cond_sample=first, **kw)
         assert torch.equal(got, ref) and torch.equal(acc, acc_ref), (Nq, split)
         assert not torch.equal(got[first * H + H:], ops.attention_probs(qh.cuda(), kh.cuda(), B, H, Nq, Nk, d, scale, ld, **kw)[first * H + H:])
-    # self-attention (long rows, two sweeps): replacement by the base prompt's rows + accumulation
-    Nq = Nk2 = 256
-    q32, k32 = torch.randn(B * Nq, H * d, generator=g) * 2, torch.randn(B * Nk2, H * d, generator=g) * 2
-    qh, qc = ops.carry_encode(q32); kh, kc = ops.carry_encode(k32)
-    kw = dict(q_carry=qc.cuda(), k_carry=kc.cuda()) if split else {}
-    ref = ops.attention_probs(qh.cuda(), kh.cuda(), B, H, Nq, Nk2, d, d ** -0.5, **kw)
-    base = ref[first * H:(first + 1) * H]
-    for e in range(1, P):
-        ref[(first + e) * H:(first + e + 1) * H] = base
-    acc0 = (torch.rand(P * H, Nq, Nk2, generator=g) * 0.1).half().cuda()
-    acc_ref = acc0.clone(); acc_ref += ref[first * H:]
-    acc = acc0.clone()
-    got = ops.attention_probs(qh.cuda(), kh.cuda(), B, H, Nq, Nk2, d, d ** -0.5, acc=acc, self_from_base=True, first_cond_sample=first, **kw)
-    assert torch.equal(got, ref) and torch.equal(acc, acc_ref)
+    # self-attention (long rows, two sweeps over K staged through LDS): replacement by the base prompt's rows + accumulation; ragged
+    # query / key counts (waves without queries still stage and synchronise; the last stage is partial) and every head-dim class
+    for Nq, Nk2, dd in ((256, 256, 40), (200, 333, 80), (96, 104, 160), (1024, 1024, 80), (130, 100, 128)):
+        q32, k32 = torch.randn(B * Nq, H * dd, generator=g) * 2, torch.randn(B * Nk2, H * dd, generator=g) * 2
+        qh, qc = ops.carry_encode(q32); kh, kc = ops.carry_encode(k32)
+        kw = dict(q_carry=qc.cuda(), k_carry=kc.cuda()) if split else {}
+        ld2 = (Nk2 + 7) // 8 * 8
+        ref = ops.attention_probs(qh.cuda(), kh.cuda(), B, H, Nq, Nk2, dd, dd ** -0.5, **kw)
+        base = ref[first * H:(first + 1) * H]
+        for e in range(1, P):
+            ref[(first + e) * H:(first + e + 1) * H] = base
+        acc0 = (torch.rand(P * H, Nq, ld2, generator=g) * 0.1).half().cuda()          # padded rows, as the executor's P
+        acc_ref = acc0.clone(); acc_ref += ref[first * H:]                             # (pad columns of P are zero)
+        acc = acc0.clone()
+        got = ops.attention_probs(qh.cuda(), kh.cuda(), B, H, Nq, Nk2, dd, dd ** -0.5, acc=acc[:, :, :Nk2], self_from_base=True,
+                                  first_cond_sample=first, **kw)
+        assert torch.equal(got, ref) and torch.equal(acc, acc_ref), (Nq, Nk2, dd, split)
 
 
 def test_flash_attention_ring_is_bit_identical_to_a_fully_fenced_build():

@@ -69,7 +69,8 @@ const char* icd_build_sha(void);
 #define ICD_GEMM_TUNE_NO_BIG     0x00200000   /* never take one                                                      */
 #define ICD_GEMM_TUNE_NO_LN_INLINE 0x00800000 /* ICD_GEMM_LN_COMPUTE: always take the separate statistics launch (A/B)        */
 #define ICD_GEMM_TUNE_BN256      0x00400000   /* big tiles: only the BN = 256 shapes                                 */
-#define ICD_GEMM_TUNE_BIG_CFG(i) (((i) + 1) << 24)   /* force big-tile configuration i (0..3, see gemm_common.h)      */
+#define ICD_GEMM_TUNE_NO_PP      0x20000000   /* never take the ping-pong 256 x 256 tile (gemm_pp.hip): A/B against the lockstep tiles */
+#define ICD_GEMM_TUNE_BIG_CFG(i) (((i) + 1) << 24)   /* force big-tile configuration i (0..4, see gemm_common.h)      */
 
 /* out = alpha * (A (*) W^T) + bias[n] + rowbias[m / rows_per_sample][n] + resid[m][n]
  * A is either a dense row-major [M, K] matrix (mode 0; Linear, 1x1 conv, attention bmm) or the implicit im2col
@@ -262,6 +263,10 @@ typedef struct {
     const float* edit_D;
     int32_t first_cond_sample, self_from_base;
     int64_t first_cond_row;       /* alternative to first_cond_sample for callers that know rows, not heads: first_cond_sample = first_cond_row / H */
+    int32_t edit_count;           /* number of edited prompts the caller built edit_At / edit_D (or planned self_from_base) for; when > 0 the launch
+                                   * is rejected unless it equals B - first_cond_sample - 1 (the kernel indexes the operators by sample: a caller
+                                   * whose conditional samples are not exactly [base | edit_count edited prompts] must not use this epilogue) */
+    int32_t reserved0;
 } icd_probs_epilogue;
 int icd_attention_probs_ex(const void* q, const void* q_carry, const void* k, const void* k_carry, void* probs, int32_t B, int32_t H,
                            int32_t Nq, int32_t Nk, int32_t d, int32_t ldq, int32_t ldk, int32_t ldp, float scale,

@@ -60,7 +60,7 @@ class GemmDesc(C.Structure):
 class ProbsEpilogue(C.Structure):
     """icd_probs_epilogue: what the shipped controllers do to P, done in the probability kernel's epilogue."""
     _fields_ = [("acc", C.c_void_p), ("edit_At", C.c_void_p), ("edit_D", C.c_void_p), ("first_cond_sample", C.c_int32),
-                ("self_from_base", C.c_int32), ("first_cond_row", C.c_int64)]
+                ("self_from_base", C.c_int32), ("first_cond_row", C.c_int64), ("edit_count", C.c_int32), ("reserved0", C.c_int32)]
 
 
 class GemmPlanInfo(C.Structure):

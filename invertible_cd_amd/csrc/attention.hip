@@ -1145,6 +1145,9 @@ static int attention_probs_run(const void* q, const void* qc, const void* k, con
         ep.acc = (half_t*)epi->acc; ep.At = (const half_t*)epi->edit_At; ep.D = epi->edit_D;
         ep.b0 = epi->first_cond_row > 0 ? (int)(epi->first_cond_row / H) : epi->first_cond_sample; ep.self_base = epi->self_from_base != 0;
         ICD_CHECK_ARG(epi->first_cond_row % H == 0 && ep.b0 < B, "icd_attention_probs_ex: first_cond_row must be a multiple of H inside the batch");
+        ICD_CHECK_ARG(!(ep.At || ep.self_base) || B - ep.b0 >= 2, "icd_attention_probs_ex: an edit needs a base prompt and at least one edited prompt");
+        ICD_CHECK_ARG(epi->edit_count <= 0 || epi->edit_count == B - ep.b0 - 1,
+                      "icd_attention_probs_ex: edit_count %d does not match the %d edited samples of the launch", epi->edit_count, B - ep.b0 - 1);
     }
     const bool use_epi = ep.acc || ep.At || ep.self_base;
     const dim3 grid((unsigned)((Nq + 127) / 128), (unsigned)(B * H));

@@ -137,12 +137,14 @@ __device__ __forceinline__ u32x2 carry_of8(const float (&v)[8], const f16x8& o) 
 // chip (about 1.3 - 1.7 us depending on the box's clocks).  tk_full applies when >= 200 CUs are busy (chip-level
 // ceiling: the same block runs about 10 - 20 % slower), tk_part when <= 160.
 struct BigTile { int bm, bn; bool geglu_ok; double tk_part, tk_full, fixed; };
-constexpr int NUM_BIG_TILES = 4;
+constexpr int NUM_BIG_TILES = 5;
+constexpr int PP_TILE = 4;                       // index of the ping-pong 256 x 256 tile (gemm_pp.hip)
 constexpr BigTile BIG_TILES[NUM_BIG_TILES] = {
     {256, 256, true, 1.00, 1.08, 9.5},
     {256, 320, false, 1.07, 1.30, 13.5},
     {192, 256, true, 0.70, 0.76, 9.6},
     {128, 320, false, 0.72, 0.80, 9.0},
+    {256, 256, true, 0.90, 0.97, 9.0},           // gemm_pp.hip: the ping-pong main loop (1.585 vs 1.755 us per k-tile at 8192^3, prologue -0.5 us)
 };
 // Further configurations were built, measured and removed in round 2 (tools/gemm_timeline.py): a
 // generated hand-scheduled 4-wave 128 x 128 main loop, a 256 x 128 x 32 tile with two co-resident blocks per CU, and a 256 x 160
@@ -150,5 +152,7 @@ constexpr BigTile BIG_TILES[NUM_BIG_TILES] = {
 // two k-halves.  None is faster: under a full-chip launch every tile family delivers the same ~4 TFLOP/s per CU because the chip is at its
 // power limit (shader clock 1.3 - 1.7 GHz measured inside the main loop, 2.3 GHz when few CUs are busy).
 int launch_big(const GemmK& k, int cfg, hipStream_t st);     // cfg = index into BIG_TILES
+int launch_pp(const GemmK& k, hipStream_t st);               // gemm_pp.hip: the ping-pong 256 x 256 tile (BIG_TILES[PP_TILE])
+bool pp_operands_ok(const GemmK& k, bool conv);              // operands addressable by its 31-bit buffer offsets
 
 }  // namespace icd_gemm_detail

@@ -434,6 +434,7 @@ class HookAdapter:
                         and type(controller).__call__ is AttentionControl.__call__ and batch > 0 and batch % 2 == 0
                         and getattr(controller, "cond_rows_only", True) and str(dev).startswith("cuda"))
         self.half = False
+        self.batch = batch                         # samples of the UNet batch ([uncond; cond] when not cond_only); 0 = unknown
 
     @staticmethod
     def _trusts_needs_probs(c):
@@ -476,8 +477,14 @@ class HookAdapter:
         epi.first_cond_row = first
         refs = []
         if isinstance(c, AttentionControlEdit):
-            if rows % c.batch_size != 0 or c.batch_size < 2:
+            # the kernel indexes the edit operators by SAMPLE (prompt jp = sample - first conditional sample, jp - 1 operators), while the
+            # controller - like the reference (utils/p2p.py:192-194) - groups the rows by heads = rows / batch_size: the two agree only when
+            # the conditional samples of this call are exactly the controller's prompts.  Anything else (more latents than prompts, an
+            # unknown batch) keeps the separate passes.
+            cond = (self.batch if self.cond_only else self.batch // 2) if self.batch > 0 else 0
+            if rows % c.batch_size != 0 or c.batch_size < 2 or cond != c.batch_size:
                 return None
+            epi.edit_count = c.batch_size - 1
             if is_cross:
                 if not (nk <= 80 and ld >= 80 and ld % 8 == 0):
                     return None                      # the torch / icd_p2p_cross_edit path handles it (and then the store add must follow it)

@@ -243,7 +243,8 @@ class UNet2DConditionModel:
         self._ws = None
         self._ws_key = None
         self._ws_mode = 0
-        self._ws_pool = {}         # (B, H, W, n_ctx, residual mode, split mask) -> (arena, probs_mode): the two precision levels keep theirs
+        self._ws_pool = {}         # (B, H, W, n_ctx) -> (arena, probs_mode, {(level, probs_mode): bytes needed}): ONE arena per shape, sized
+                                   # to the largest precision level seen (the accurate level's layout is a superset of the fast one's)
         self._applied = None       # (residual mode, split mask) last sent to the native handle by the precision policy
         # p2p plugin state (set by p2p.register_attention_control / Generator.get_noise_pred)
         self.attn_controller = None
@@ -258,6 +259,9 @@ class UNet2DConditionModel:
         #  has large-magnitude channels, DESIGN.md section 6 "Streams that are not O(1)")
         self.precision = getattr(self, "precision", None) or self._env_precision()
         self._inverting = 0
+        # 'auto', plain generation: the level the PROBE chose for these weights (None = not probed yet; see _probe_plain_level)
+        self._auto_plain = getattr(self, "_auto_plain", None)
+        self._auto_gap = getattr(self, "_auto_gap", None)
         self.kv_cache_enabled = True
         self._kv = None            # (ctx tensor, version, cache buffer, stream)
 
@@ -271,6 +275,7 @@ class UNet2DConditionModel:
             setattr(r, k, getattr(self, k))
         r._options = {}
         r.precision = self.precision
+        r._auto_plain, r._auto_gap = self._auto_plain, self._auto_gap      # the probe's verdict belongs to the weights
         r._create_handle()
         for name, value in self._options.items():
             r.set_option(name, value)
@@ -328,7 +333,7 @@ class UNet2DConditionModel:
         if level is None:
             return
         if level == "auto":
-            level = "accurate" if (self._inverting > 0 or self.attn_controller is not None) else "fast"
+            level = "accurate" if (self._inverting > 0 or self.attn_controller is not None) else (self._auto_plain or "fast")
         want = self.PRECISION[level]
         if self._applied != want:
             _lib.check(self._lib.icd_unet_set_option(self._h, _lib.ICD_UNET_OPT_RESIDUAL_MODE, want[0]), "icd_unet_set_option(residual)")
@@ -336,6 +341,29 @@ class UNet2DConditionModel:
             self._applied = want
             self._ws_key = None
             self._kv = None                      # (the cached context projections carry their error byte only at the split levels)
+
+    # 'auto' is data-aware (round 6): whether the FAST level is good enough for plain generation depends on the checkpoint - residual
+    # streams with channels beyond ~2^11 (real SD checkpoints have them; a fused LoRA widens the activations further) push one fast
+    # evaluation past 1e-3 of the fp32 result while the accurate level stays at ~0.4e-3.  The first plain evaluation of a model therefore
+    # runs BOTH levels on its own inputs and compares them (one device->host scalar, once per set of weights; replicas inherit the verdict):
+    # the gap between the two IS the fast level's excess error, measured on the data instead of predicted from a proxy such as the
+    # stream's absolute maximum.  Above AUTO_ESCALATE_GAP the policy uses the accurate level for plain generation too.
+    AUTO_ESCALATE_GAP = 0.9e-3
+
+    def _probe_plain_level(self, args, kwargs):
+        saved = self.precision
+        try:
+            self.precision = "accurate"
+            e_acc = self.__call__(*args, **kwargs)
+            self.precision = "fast"
+            e_fast = self.__call__(*args, **kwargs)
+        finally:
+            self.precision = saved
+        a, f = (e_acc.sample if hasattr(e_acc, "sample") else e_acc[0]), (e_fast.sample if hasattr(e_fast, "sample") else e_fast[0])
+        gap = float((f.float() - a.float()).norm() / a.float().norm().clamp_min(1e-30))
+        self._auto_gap = gap
+        self._auto_plain = "fast" if gap <= self.AUTO_ESCALATE_GAP else "accurate"      # (NaN compares false: accurate)
+        return e_fast if self._auto_plain == "fast" else e_acc
 
     def set_option(self, name, value):
         """Per-handle execution option (icd_unet_set_option): 'xattn_fusion' 0 / 1 / 2, 'ln_inline_stats' 0 / 1, 'xattn_tile' 0 / 2 / 4 / 5 / 6,
@@ -378,23 +406,31 @@ class UNet2DConditionModel:
     # ------------------------------------------------------------------ forward
     def _workspace(self, B, H, W, n_ctx, probs_mode):
         """Arena for one forward, sized by the materialisation rule of the attached controller (0 none, 1 the shipped
-        controllers' rule, 2 any layer): only grows, so switching controllers does not thrash the allocator."""
-        key = (B, H, W, n_ctx) + (self._applied or (None, None))
+        controllers' rule, 2 any layer): only grows, so switching controllers does not thrash the allocator.  The precision levels of
+        one shape SHARE an arena (round 6; the 'auto' policy alternates between them inside one editing pipeline, and two arenas of
+        multiple GB each could tip a near-capacity run over): it is sized to the largest level asked for so far."""
+        shape = (B, H, W, n_ctx)
+        key = shape + (self._applied or (None, None))
         if self._ws_key != key or probs_mode > self._ws_mode:
-            hit = self._ws_pool.get(key)
-            if hit is not None and hit[1] >= probs_mode:
-                self._ws, self._ws_mode = hit
-            else:
-                nbytes = self._lib.icd_unet_workspace_bytes_ex(self._h, B, H, W, n_ctx, probs_mode)
-                if nbytes <= 0:
+            hit = self._ws_pool.get(shape)
+            need_key = (self._applied, probs_mode)
+            need = hit[2].get(need_key) if hit is not None else None
+            if need is None:
+                need = self._lib.icd_unet_workspace_bytes_ex(self._h, B, H, W, n_ctx, probs_mode)
+                if need <= 0:
                     raise RuntimeError("icd_unet_workspace_bytes failed")
+            if hit is not None and hit[0].numel() >= need:
+                hit[2][need_key] = need
+                self._ws, self._ws_mode = hit[0], probs_mode
+            else:
+                sizes = dict(hit[2]) if hit is not None else {}
+                sizes[need_key] = need
                 self._ws = None
-                self._ws_pool.pop(key, None)
-                if len(self._ws_pool) >= 2:          # one arena per precision level of the current shape, not a history of shapes
-                    self._ws_pool.clear()
-                self._ws = torch.empty((nbytes,), dtype=torch.uint8, device=self.device)
+                self._ws_pool.clear()                # one shape at a time, not a history of shapes; the old arena goes back to the allocator first
+                hit = None
+                self._ws = torch.empty((need,), dtype=torch.uint8, device=self.device)
                 self._ws_mode = probs_mode
-                self._ws_pool[key] = (self._ws, probs_mode)
+                self._ws_pool[shape] = (self._ws, probs_mode, sizes)
             self._ws_key = key
         return self._ws
 
@@ -447,6 +483,11 @@ class UNet2DConditionModel:
                  attention_mask=None, cross_attention_kwargs=None, added_cond_kwargs=None, return_dict=True, **kwargs):
         if encoder_hidden_states is None:
             raise ValueError("encoder_hidden_states is required")
+        if (self.precision == "auto" and self._auto_plain is None and self._inverting == 0 and self.attn_controller is None
+                and str(self.device).startswith("cuda") and not torch.cuda.is_current_stream_capturing()):
+            return self._probe_plain_level((sample, timestep), dict(encoder_hidden_states=encoder_hidden_states, class_labels=class_labels,
+                                           timestep_cond=timestep_cond, attention_mask=attention_mask, cross_attention_kwargs=cross_attention_kwargs,
+                                           added_cond_kwargs=added_cond_kwargs, return_dict=return_dict, **kwargs))
         if sample.dim() != 4 or sample.shape[1] != self.cfg.in_channels:
             raise ValueError(f"sample must be [B,{self.cfg.in_channels},H,W], got {tuple(sample.shape)}")
         dev = self.device

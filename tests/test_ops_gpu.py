@@ -96,7 +96,33 @@ def test_gemm_big_tile_dense(M, N, K):
     assert rel_l2(outg, val * F.gelu(gate)) < TOL
 
 
-@pytest.mark.parametrize("cfg_i", [0, 1, 2, 3])
+PP_TILE_FLAG = 5 << 24                               # ICD_GEMM_TUNE_BIG_CFG(4): the ping-pong 256 x 256 tile (gemm_pp.hip)
+
+
+@pytest.mark.parametrize("M,N,K", [(512, 256, 64), (300, 512, 128), (1000, 1280, 1344), (1024, 1280, 320), (256, 256, 4096), (2048, 2560, 1280),
+                                   (777, 256, 192)])
+def test_gemm_ping_pong_tile(M, N, K):
+    """The ping-pong ("8-phase") 256 x 256 tile forced on small and ragged shapes: 1, 2, 3, odd and even k-tile counts (prologue / tail of
+    the counted-vmcnt pipeline), ragged M, split-K where the planner splits, bias + residual, GEGLU, plain."""
+    ops = _ops()
+    a, w = r16(M, K, seed=661), r16(N, K, seed=662, scale=K ** -0.5)
+    bias = torch.randn(N, generator=torch.Generator().manual_seed(663))
+    res = r16(M, N, seed=664)
+    ref = a.float() @ w.float().t()
+    for _ in range(3):                                # a race in the staging pipeline would come and go between runs
+        out = ops.gemm(a.cuda(), w.cuda(), bias=bias.cuda(), resid=res.cuda(), debug_flags=PP_TILE_FLAG)
+        assert rel_l2(out, ref + bias + res.float()) < TOL
+    plain = ops.gemm(a.cuda(), w.cuda(), debug_flags=PP_TILE_FLAG)
+    assert rel_l2(plain, ref) < TOL
+    # bit-identical to the lockstep 256 x 256 tile: same k order, same accumulator layout, same epilogue
+    assert torch.equal(plain, ops.gemm(a.cuda(), w.cuda(), debug_flags=1 << 24))
+    perm = ops.geglu_perm(N // 2)
+    outg = ops.gemm(a.cuda(), w[perm].contiguous().cuda(), bias=bias[perm].contiguous().cuda(), geglu=True, debug_flags=PP_TILE_FLAG)
+    val, gate = (ref + bias).chunk(2, dim=-1)
+    assert rel_l2(outg, val * F.gelu(gate)) < TOL
+
+
+@pytest.mark.parametrize("cfg_i", [0, 1, 2, 3, 4])
 def test_gemm_every_big_tile_configuration(cfg_i):
     """Each gemm_big.hip configuration forced in turn (ICD_GEMM_TUNE_BIG_CFG): dense with bias + residual on a ragged M, the
     transposed (V^T) epilogue and a 3x3 conv with time bias."""
@@ -127,7 +153,8 @@ def test_gemm_every_big_tile_configuration(cfg_i):
 @pytest.mark.parametrize("M,C,N,flags,geglu", [(300, 320, 640, 0, False), (1024, 640, 1280, 0, False), (512, 1280, 1280, 3 << 24, False),
                                                (1000, 1280, 2560, 2 << 24, False), (1000, 1280, 2560, 1 << 24, True),
                                                (1000, 1280, 1280, 4 << 24, False), (2048, 320, 320, 0x100000, False),
-                                               (1000, 1280, 2560, (2 << 24) | 0x800000, False)])
+                                               (1000, 1280, 2560, (2 << 24) | 0x800000, False), (1000, 1280, 2560, 5 << 24, False),
+                                               (1000, 1280, 2560, 5 << 24, True), (700, 320, 1280, 5 << 24, False)])
 def test_gemm_computes_the_layernorm_statistics_it_applies(M, C, N, flags, geglu):
     """ICD_GEMM_LN_COMPUTE: the GEMM behind a LayerNorm computes (mean, rstd) of its A rows itself - the big tiles from the MFMA
     operand fragments of their main loop (v_dot2 sums in the waves of tile column 0, an LDS table feeds the epilogue, n-tile 0
@@ -164,7 +191,7 @@ def test_gemm_computes_the_layernorm_statistics_it_applies(M, C, N, flags, geglu
 
 
 @pytest.mark.parametrize("ratio", [50.0, 3.0, 0.0])
-@pytest.mark.parametrize("M,C,N,flags", [(1024, 640, 1280, 0x100000), (2048, 320, 320, 0x100000), (512, 1280, 1280, 3 << 24)])
+@pytest.mark.parametrize("M,C,N,flags", [(1024, 640, 1280, 0x100000), (2048, 320, 320, 0x100000), (512, 1280, 1280, 3 << 24), (512, 1280, 1280, 5 << 24)])
 def test_in_loop_layernorm_statistics_survive_a_large_row_offset(M, C, N, flags, ratio):
     """ICD_GEMM_LN_COMPUTE on the big tiles sums x and x^2 of each row from the MFMA operand fragments (one pass).  E[x^2] - mean^2
     cancels when a row's offset dominates its spread: at |mean| / sigma = 50 the one-pass variance alone is off by ~2.5e-3.  Rows with

@@ -181,6 +181,24 @@ def test_hook_adapter_tick_vs_materialise():
     assert seen == [((2, 4096, 4096), False, "up")]
 
 
+def test_fused_epilogue_is_planned_only_when_the_samples_are_the_controllers_prompts():
+    """The probability kernel's epilogue indexes the edit operators by SAMPLE; the controller (like utils/p2p.py:192-194) groups rows by
+    heads = rows / batch_size.  The two agree only when the conditional samples of the call are exactly the controller's prompts: a
+    2-prompt controller on a 4-latent cond-only batch (or an unknown batch) must fall back to the separate passes."""
+    prompts = ["a cat on a bench", "a dog on a bench"]
+    c = p2p.AttentionReplace(prompts, 4, cross_replace_steps=0.8, self_replace_steps=0.6)
+    heads = 2
+    for batch, cond_only, want in [(2, True, True), (4, True, False), (4, False, True), (8, False, False), (0, True, False), (3, True, False)]:
+        ad = p2p.HookAdapter(c, cond_only=cond_only, dev="cpu", batch=batch)
+        bh = max(batch, 2) * heads
+        epi = ad._plan_epilogue(True, "down", bh, 256, 77, 80)
+        assert (epi is not None and bool(epi.edit_At)) == want, (batch, cond_only)
+        if want:
+            assert epi.edit_count == 1 and epi.first_cond_row == (0 if cond_only else bh // 2)
+        epi = ad._plan_epilogue(False, "down", bh, 256, 256, 256)                       # self-attention replacement (step 0 is inside its window)
+        assert (epi is not None and epi.self_from_base == 1) == want, (batch, cond_only)
+
+
 def test_seq_aligner(golden_dir):
     g = np.load(os.path.join(golden_dir, "seq_aligner.npz"))
     pr = json.load(open(os.path.join(golden_dir, "seq_aligner_prompts.json")))

@@ -51,9 +51,20 @@ def _tables(sched_ref):
     return np.sqrt(ac), np.sqrt(1 - ac)
 
 
-def _sd15_setup(E, B, H, W, seed, full=False):
+def _fused(E, cfg, sd, seed):
+    """LoRA-fused weights as bench.py builds them (synthetic rank-64 LoRA -> loading.fuse_lora, utils/loading.py:64-71,119-125), rounded to the
+    fp16 the executor stores: BOTH sides (oracle and GPU) get these, so the loop is checked on the weight statistics the benchmark runs
+    (the fused update widens the activations; the fusion arithmetic itself is test_loading_gpu.py's business)."""
+    from invertible_cd_amd.loading import fuse_lora
+    fused = fuse_lora(sd, E["synthetic"].synthetic_lora(cfg, seed=seed + 100), lora_dtype=torch.float16)
+    return {k: v.half().float() for k, v in fused.items()}
+
+
+def _sd15_setup(E, B, H, W, seed, full=False, lora=False):
     cfg = E["SD15"] if full else E["SD15"].scaled((64, 128, 256, 256), cross_dim=64)
     sd = {k: v.half().float() for k, v in E["synthetic"].synthetic_state_dict(cfg, seed=seed).items()}
+    if lora:
+        sd = _fused(E, cfg, sd, seed)
     inp = E["synthetic"].synthetic_inputs(cfg, B, H, W, seed=seed)
     lat, ctx = inp["latents"].half().float(), inp["context"].half().float()
     model = E["StableDiffusionPipeline"](E["unet"].UNet2DConditionModel(cfg, sd, dtype=torch.float16), E["DDIMScheduler"].sd15(),
@@ -82,13 +93,14 @@ def _oracle_loop(E, sd, cfg, x, ctx, pairs, w_vals, controller=None, added=None)
     return x
 
 
-@pytest.mark.parametrize("eliminate", [True, False])
-def test_sd15_reverse_with_attention_store(eliminate):
-    """cfg 2/3: 4-step reverse, AttentionStore registered; latents AND every stored probability tensor vs the oracle."""
+@pytest.mark.parametrize("eliminate,lora", [(True, False), (False, False), (True, True)])
+def test_sd15_reverse_with_attention_store(eliminate, lora):
+    """cfg 2/3: 4-step reverse, AttentionStore registered; latents AND every stored probability tensor vs the oracle.
+    lora (round 6): the same loop on LoRA-fused weights, as the benchmark (and every shipped iCD checkpoint) runs."""
     E = _env()
     p2p = E["p2p"]
     B, H, W, gs = 3, 32, 32, 7.0
-    cfg, sd, lat, ctx, model, solver = _sd15_setup(E, B, H, W, seed=11)
+    cfg, sd, lat, ctx, model, solver = _sd15_setup(E, B, H, W, seed=11, lora=lora)
     solver.eliminate_dead_uncond = eliminate
     store = p2p.AttentionStore()
     p2p.register_attention_control(model, store)
@@ -100,7 +112,7 @@ def test_sd15_reverse_with_attention_store(eliminate):
     ref_store.num_att_layers = 32
     ref = _oracle_loop(E, sd, cfg, lat.clone(), ctx, list(zip(REV_T, REV_S)), [[gs] * B] * 4, controller=ref_store)
     err = rel_l2(outs[-1], ref)
-    print(f"[sd15 reverse, eliminate={eliminate}] rel-L2(latents) = {err:.3e}")
+    print(f"[sd15 reverse, eliminate={eliminate}, lora={lora}] rel-L2(latents) = {err:.3e}")
     assert err < 1e-3                                # measured 2.9e-4 (4.1e-4 on the plain fp16 stream of rounds 1-3)
     assert store.cur_step == ref_store.cur_step == 4
     n_checked, worst = 0, 0.0
@@ -114,7 +126,7 @@ def test_sd15_reverse_with_attention_store(eliminate):
             worst = max(worst, e)
             assert e < 1e-3, (key, e)              # the north star's bar on every stored tensor (worst measured: 8.3e-4)
             n_checked += 1
-    print(f"[sd15 reverse, eliminate={eliminate}] worst attention-store tensor rel-L2 = {worst:.3e}")
+    print(f"[sd15 reverse, eliminate={eliminate}, lora={lora}] worst attention-store tensor rel-L2 = {worst:.3e}")
     # latent 32x32 -> query counts 1024,1024,256,256,64,64 down; 16 mid; up 64x3,256x3,1024x3: all <= 32^2 -> all 32 stored
     assert n_checked == 32
 
@@ -161,12 +173,14 @@ def test_full_width_sd15_64x64_reverse_store_and_inversion_meet_1e3():
     assert e_inv < 1e-3
 
 
-def test_sd15_inversion_then_replace_edit():
-    """cfg 3: consistency inversion (forward model, w = 0) then a 2-prompt AttentionReplace edit on the reverse model."""
+@pytest.mark.parametrize("lora", [False, True])
+def test_sd15_inversion_then_replace_edit(lora):
+    """cfg 3: consistency inversion (forward model, w = 0) then a 2-prompt AttentionReplace edit on the reverse model.
+    lora (round 6): on LoRA-fused weights."""
     E = _env()
     p2p = E["p2p"]
     B, H, W = 2, 32, 32
-    cfg, sd, lat, ctx, model, solver = _sd15_setup(E, B, H, W, seed=12)
+    cfg, sd, lat, ctx, model, solver = _sd15_setup(E, B, H, W, seed=12, lora=lora)
     # ---- inversion: 4D latents pass straight through image2latent; add_noise at t=19 with the CPU generator(seed)
     solver.latent2image = lambda z, return_type="np": np.zeros((1,))
     img = lat.cuda()
@@ -178,7 +192,7 @@ def test_sd15_inversion_then_replace_edit():
     # B == 2 -> CFG-doubled batch of 4 -> w vector [0,0,0,gs] with gs = 0 -> all zeros
     ref_inv = _oracle_loop(E, sd, cfg, x0.clone(), ctx, list(zip(FWD_T, FWD_S)), [[0.0, 0.0]] * 4)
     e_inv = rel_l2(inv[0], ref_inv)
-    print(f"[sd15 inversion] rel-L2 = {e_inv:.3e}")
+    print(f"[sd15 inversion, lora={lora}] rel-L2 = {e_inv:.3e}")
     assert e_inv < 1e-3                              # round 5, accurate level: 6.6e-4 (1.03e-3 on the carry alone, 1.37e-3 on the plain fp16 stream)
     # ---- edit: replace controller (cross 0.5 / self 0.5), dynamic guidance tau = 0.8, gs = 19
     p2p.tokenizer = E["synthetic"].SyntheticTokenizer()
@@ -197,7 +211,7 @@ def test_sd15_inversion_then_replace_edit():
     ws = [[0.0, 0.0]] + [[0.0, 19.0]] * 3
     ref = _oracle_loop(E, sd, cfg, start.clone(), ctx, list(zip(REV_T, REV_S)), ws, controller=ref_ctrl)
     e = rel_l2(outs[-1], ref)
-    print(f"[sd15 replace edit] rel-L2 = {e:.3e}")
+    print(f"[sd15 replace edit, lora={lora}] rel-L2 = {e:.3e}")
     assert e < 1e-3                                  # round 5: 7.7e-4 (1.20e-3 on the carry alone; gs = 19, edited probabilities)
     assert ctrl.cur_step == 4
     worst, errs = 0.0, []
@@ -206,18 +220,22 @@ def test_sd15_inversion_then_replace_edit():
             errs.append((rel_l2(g, r), key, i, tuple(r.shape)))
     errs.sort(reverse=True)
     worst = errs[0][0]
-    print(f"[sd15 replace edit] worst attention-store tensor rel-L2 = {worst:.3e}; top: " +
+    print(f"[sd15 replace edit, lora={lora}] worst attention-store tensor rel-L2 = {worst:.3e}; top: " +
           ", ".join(f"{k}[{i}]{sh} {e:.2e}" for e, k, i, sh in errs[:6]))
     for e, k, i, sh in errs:
         assert e < STORE_BAR, (k, i, sh, e)
 
 
-def test_sdxl_reverse_and_dynamic_edit_pipeline():
-    """cfg 4 + cfg 5: SDXL 4-step reverse; 3-step forward + 3-step reverse with dynamic guidance (tau = 0.7)."""
+@pytest.mark.parametrize("lora", [False, True])
+def test_sdxl_reverse_and_dynamic_edit_pipeline(lora):
+    """cfg 4 + cfg 5: SDXL 4-step reverse; 3-step forward + 3-step reverse with dynamic guidance (tau = 0.7).
+    lora (round 6): on LoRA-fused weights (utils/loading.py:119-125)."""
     E = _env()
     X = E["generation_sdxl"]
     cfg = E["SDXL"].scaled((64, 128, 256), cross_dim=128, heads=(2, 4, 8))
     sd = {k: v.half().float() for k, v in E["synthetic"].synthetic_state_dict(cfg, seed=21).items()}
+    if lora:
+        sd = _fused(E, cfg, sd, 21)
     B, H, W = 2, 32, 32
     inp = E["synthetic"].synthetic_inputs(cfg, B, H, W, seed=21)
     lat, ctx = inp["latents"].half().float(), inp["context"].half().float()
@@ -234,7 +252,7 @@ def test_sdxl_reverse_and_dynamic_edit_pipeline():
     pairs = list(zip([999, 699, 499, 249], [699, 499, 249, 0]))
     ref = _oracle_loop_xl(E, sd, cfg, lat.clone(), ctx, pairs, [[7.0] * B] * 4, added)
     e4 = rel_l2(out, ref)
-    print(f"[sdxl reverse] rel-L2 = {e4:.3e}")
+    print(f"[sdxl reverse, lora={lora}] rel-L2 = {e4:.3e}")
     assert e4 < 1e-3                                 # measured 4.9e-4 (6.1e-4 before the carry)
     # cfg 5: forward 3 steps (w = 0) from noised latents at t = 19, then reverse 3 steps with tau = 0.7, gs = 19
     fwd, start = X.inverse_sample_deterministic(fpipe, lat.cuda().half(), ["x"] * B, num_inference_steps=3, timesteps=[19, 339, 699],
@@ -247,7 +265,7 @@ def test_sdxl_reverse_and_dynamic_edit_pipeline():
     assert rel_l2(x0, float(alpha[19]) * lat + float(sigma[19]) * noise) < 2e-3
     ref_f = _oracle_loop_xl(E, sd, cfg, x0, ctx, list(zip([19, 339, 699], [339, 699, 999])), [[0.0] * B] * 3, added)
     e5f = rel_l2(fwd, ref_f)
-    print(f"[sdxl forward] rel-L2 = {e5f:.3e}")
+    print(f"[sdxl forward, lora={lora}] rel-L2 = {e5f:.3e}")
     assert e5f < 1e-3                                # round 5, accurate level (1.45e-3 on the carry alone): three forward steps amplify
     _, rev = X.sample_deterministic(pipe, ["x"] * B, latents=ref_f.cuda().half(), num_inference_steps=3, guidance_scale=19.0,
                                     is_sdxl=True, timesteps=[339, 699, 999], compute_embeddings_fn=emb, return_latent=True,
@@ -256,7 +274,7 @@ def test_sdxl_reverse_and_dynamic_edit_pipeline():
     assert [w[0] for w in ws] == [0.0, 19.0, 19.0]
     ref_r = _oracle_loop_xl(E, sd, cfg, ref_f.half().float(), ctx, list(zip([999, 699, 339], [699, 339, 0])), ws, added)
     e5r = rel_l2(rev, ref_r)
-    print(f"[sdxl dynamic reverse] rel-L2 = {e5r:.3e}")
+    print(f"[sdxl dynamic reverse, lora={lora}] rel-L2 = {e5r:.3e}")
     assert e5r < 1e-3                                # round 5, accurate level (1.31e-3 on the carry alone; gs = 19 from t = 999)
 
 

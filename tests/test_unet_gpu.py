@@ -343,7 +343,9 @@ def test_precision_policy_selects_the_level_the_samplers_ask_for():
         e_acc = m(x, 500, **kw).sample
         assert m._applied == acc
     assert not torch.equal(e_fast, e_acc) and rel_l2(e_fast, e_acc) < 2e-3
-    assert torch.equal(m(x, 500, **kw).sample, e_fast) and m._applied == fast and len(m._ws_pool) == 2      # back, arenas of both levels kept
+    assert torch.equal(m(x, 500, **kw).sample, e_fast) and m._applied == fast and len(m._ws_pool) == 1      # back; ONE arena serves both levels
+    # (round 6) the first plain evaluation probed both levels on its own data: these weights keep the fast level for plain generation
+    assert m._auto_plain == "fast" and 0 < m._auto_gap <= m.AUTO_ESCALATE_GAP
     class _M:                                                  # register_attention_control wants a model with .unet
         pass
     holder = _M()
@@ -390,6 +392,15 @@ def test_large_magnitude_channels_keep_the_stream_finite_at_every_precision_leve
         eps = m(lat.half().cuda(), torch.tensor(519), encoder_hidden_states=ctx.cuda(), timestep_cond=cond.cuda()).sample
         assert torch.isfinite(eps).all(), name
         errs[name] = rel_l2(eps, ref)
+    # the data-aware 'auto' policy (round 6): on THESE weights the probe finds the fast level more than AUTO_ESCALATE_GAP away from the accurate
+    # one and plain generation runs at the accurate level - inside the north star's 1e-3 where the fast level is not
+    m2 = unet.UNet2DConditionModel(cfg, sd)
+    assert m2.precision == "auto"
+    eps = m2(lat.half().cuda(), torch.tensor(519), encoder_hidden_states=ctx.cuda(), timestep_cond=cond.cuda()).sample
+    errs["auto"] = rel_l2(eps, ref)
+    print(f"[large-magnitude channels] auto policy: probe gap {m2._auto_gap:.3e} -> {m2._auto_plain}")
+    assert m2._auto_plain == "accurate" and m2._auto_gap > m2.AUTO_ESCALATE_GAP
+    assert errs["auto"] < 1e-3 and errs["auto"] == pytest.approx(errs["accurate"], rel=1e-6)
     print("[large-magnitude channels] rel-L2 vs the fp32 oracle: " + ", ".join(f"{k} {v:.3e}" for k, v in errs.items()))
     assert errs["carry"] <= 1.05 * errs["fp16"] and errs["accurate"] <= 1.05 * errs["carry"]
     assert errs["fp16"] < 2e-2                                  # (fp16 storage of 2^14-sized values: ulp 16 on a stream whose signal is O(1))

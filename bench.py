@@ -69,6 +69,8 @@ def parse():
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="do not measure roofline.traffic in this run (two rocprofv3 --pmc child passes of one step per architecture after "
                          "the timed legs, N = 1 only); the committed PMC summary of the same workload is reported instead")
+    ap.add_argument("--leg", default="all", choices=["all", "edit"],
+                    help="internal (the PMC child passes of live_traffic): 'edit' runs ONLY the inversion + edit leg of --arch at --batch")
     ap.add_argument("--in-flight", type=int, default=2,
                     help="independent batches in flight per GPU (host threads x HIP streams x executor replicas over one set of weights; "
                          "InFlight): 1 = the sequential loop of rounds 1-3.  Every UNet call still runs the configuration's batch")
@@ -269,7 +271,7 @@ def hbm_traffic(arch, batch, family):
     return best or (None, None, None)
 
 
-def live_traffic(arch, batch, family, timeout_s=240):
+def live_traffic(arch, batch, family, timeout_s=240, leg="all"):
     """roofline.traffic measured IN THIS RUN: two rocprofv3 --pmc child passes (FETCH_SIZE, then WRITE_SIZE - one counter per pass, with
     --kernel-trace only, as MI355X_MICROARCH.md prescribes) over one step of the same leg in a fresh process, summarised per kernel family
     with tools/hbm_traffic.py's own code: bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024.  Returns (bytes per launch, seconds
@@ -290,7 +292,8 @@ def live_traffic(arch, batch, family, timeout_s=240):
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR", "TORCHELASTIC_RUN_ID"):
         env.pop(k, None)
     child = [sys.executable, os.path.abspath(__file__), "--arch", arch, "--batch", str(batch), "--steps", "1", "--warmup", "1", "--in-flight", "1",
-             "--no-cpu-baseline", "--no-vae", "--no-ref-batching", "--no-profile", "--no-sdxl", "--no-edit", "--no-live-traffic"]
+             "--no-cpu-baseline", "--no-vae", "--no-ref-batching", "--no-profile", "--no-sdxl", "--no-live-traffic"]
+    child += ["--leg", "edit", "--in-flight-edit", "1"] if leg == "edit" else ["--no-edit"]
     try:
         per = {}
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -421,8 +424,9 @@ def time_leg(step, steps, warmup, batch, device, world, rank, decode=None, event
 
 
 def family_table(step):
-    """One pass with every executor launch bracketed by HIP events: the per-family table, and the dominant family = the one carrying
-    the most algorithmic work (stable from run to run, unlike a max over times when two families are within a few per cent)."""
+    """One pass with every executor launch bracketed by HIP events: the per-family table, and the dominant family = the one the step
+    spends the most TIME in (round 6; rounds 1 - 5 took the one carrying the most algorithmic work, which named gemm_conv while
+    gemm_dense was 3 ms larger on the SD1.5 line).  The per-family table on the line carries every family's time and rate either way."""
     from invertible_cd_amd import _lib
     torch.cuda.synchronize()
     _lib.profile_enable(True)
@@ -430,7 +434,7 @@ def family_table(step):
     torch.cuda.synchronize()
     fam = {k: v for k, v in _lib.profile_read().items() if v["launches"]}
     _lib.profile_enable(False)
-    return fam, max(fam, key=lambda k: (fam[k]["flops"], fam[k]["ms"]))
+    return fam, max(fam, key=lambda k: (fam[k]["ms"], fam[k]["flops"]))
 
 
 def workload_group(wl, n):
@@ -754,6 +758,14 @@ def main():
     batch = a.batch or (32 if a.arch == "sd15" else 8)
     default_run = a.arch == "sd15" and not a.batch
     wl = (SD15Workload if a.arch == "sd15" else SDXLWorkload)(device)
+    if a.leg == "edit":                                 # child pass of live_traffic(leg="edit"): the edit leg alone, then out
+        e = run_edit(a, wl, a.arch, a.batch or (8 if a.arch == "sd15" else 16), 1, 1, device, world, rank)
+        if dist.is_initialized():
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps(e), file=_REAL_STDOUT, flush=True)
+        return
     out = run_reverse(a, wl, a.arch, batch, a.steps, a.warmup, device, world, rank, primary=True)
     # The default run carries every BASELINE configuration's per-GPU share on the same JSON line, inside the driver's clock:
     # `value` stays configs[1]; "edit" = configs[2] (B = 8, inversion + reverse with AttentionStore), "sdxl" = configs[3]'s 8 images
@@ -810,6 +822,16 @@ def main():
                            "traffic_kernels_sha": xr["kernels_sha"], "traffic_seconds": round(info, 1)})
             else:
                 xr["traffic_live_error"] = info
+        # ... and of the two edit legs (round 6): child passes that run the edit leg alone (--leg edit), counters on the family's kernels
+        for key, arch_e, b_e, lim in (("edit", "sd15", 8, 150), ("sdxl_edit", "sdxl", 16, 400)):
+            er = out.get(key, {}).get("roofline") if default_run else None
+            if er:
+                t_bytes, info = live_traffic(arch_e, b_e, er["kernel"], timeout_s=lim, leg="edit")
+                if t_bytes:
+                    er.update({"traffic": t_bytes, "traffic_source": "live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes of one edit step, this run",
+                               "traffic_kernels_sha": er["kernels_sha"], "traffic_seconds": round(info, 1)})
+                else:
+                    er["traffic_live_error"] = info
     if world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(a.arch, None, cfg_for_cpu)
     print(json.dumps(out), file=_REAL_STDOUT, flush=True)

@@ -70,7 +70,7 @@ const char* icd_build_sha(void);
 #define ICD_GEMM_TUNE_NO_LN_INLINE 0x00800000 /* ICD_GEMM_LN_COMPUTE: always take the separate statistics launch (A/B)        */
 #define ICD_GEMM_TUNE_BN256      0x00400000   /* big tiles: only the BN = 256 shapes                                 */
 #define ICD_GEMM_TUNE_NO_PP      0x20000000   /* never take the ping-pong 256 x 256 tile (gemm_pp.hip): A/B against the lockstep tiles */
-#define ICD_GEMM_TUNE_BIG_CFG(i) (((i) + 1) << 24)   /* force big-tile configuration i (0..4, see gemm_common.h)      */
+#define ICD_GEMM_TUNE_BIG_CFG(i) (((i) + 1) << 24)   /* force big-tile configuration i (0..5, see gemm_common.h)      */
 
 /* out = alpha * (A (*) W^T) + bias[n] + rowbias[m / rows_per_sample][n] + resid[m][n]
  * A is either a dense row-major [M, K] matrix (mode 0; Linear, 1x1 conv, attention bmm) or the implicit im2col
@@ -488,7 +488,12 @@ typedef struct {
      * kv_cache of icd_unet_kv_cache_bytes() the two context projections of a forward are written there, and a later forward with
      * kv_cache_valid != 0 (the caller vouches that `context`, batch and n_ctx are those of the forward that filled it) skips
      * them and reads the cache.  NULL: projections live in the workspace and are recomputed every forward.  Results are
-     * bit-identical either way. */
+     * bit-identical either way.
+     * INVALIDATION: the cache's layout belongs to the options it was filled under.  With ICD_RESIDUAL_SPLIT + ICD_SPLIT_QK the K rows of the
+     * layers a controller keeps carry an error byte that the plain levels never write: after icd_unet_set_option(ICD_UNET_OPT_RESIDUAL_MODE
+     * / ICD_UNET_OPT_SPLIT_MASK) - and after a change of batch, n_ctx or context - the next forward must run with kv_cache_valid = 0
+     * (icd_unet_kv_cache_bytes may also differ: size it again).  The handle cannot check this: a stale `valid` flag reads bytes the
+     * filling forward did not write.  (unet.UNet2DConditionModel drops its cache on every precision change.) */
     void* kv_cache;
     int64_t kv_cache_bytes;
     int32_t kv_cache_valid;

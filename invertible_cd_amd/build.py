@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libicd_amd.so")
-SOURCES = ["gemm.hip", "gemm_big.hip", "gemm_pp.hip", "norm.hip", "attention.hip", "elementwise.hip", "p2p.hip", "runtime.hip", "error.cpp"]
+SOURCES = ["gemm.hip", "gemm_big.hip", "gemm_pp.hip", "gemm_pp320.hip", "norm.hip", "attention.hip", "elementwise.hip", "p2p.hip", "runtime.hip", "error.cpp"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
 # attention.hip: softmax max-chains need no NaN canonicalisation (infinities are still honoured for the key mask)

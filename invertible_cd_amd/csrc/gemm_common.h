@@ -137,14 +137,18 @@ __device__ __forceinline__ u32x2 carry_of8(const float (&v)[8], const f16x8& o) 
 // chip (about 1.3 - 1.7 us depending on the box's clocks).  tk_full applies when >= 200 CUs are busy (chip-level
 // ceiling: the same block runs about 10 - 20 % slower), tk_part when <= 160.
 struct BigTile { int bm, bn; bool geglu_ok; double tk_part, tk_full, fixed; };
-constexpr int NUM_BIG_TILES = 5;
+constexpr int NUM_BIG_TILES = 6;
 constexpr int PP_TILE = 4;                       // index of the ping-pong 256 x 256 tile (gemm_pp.hip)
+constexpr int PP320_TILE = 5;                    //              ... 256 x 320 tile (gemm_pp320.hip)
 constexpr BigTile BIG_TILES[NUM_BIG_TILES] = {
     {256, 256, true, 1.00, 1.08, 9.5},
     {256, 320, false, 1.07, 1.30, 13.5},
     {192, 256, true, 0.70, 0.76, 9.6},
     {128, 320, false, 0.72, 0.80, 9.0},
     {256, 256, true, 0.90, 0.97, 9.0},           // gemm_pp.hip: the ping-pong main loop (1.585 vs 1.755 us per k-tile at 8192^3, prologue -0.5 us)
+    {256, 320, false, 1.00, 1.21, 14.2},         // gemm_pp320.hip: k-tiles 3 - 7 % cheaper than the lockstep 256 x 320 tile, one more phase of fill and
+                                                 // drain: slower below ~8 k-tiles (131072 x 320 x 320: 60.7 vs 55.3 us), faster from K = 640 on
+                                                 // (32768 x 640 x 640: 37.6 vs 40.6; conv 131072 x 320 x 8640: 604 vs 640) - profiles/r06_tune_*.txt
 };
 // Further configurations were built, measured and removed in round 2 (tools/gemm_timeline.py): a
 // generated hand-scheduled 4-wave 128 x 128 main loop, a 256 x 128 x 32 tile with two co-resident blocks per CU, and a 256 x 160
@@ -153,6 +157,7 @@ constexpr BigTile BIG_TILES[NUM_BIG_TILES] = {
 // power limit (shader clock 1.3 - 1.7 GHz measured inside the main loop, 2.3 GHz when few CUs are busy).
 int launch_big(const GemmK& k, int cfg, hipStream_t st);     // cfg = index into BIG_TILES
 int launch_pp(const GemmK& k, hipStream_t st);               // gemm_pp.hip: the ping-pong 256 x 256 tile (BIG_TILES[PP_TILE])
+int launch_pp320(const GemmK& k, hipStream_t st);            // gemm_pp320.hip: the ping-pong 256 x 320 tile (BIG_TILES[PP320_TILE])
 bool pp_operands_ok(const GemmK& k, bool conv);              // operands addressable by its 31-bit buffer offsets
 
 }  // namespace icd_gemm_detail

@@ -306,12 +306,12 @@ __device__ __forceinline__ void wave_epilogue(const GemmK& p, f32x16 (&acc)[TM][
                         }
                     }
                     if (p.out32) {
-                        float* o32 = p.out32 + (long long)m * p.ldo + n;
+                        float* o32 = p.out32 + out_row(p, m) * p.ldo + n;
                         *reinterpret_cast<f32x4*>(o32) = (f32x4){v[0], v[1], v[2], v[3]};
                         *reinterpret_cast<f32x4*>(o32 + 4) = (f32x4){v[4], v[5], v[6], v[7]};
                     }
-                    if (out_f32) {
-                        float* out = reinterpret_cast<float*>(p.out) + (long long)m * p.ldo + n;
+                    if (out_f32) {                           // (through the row map too: a phase conv with fp32 output, icd_gemm_desc.out_remap_w)
+                        float* out = reinterpret_cast<float*>(p.out) + out_row(p, m) * p.ldo + n;
                         *reinterpret_cast<f32x4*>(out) = (f32x4){v[0], v[1], v[2], v[3]};
                         *reinterpret_cast<f32x4*>(out + 4) = (f32x4){v[4], v[5], v[6], v[7]};
                     } else {

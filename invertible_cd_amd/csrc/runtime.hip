@@ -797,16 +797,19 @@ struct Exec {
                 // (the last upsampler - at the output resolution, damped by nothing downstream - or every one: ICD_SPLIT_UP_ALL)
                 const bool sup = split(ICD_SPLIT_UP) && (i == L - 2 || split(ICD_SPLIT_UP_ALL));
                 const long long hin = (long long)B * Hh * Ww;
+                // (the phase form maps output rows with a divide by the input width: icd_gemm needs out_remap_w >= 2.  A level one pixel wide -
+                //  latents of 2^(levels - 1) pixels, which icd_unet_forward accepts - takes the 3 x 3 form, as before round 5)
+                const bool phases = u->up_phases && Ww >= 2;
                 half_t* lo = nullptr;                // the upsampling conv over [h | lo]
-                if (sup && u->up_phases) {           // ... in the phase form over [h | lo | h] against [W_hi | W_hi | W_lo] (the tap sums are not fp16 numbers)
+                if (sup && phases) {           // ... in the phase form over [h | lo | h] against [W_hi | W_hi | W_lo] (the tap sums are not fp16 numbers)
                     lo = alloc<half_t>(hin * 2 * Cout);
                     if (ok() && !dry) {
                         ProfScope ps(true, st, ICD_PROF_MISC, 0.0, 7.0 * (double)hin * Cout);
                         run(icd_carry_expand2(h.aux, h.p, hin, Cout, lo, st));
                     }
                 } else if (sup) lo = expand(h.aux, hin * Cout);
-                Act la{lo, (sup && u->up_phases) ? 2 * Cout : Cout};
-                if (u->up_phases) {
+                Act la{lo, (sup && phases) ? 2 * Cout : Cout};
+                if (phases) {
                     // nearest 2x + conv3x3 as four 2 x 2 convs on the input grid, one per output pixel phase: 16 tap GEMMs instead of 36
                     for (int ph = 0; ph < 4 && ok(); ++ph) {
                         const std::string wn = upn + (sup ? ".phase3." : ".phase.") + std::to_string(ph);

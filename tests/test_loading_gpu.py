@@ -73,7 +73,8 @@ def test_load_models_from_disk_matches_oracle_fused_weights(tmp_path):
         errs[name + "_vs_unfused"] = _check(pipe.unet, cfg, full, 2, False)
     print("[loader sd15] (error, fp16-torch floor):", {k: f"{e:.3e}/{f:.3e}" for k, (e, f) in errs.items()})
     for k in ("teacher", "reverse", "forward"):
-        assert errs[k][0] <= 1.5 * errs[k][1] + 1e-4 and errs[k][0] < 1.2e-3, (k, errs[k])     # measured 0.73 - 0.83e-3
+        assert errs[k][0] <= 1.5 * errs[k][1] + 1e-4 and errs[k][0] < 1e-3, (k, errs[k])       # the north star's bar on ONE evaluation (round 6:
+        # the 'auto' policy probes the checkpoint - unet._probe_plain_level - and runs plain generation at the accurate level where the fast one is too far off)
     assert errs["reverse_vs_unfused"][0] > 1e-2 and errs["forward_vs_unfused"][0] > 1e-2     # the LoRA really changed the function
 
 
@@ -91,8 +92,10 @@ def test_load_models_xl_from_disk_matches_oracle_fused_weights(tmp_path):
     res = {"teacher": _check(stable.unet, cfg, full, 3, True), "reverse": _check(pipe.unet, cfg, fused_r, 4, True),
            "forward": _check(forw.unet, cfg, fused_f, 4, True), "reverse_vs_unfused": _check(pipe.unet, cfg, full, 4, True)}
     print("[loader sdxl] (error, fp16-torch floor):", {k: f"{e:.3e}/{f:.3e}" for k, (e, f) in res.items()})
+    print("[loader sdxl] precision probe (gap, plain level):", {n: (f"{m.unet._auto_gap:.3e}", m.unet._auto_plain) for n, m in (("teacher", stable), ("reverse", pipe), ("forward", forw))})
     for k in ("teacher", "reverse", "forward"):
-        assert res[k][0] <= 1.5 * res[k][1] + 1e-4 and res[k][0] < 1.2e-3, (k, res[k])       # measured 0.80 - 0.99e-3 (the fused LoRA widens the activations)
+        assert res[k][0] <= 1.5 * res[k][1] + 1e-4 and res[k][0] < 1e-3, (k, res[k])         # round 6 (was 1.2e-3: the fused LoRA widens the activations,
+        # 1.04e-3 at the fast level - the probe of the 'auto' policy now sees that on the checkpoint itself and escalates)
     assert res["reverse_vs_unfused"][0] > 1e-2
 
 

@@ -97,32 +97,37 @@ def test_gemm_big_tile_dense(M, N, K):
 
 
 PP_TILE_FLAG = 5 << 24                               # ICD_GEMM_TUNE_BIG_CFG(4): the ping-pong 256 x 256 tile (gemm_pp.hip)
+PP320_TILE_FLAG = 6 << 24                            # ICD_GEMM_TUNE_BIG_CFG(5): the ping-pong 256 x 320 tile (gemm_pp320.hip)
 
 
-@pytest.mark.parametrize("M,N,K", [(512, 256, 64), (300, 512, 128), (1000, 1280, 1344), (1024, 1280, 320), (256, 256, 4096), (2048, 2560, 1280),
-                                   (777, 256, 192)])
-def test_gemm_ping_pong_tile(M, N, K):
-    """The ping-pong ("8-phase") 256 x 256 tile forced on small and ragged shapes: 1, 2, 3, odd and even k-tile counts (prologue / tail of
-    the counted-vmcnt pipeline), ragged M, split-K where the planner splits, bias + residual, GEGLU, plain."""
+@pytest.mark.parametrize("tile", [256, 320])
+@pytest.mark.parametrize("M,nn,K", [(512, 1, 64), (300, 2, 128), (1000, 4, 1344), (1024, 4, 320), (256, 1, 4096), (2048, 8, 1280), (777, 1, 192)])
+def test_gemm_ping_pong_tile(M, nn, K, tile):
+    """The ping-pong ("8-phase") tiles forced on small and ragged shapes: 1, 2, 3, odd and even k-tile counts (prologue / tail of the
+    counted-vmcnt pipelines), ragged M, split-K where the planner splits, bias + residual, GEGLU (256 x 256), plain."""
     ops = _ops()
+    N = nn * tile
+    flag, lockstep = (PP_TILE_FLAG, 1 << 24) if tile == 256 else (PP320_TILE_FLAG, 2 << 24)
     a, w = r16(M, K, seed=661), r16(N, K, seed=662, scale=K ** -0.5)
     bias = torch.randn(N, generator=torch.Generator().manual_seed(663))
     res = r16(M, N, seed=664)
     ref = a.float() @ w.float().t()
+    assert _lib_plan(ops, M, N, K, flag).tile_n == tile
     for _ in range(3):                                # a race in the staging pipeline would come and go between runs
-        out = ops.gemm(a.cuda(), w.cuda(), bias=bias.cuda(), resid=res.cuda(), debug_flags=PP_TILE_FLAG)
+        out = ops.gemm(a.cuda(), w.cuda(), bias=bias.cuda(), resid=res.cuda(), debug_flags=flag)
         assert rel_l2(out, ref + bias + res.float()) < TOL
-    plain = ops.gemm(a.cuda(), w.cuda(), debug_flags=PP_TILE_FLAG)
+    plain = ops.gemm(a.cuda(), w.cuda(), debug_flags=flag)
     assert rel_l2(plain, ref) < TOL
-    # bit-identical to the lockstep 256 x 256 tile: same k order, same accumulator layout, same epilogue
-    assert torch.equal(plain, ops.gemm(a.cuda(), w.cuda(), debug_flags=1 << 24))
-    perm = ops.geglu_perm(N // 2)
-    outg = ops.gemm(a.cuda(), w[perm].contiguous().cuda(), bias=bias[perm].contiguous().cuda(), geglu=True, debug_flags=PP_TILE_FLAG)
-    val, gate = (ref + bias).chunk(2, dim=-1)
-    assert rel_l2(outg, val * F.gelu(gate)) < TOL
+    # bit-identical to the lockstep tile of the same shape: same k order, same accumulator layout, same epilogue
+    assert torch.equal(plain, ops.gemm(a.cuda(), w.cuda(), debug_flags=lockstep))
+    if tile == 256:
+        perm = ops.geglu_perm(N // 2)
+        outg = ops.gemm(a.cuda(), w[perm].contiguous().cuda(), bias=bias[perm].contiguous().cuda(), geglu=True, debug_flags=flag)
+        val, gate = (ref + bias).chunk(2, dim=-1)
+        assert rel_l2(outg, val * F.gelu(gate)) < TOL
 
 
-@pytest.mark.parametrize("cfg_i", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("cfg_i", [0, 1, 2, 3, 4, 5])
 def test_gemm_every_big_tile_configuration(cfg_i):
     """Each gemm_big.hip configuration forced in turn (ICD_GEMM_TUNE_BIG_CFG): dense with bias + residual on a ragged M, the
     transposed (V^T) epilogue and a 3x3 conv with time bias."""
@@ -154,7 +159,8 @@ def test_gemm_every_big_tile_configuration(cfg_i):
                                                (1000, 1280, 2560, 2 << 24, False), (1000, 1280, 2560, 1 << 24, True),
                                                (1000, 1280, 1280, 4 << 24, False), (2048, 320, 320, 0x100000, False),
                                                (1000, 1280, 2560, (2 << 24) | 0x800000, False), (1000, 1280, 2560, 5 << 24, False),
-                                               (1000, 1280, 2560, 5 << 24, True), (700, 320, 1280, 5 << 24, False)])
+                                               (1000, 1280, 2560, 5 << 24, True), (700, 320, 1280, 5 << 24, False),
+                                               (1000, 1280, 2560, 6 << 24, False), (700, 320, 1280, 6 << 24, False), (2048, 320, 320, 6 << 24, False)])
 def test_gemm_computes_the_layernorm_statistics_it_applies(M, C, N, flags, geglu):
     """ICD_GEMM_LN_COMPUTE: the GEMM behind a LayerNorm computes (mean, rstd) of its A rows itself - the big tiles from the MFMA
     operand fragments of their main loop (v_dot2 sums in the waves of tile column 0, an LDS table feeds the epilogue, n-tile 0
@@ -191,7 +197,8 @@ def test_gemm_computes_the_layernorm_statistics_it_applies(M, C, N, flags, geglu
 
 
 @pytest.mark.parametrize("ratio", [50.0, 3.0, 0.0])
-@pytest.mark.parametrize("M,C,N,flags", [(1024, 640, 1280, 0x100000), (2048, 320, 320, 0x100000), (512, 1280, 1280, 3 << 24), (512, 1280, 1280, 5 << 24)])
+@pytest.mark.parametrize("M,C,N,flags", [(1024, 640, 1280, 0x100000), (2048, 320, 320, 0x100000), (512, 1280, 1280, 3 << 24), (512, 1280, 1280, 5 << 24),
+                                         (512, 1280, 1280, 6 << 24)])
 def test_in_loop_layernorm_statistics_survive_a_large_row_offset(M, C, N, flags, ratio):
     """ICD_GEMM_LN_COMPUTE on the big tiles sums x and x^2 of each row from the MFMA operand fragments (one pass).  E[x^2] - mean^2
     cancels when a row's offset dominates its spread: at |mean| / sigma = 50 the one-pass variance alone is off by ~2.5e-3.  Rows with
@@ -575,6 +582,25 @@ def test_upsampling_conv_in_phase_form(B, H, W, C, Co):
     print(f"[upsample phases B={B} {H}x{W} C={C}->{Co}] phase form {e_new:.3e}, 3x3 form {e_old:.3e}")
     assert e_new < 3e-4 and e_old < 3e-4                    # (fp16 output rounding 1.7e-4 + the fp16 rounding of the summed taps)
     assert rel_l2(ops.carry_decode(out, oc), ref) < 0.6 * e_new
+
+
+def test_phase_form_conv_with_fp32_output_lands_on_the_mapped_rows():
+    """the row map of the phase form (icd_gemm_desc.out_remap_w) also applies to ICD_GEMM_OUT_F32 outputs on the big tiles
+    (their general epilogue wrote GEMM row m instead of the mapped row)."""
+    ops = _ops()
+    from invertible_cd_amd.unet import upsample_phase_weights
+    B, H, W, C, Co = 2, 16, 16, 1280, 1280
+    x = r16(B, C, H, W, seed=70)
+    w = r16(Co, C, 3, 3, seed=71, scale=(9 * C) ** -0.5)
+    xn = to_nhwc(x).cuda()
+    o16 = torch.empty(B * 4 * H * W, Co, device="cuda", dtype=torch.float16)
+    o32 = torch.full((B * 4 * H * W, Co), float("nan"), device="cuda", dtype=torch.float32)
+    for ph, wp in enumerate(upsample_phase_weights(w)):
+        wq = wp.reshape(Co, -1).half().contiguous().cuda()
+        ops.conv3x3(xn, B, H, W, wq, None, phase=ph, out=o16)
+        ops.conv3x3(xn, B, H, W, wq, None, phase=ph, out=o32, out_f32=True)
+    assert torch.isfinite(o32).all()                         # every row of the fp32 output was written ...
+    assert torch.equal(o32.half(), o16)                      # ... with the value the fp16 output rounds
 
 
 def test_error_carry_saturates_instead_of_overflowing():

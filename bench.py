@@ -87,6 +87,9 @@ def parse():
     ap.add_argument("--no-fused-epilogue", action="store_true",
                     help="edit leg: accumulate the attention store with a launch of its own per hooked layer instead of in the probability "
                          "kernel's epilogue (A/B of icd_probs_epilogue)")
+    ap.add_argument("--gemm-tune", type=lambda v: int(v, 0), default=0,
+                    help="A/B switch (UNet option gemm_tune): ICD_GEMM_TUNE_* planner bits for every GEMM launch, e.g. 0x20000000 = never the "
+                         "ping-pong tiles (gemm_pp*.hip): the lockstep tiles of rounds 1-5")
     ap.add_argument("--attn-valu-scale", type=int, default=0, choices=[0, 1],
                     help="A/B switch (UNet option attn_valu_scale): 1 = flash attention applies the softmax offset with an FMA per score "
                          "on the VALU, 0 (default) = the MFMA subtracts it")
@@ -477,6 +480,8 @@ def run_reverse(a, wl, arch, batch, steps, warmup, device, world, rank, primary)
     from invertible_cd_amd import dist_utils
     wl.net.set_option("ln_inline_stats", a.ln_inline_stats).set_option("xattn_fusion", a.xattn_fusion)     # per-handle A/B switches
     wl.net.set_option("attn_valu_scale", a.attn_valu_scale).set_option("xattn_tile", a.xattn_tile)
+    if a.gemm_tune:
+        wl.net.set_option("gemm_tune", a.gemm_tune)
     set_precision(a, wl.net)
     step = wl.reverse_step(batch)
     group = workload_group(wl, a.in_flight)              # this workload + its replicas (same weights, own handle / arena / stream)

@@ -437,6 +437,10 @@ int32_t icd_unet_num_attention_layers(const icd_unet* u);
  * output pixel phase, with tap-summed weights `<name>.phase.<2 py + px>` (icd_gemm_desc.conv_ktaps): 4/9 of the flops; 0 = the 3 x 3
  * conv with the upsampling folded into its loader (rounds 1 - 4). */
 #define ICD_UNET_OPT_UPSAMPLE_PHASES 7
+/* ICD_UNET_OPT_GEMM_TUNE: ICD_GEMM_TUNE_* planner bits (NO_PP, NO_BIG, BN256) OR-ed into every icd_gemm launch of this handle: same-process, same-box
+ * A/B of a tile family over a whole forward (bench.py --gemm-tune); 0 (default) = the planner's own choice.  Results differ by fp32 summation
+ * order where a different split-K plan is taken, not otherwise. */
+#define ICD_UNET_OPT_GEMM_TUNE       8
 #define ICD_SPLIT_GN          1    /* every GroupNorm normalises fp16 + carry (skip tensors keep their carry for it) */
 #define ICD_SPLIT_CONV1       2    /* conv1 of a ResnetBlock2D hands its output to GroupNorm 2 with a carry */
 #define ICD_SPLIT_SHORTCUT    4    /* conv_shortcut over [x | lo] (needs ICD_SPLIT_GN: that GroupNorm writes lo) */

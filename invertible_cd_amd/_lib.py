@@ -23,6 +23,8 @@ ICD_UNET_OPT_RESIDUAL_MODE = 5
 ICD_UNET_OPT_RESIDUAL_F32 = 5           # round-3 name
 ICD_UNET_OPT_SPLIT_MASK = 6
 ICD_UNET_OPT_UPSAMPLE_PHASES = 7
+ICD_UNET_OPT_GEMM_TUNE = 8
+ICD_GEMM_TUNE_NO_PP = 0x20000000
 ICD_SPLIT_GN, ICD_SPLIT_CONV1, ICD_SPLIT_SHORTCUT, ICD_SPLIT_PROJ_OUT, ICD_SPLIT_DOWN, ICD_SPLIT_SAMPLER_OUT, ICD_SPLIT_UP, ICD_SPLIT_TEMB = 1, 2, 4, 8, 16, 32, 64, 128
 ICD_SPLIT_QK = 256
 ICD_SPLIT_UP_ALL = 512

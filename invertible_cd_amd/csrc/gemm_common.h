@@ -150,6 +150,9 @@ constexpr BigTile BIG_TILES[NUM_BIG_TILES] = {
                                                  // drain: slower below ~8 k-tiles (131072 x 320 x 320: 60.7 vs 55.3 us), faster from K = 640 on
                                                  // (32768 x 640 x 640: 37.6 vs 40.6; conv 131072 x 320 x 8640: 604 vs 640) - profiles/r06_tune_*.txt
 };
+// Round 6: 128 x 320 / 128 x 256 tiles with four waves and TWO co-resident blocks per CU on a 32-wide k-step (gemm_duo.hip) were built for the
+// short-K dense layers, measured and removed: 131072 x 320 x 320 58.1 us against 55.8 on the 256 x 320 tile, the K = 320 GEGLU projection
+// 386.8 against 330.8 (profiles/r06_duo_tiles.txt) - two blocks sharing a CU do not hide each other's epilogue any better than the chip already does.
 // Further configurations were built, measured and removed in round 2 (tools/gemm_timeline.py): a
 // generated hand-scheduled 4-wave 128 x 128 main loop, a 256 x 128 x 32 tile with two co-resident blocks per CU, and a 256 x 160
 // tile (exactly 256 blocks for M = 8192, N = 1280) both as 4 waves of 64 x 160 and as 8 waves sharing each wave tile between

@@ -143,6 +143,7 @@ struct icd_unet {
     // Upsample2D (nearest 2x + conv3x3) as four 2 x 2 convs on the input grid with tap-summed weights (icd_gemm_desc.conv_ktaps):
     // 4/9 of the flops of the 3 x 3 conv on the upsampled map - 8.5 % of an SD1.5 forward's flops become 3.8 %.  0: the 3 x 3 form (A/B).
     bool up_phases = true;
+    int gemm_tune = 0;           // ICD_UNET_OPT_GEMM_TUNE: ICD_GEMM_TUNE_* bits OR-ed into every icd_gemm launch of the executor (A/B)
 };
 
 namespace {
@@ -225,6 +226,7 @@ struct Exec {
         ProfScope ps(true, st, d.mode == 1 ? ICD_PROF_GEMM_CONV : (nb > 1 ? ICD_PROF_GEMM_BATCHED : ICD_PROF_GEMM_DENSE),
                      af, 0.0, d.M, d.N, d.K, d.mode == 1 ? d.ksize * 100 + d.stride * 10 + d.upsample : d.flags);
         ps.executed(xf);
+        d.flags |= u->gemm_tune;
         ps.plan(d);
         run(icd_gemm(&d, st));
     }
@@ -890,6 +892,10 @@ extern "C" int icd_unet_set_option(icd_unet* u, int32_t option, int32_t value) {
     case ICD_UNET_OPT_LN_INLINE_STATS:
         ICD_CHECK_ARG(value == 0 || value == 1, "icd_unet_set_option: ICD_UNET_OPT_LN_INLINE_STATS takes 0 or 1 (got %d)", value);
         u->ln_inline = value != 0; return ICD_OK;
+    case ICD_UNET_OPT_GEMM_TUNE:
+        ICD_CHECK_ARG((value & ~(ICD_GEMM_TUNE_NO_PP | ICD_GEMM_TUNE_NO_BIG | ICD_GEMM_TUNE_BN256)) == 0,
+                      "icd_unet_set_option: ICD_UNET_OPT_GEMM_TUNE takes ICD_GEMM_TUNE_NO_PP / _NO_BIG / _BN256 bits (got 0x%x)", value);
+        u->gemm_tune = value; return ICD_OK;
     }
     icd_set_error("icd_unet_set_option: unknown option %d", option);
     return ICD_ERR_INVALID_ARG;

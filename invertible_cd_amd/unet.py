@@ -285,7 +285,8 @@ class UNet2DConditionModel:
     OPTIONS = {"xattn_fusion": _lib.ICD_UNET_OPT_XATTN_FUSION, "ln_inline_stats": _lib.ICD_UNET_OPT_LN_INLINE_STATS,
                "xattn_tile": _lib.ICD_UNET_OPT_XATTN_TILE, "attn_valu_scale": _lib.ICD_UNET_OPT_ATTN_VALU_SCALE,
                "residual": _lib.ICD_UNET_OPT_RESIDUAL_MODE, "residual_f32": _lib.ICD_UNET_OPT_RESIDUAL_MODE,
-               "split_mask": _lib.ICD_UNET_OPT_SPLIT_MASK, "upsample_phases": _lib.ICD_UNET_OPT_UPSAMPLE_PHASES}
+               "split_mask": _lib.ICD_UNET_OPT_SPLIT_MASK, "upsample_phases": _lib.ICD_UNET_OPT_UPSAMPLE_PHASES,
+               "gemm_tune": _lib.ICD_UNET_OPT_GEMM_TUNE}
 
     # ------------------------------------------------------------------ precision policy
     # Numerical precision of the residual stream and of its consumers (icd_unet options residual / split_mask):

@@ -35,7 +35,7 @@ def main():
     batch = a.batch or (32 if a.arch == "sd15" else 8)
     step = wl.reverse_step(batch) if a.leg == "reverse" else wl.edit_step(batch)
     names = [o.split("=")[0] for o in a.opt]
-    values = [[int(v) for v in o.split("=")[1].split(",")] for o in a.opt]
+    values = [[int(v, 0) for v in o.split("=")[1].split(",")] for o in a.opt]
     variants = [dict(zip(names, combo)) for combo in itertools.product(*values)] or [{}]
 
     def apply(v):

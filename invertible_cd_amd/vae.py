@@ -240,6 +240,7 @@ class AutoencoderKL:
         self._ws = None                        # split3 weights of the fp32-fidelity path, packed on first use
         self.max_chunk = max_chunk            # samples per pass (bounds the 512x512x128-channel activations and the scores)
         self.fused_attention = fused_attention    # None: fused flash kernel when the head dim allows it (<= 160)
+        self.carry = True                         # fp16 path: error-carried residual stream + GroupNorm over fp16 + carry (round 6); False: plain fp16 stream
         self.upsample_phases = True               # fp16 decoder: Upsample2D as four 2 x 2 convs on the input grid (4/9 of its flops); False: 3 x 3 form
 
     # -- diffusers plumbing the reference uses
@@ -399,21 +400,36 @@ class AutoencoderKL:
     def eval(self):
         return self
 
-    # -- blocks (token-major fp16 [B*H*W, C])
-    def _resnet(self, p, x, B, H, W):
-        w, g = self.w, self.cfg.norm_num_groups
-        h = ops.groupnorm(x, B, H * W, w[p + "norm1.weight"], w[p + "norm1.bias"], EPS, True, groups=g)
-        h = ops.conv3x3(h, B, H, W, w[p + "conv1.weight"], w[p + "conv1.bias"])
-        h = ops.groupnorm(h, B, H * W, w[p + "norm2.weight"], w[p + "norm2.bias"], EPS, True, groups=g)
-        sc = x
-        if p + "conv_shortcut.weight" in w:
-            sc = ops.gemm(x, w[p + "conv_shortcut.weight"], w[p + "conv_shortcut.bias"])
-        return ops.conv3x3(h, B, H, W, w[p + "conv2.weight"], w[p + "conv2.bias"], resid=sc)
+    # -- blocks (token-major fp16 [B*H*W, C]).  Round 6: the residual stream carries its rounding error (`self.carry`, default on): every
+    # x <- x + f(x) of a ResnetBlock2D / the mid-block attention keeps what the fp16 rounding of the sum lost in one bf8 byte per element
+    # (icd_gemm_desc.resid_carry / out_carry, the UNet's residual mode 2) and every GroupNorm normalises fp16 + carry (icd_groupnorm_carry):
+    # the stream behaves like a 14-bit-mantissa tensor.  A stream is the pair (x, xc); xc None = no carry yet.
+    def _gn(self, x, xc, B, HW, wk, bk, silu):
+        g = self.cfg.norm_num_groups
+        if xc is None:
+            return ops.groupnorm(x, B, HW, self.w[wk], self.w[bk], EPS, silu, groups=g)
+        return ops.groupnorm_carry(x, B, HW, self.w[wk], self.w[bk], EPS, silu, carry=xc, groups=g)
 
-    def _attention(self, p, x, B, H, W):
-        w, g = self.w, self.cfg.norm_num_groups
+    def _oc(self, rows, cols, like):
+        return torch.empty((rows, cols), device=like.device, dtype=torch.uint8) if self.carry else None
+
+    def _resnet(self, p, x, xc, B, H, W):
+        w = self.w
+        h = self._gn(x, xc, B, H * W, p + "norm1.weight", p + "norm1.bias", True)
+        c1 = self._oc(h.shape[0], w[p + "conv1.weight"].shape[0], h)
+        h = ops.conv3x3(h, B, H, W, w[p + "conv1.weight"], w[p + "conv1.bias"], out_carry=c1)
+        h = self._gn(h, c1, B, H * W, p + "norm2.weight", p + "norm2.bias", True)
+        sc, scc = x, xc
+        if p + "conv_shortcut.weight" in w:
+            scc = self._oc(x.shape[0], w[p + "conv_shortcut.weight"].shape[0], x)
+            sc = ops.gemm(x, w[p + "conv_shortcut.weight"], w[p + "conv_shortcut.bias"], out_carry=scc)
+        oc = self._oc(sc.shape[0], sc.shape[1], sc)
+        return ops.conv3x3(h, B, H, W, w[p + "conv2.weight"], w[p + "conv2.bias"], resid=sc, resid_carry=scc, out_carry=oc), oc
+
+    def _attention(self, p, x, xc, B, H, W):
+        w = self.w
         C, N = x.shape[1], H * W
-        h = ops.groupnorm(x, B, N, w[p + "group_norm.weight"], w[p + "group_norm.bias"], EPS, False, groups=g)
+        h = self._gn(x, xc, B, N, p + "group_norm.weight", p + "group_norm.bias", False)
         qk = ops.gemm(h, w[p + "to_qk.weight"], w[p + "to_qk.bias"])
         q, k = qk[:, :C], qk[:, C:]
         ld = (N + 7) // 8 * 8
@@ -430,12 +446,13 @@ class AutoencoderKL:
                 s = ops.attention_scores(q[b0 * N:(b0 + bc) * N], k[b0 * N:(b0 + bc) * N], bc, 1, N, N, C, scale, ld)
                 pr = ops.softmax_rows(s.reshape(bc * N, ld), N, ld).reshape(bc, N, ld)
                 ops.attention_apply(pr, vt[b0:b0 + bc], bc, 1, N, C, out=o[b0 * N:(b0 + bc) * N])
-        return ops.gemm(o, w[p + "to_out.weight"], w[p + "to_out.bias"], resid=x)
+        oc = self._oc(x.shape[0], x.shape[1], x)
+        return ops.gemm(o, w[p + "to_out.weight"], w[p + "to_out.bias"], resid=x, resid_carry=xc, out_carry=oc), oc
 
-    def _mid(self, p, x, B, H, W):
-        x = self._resnet(p + "resnets.0.", x, B, H, W)
-        x = self._attention(p + "attentions.0.", x, B, H, W)
-        return self._resnet(p + "resnets.1.", x, B, H, W)
+    def _mid(self, p, x, xc, B, H, W):
+        x, xc = self._resnet(p + "resnets.0.", x, xc, B, H, W)
+        x, xc = self._attention(p + "attentions.0.", x, xc, B, H, W)
+        return self._resnet(p + "resnets.1.", x, xc, B, H, W)
 
     # -- public
     @torch.no_grad()
@@ -455,24 +472,26 @@ class AutoencoderKL:
         w, cfg = self.w, self.cfg
         B, _, H, W = z.shape
         x = ops.pack_nchw(z, ones_channel=cfg.latent_channels)
-        x = ops.conv3x3(x, B, H, W, w["decoder.conv_in.weight"], w["decoder.conv_in.bias"])
-        x = self._mid("decoder.mid_block.", x, B, H, W)
+        xc = self._oc(B * H * W, w["decoder.conv_in.weight"].shape[0], x)
+        x = ops.conv3x3(x, B, H, W, w["decoder.conv_in.weight"], w["decoder.conv_in.bias"], out_carry=xc)
+        x, xc = self._mid("decoder.mid_block.", x, xc, B, H, W)
         nb = len(cfg.block_out_channels)
         for i in range(nb):
             for j in range(cfg.layers_per_block + 1):
-                x = self._resnet(f"decoder.up_blocks.{i}.resnets.{j}.", x, B, H, W)
+                x, xc = self._resnet(f"decoder.up_blocks.{i}.resnets.{j}.", x, xc, B, H, W)
             if i < nb - 1:
                 k = f"decoder.up_blocks.{i}.upsamplers.0.conv."
+                uc = self._oc(B * 4 * H * W, x.shape[-1], x)
                 if self.upsample_phases and W >= 2:
                     up = torch.empty((B * 4 * H * W, x.shape[-1]), device=x.device, dtype=torch.float16)
                     for ph in range(4):
-                        ops.conv3x3(x, B, H, W, w[k + f"phase.{ph}"], w[k + "bias"], phase=ph, out=up)
+                        ops.conv3x3(x, B, H, W, w[k + f"phase.{ph}"], w[k + "bias"], phase=ph, out=up, out_carry=uc)
                     x = up
                 else:
-                    x = ops.conv3x3(x, B, H, W, w[k + "weight"], w[k + "bias"], upsample=True)
+                    x = ops.conv3x3(x, B, H, W, w[k + "weight"], w[k + "bias"], upsample=True, out_carry=uc)
+                xc = uc
                 H, W = 2 * H, 2 * W
-        x = ops.groupnorm(x, B, H * W, w["decoder.conv_norm_out.weight"], w["decoder.conv_norm_out.bias"], EPS, True,
-                          groups=cfg.norm_num_groups)
+        x = self._gn(x, xc, B, H * W, "decoder.conv_norm_out.weight", "decoder.conv_norm_out.bias", True)
         return ops.conv_out(x, B, H, W, w["decoder.conv_out.weight"], w["decoder.conv_out.bias"],
                             out_dtype=torch.float32 if self.dtype == torch.float32 else torch.float16, cout=cfg.out_channels)
 
@@ -495,18 +514,20 @@ class AutoencoderKL:
         w, cfg = self.w, self.cfg
         B, _, H, W = img.shape
         x = ops.pack_nchw(img)
-        x = ops.conv3x3(x, B, H, W, w["encoder.conv_in.weight"], w["encoder.conv_in.bias"])
+        xc = self._oc(B * H * W, w["encoder.conv_in.weight"].shape[0], x)
+        x = ops.conv3x3(x, B, H, W, w["encoder.conv_in.weight"], w["encoder.conv_in.bias"], out_carry=xc)
         nb = len(cfg.block_out_channels)
         for i in range(nb):
             for j in range(cfg.layers_per_block):
-                x = self._resnet(f"encoder.down_blocks.{i}.resnets.{j}.", x, B, H, W)
+                x, xc = self._resnet(f"encoder.down_blocks.{i}.resnets.{j}.", x, xc, B, H, W)
             if i < nb - 1:
                 k = f"encoder.down_blocks.{i}.downsamplers.0.conv."
-                x = ops.conv3x3(x, B, H, W, w[k + "weight"], w[k + "bias"], stride=2, pad_hi=True)
+                dc = self._oc(B * (H // 2) * (W // 2), x.shape[-1], x)
+                x = ops.conv3x3(x, B, H, W, w[k + "weight"], w[k + "bias"], stride=2, pad_hi=True, out_carry=dc)
+                xc = dc
                 H, W = H // 2, W // 2
-        x = self._mid("encoder.mid_block.", x, B, H, W)
-        x = ops.groupnorm(x, B, H * W, w["encoder.conv_norm_out.weight"], w["encoder.conv_norm_out.bias"], EPS, True,
-                          groups=cfg.norm_num_groups)
+        x, xc = self._mid("encoder.mid_block.", x, xc, B, H, W)
+        x = self._gn(x, xc, B, H * W, "encoder.conv_norm_out.weight", "encoder.conv_norm_out.bias", True)
         od = torch.float32 if self.dtype == torch.float32 else torch.float16
         mean = ops.conv_out(x, B, H, W, w["encoder.conv_out_mean.weight"], w["encoder.conv_out_mean.bias"], out_dtype=od, cout=4)
         logvar = ops.conv_out(x, B, H, W, w["encoder.conv_out_logvar.weight"], w["encoder.conv_out_logvar.bias"], out_dtype=od, cout=4)

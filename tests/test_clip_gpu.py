@@ -62,7 +62,7 @@ def test_full_clip_vit_l():
     e = rel_l2(got.float().cpu(), ref["last_hidden_state"])
     e2 = rel_l2(out.hidden_states[-2].float().cpu(), ref["hidden_states"][-2])
     print(f"[clip ViT-L full] last_hidden_state rel-L2 = {e:.3e}, hidden_states[-2] = {e2:.3e}")
-    assert e < 3e-3 and e2 < 3e-3
+    assert e < 1e-3 and e2 < 1e-3                        # round 6: fp32 twin of the residual stream (1.07e-3 / 1.03e-3 on the plain fp16 stream)
 
 
 def test_bigg_width_four_layers_with_projection():
@@ -73,7 +73,7 @@ def test_bigg_width_four_layers_with_projection():
     e = rel_l2(out.hidden_states[-2].float().cpu(), ref["hidden_states"][-2])
     e2 = rel_l2(out[0].float().cpu(), ref["text_embeds"])
     print(f"[clip bigG width] hidden_states[-2] rel-L2 = {e:.3e}, text_embeds = {e2:.3e}")
-    assert e < 3e-3 and e2 < 3e-3 and out[0].shape == (2, 1280)
+    assert e < 1e-3 and e2 < 1e-3 and out[0].shape == (2, 1280)
 
 
 def test_interface_errors():

@@ -1,7 +1,7 @@
 """AutoencoderKL on the HIP kernels vs the CPU oracle (oracle/vae_ref.py) - SURVEY.md section 8f rank 1.
 
 Reduced widths for the oracle-checked cases (the oracle finishes in seconds), full SD-VAE width for size-independent
-properties.  Tolerance: rel-L2 <= 3e-3 against the fp32 oracle on identical fp16-representable weights (the decoder chains
+properties.  Tolerance: rel-L2 < 1e-3 (round 6; 3e-3 before the residual stream carried its rounding error) against the fp32 oracle on identical fp16-representable weights (the decoder chains
 ~30 fp16-storage operators; measured values are printed).
 """
 import pytest
@@ -36,13 +36,13 @@ def test_decode_matches_oracle(widths, fused):
     assert got.shape == ref.shape == (2, 3, 128, 192)
     e = rel_l2(got, ref)
     print(f"[vae decode {widths} fused={fused}] rel-L2 = {e:.3e}")
-    assert e < 3e-3
+    assert e < 1e-3                                       # round 6: error-carried residual stream (1.3e-3 on the plain fp16 stream)
     # round 5: the decoder's three Upsample2D convs run in phase form (four 2 x 2 convs on the input grid); the 3 x 3 form stays selectable
     m.upsample_phases = False
     old = m.decode(z.cuda())["sample"].float().cpu()
     e_old = rel_l2(old, ref)
     print(f"[vae decode {widths} fused={fused}] 3x3 upsampler form rel-L2 = {e_old:.3e}, distance between the forms {rel_l2(got, old):.3e}")
-    assert e_old < 3e-3 and abs(e - e_old) < 3e-4 and not torch.equal(got, old)
+    assert e_old < 1e-3 and abs(e - e_old) < 3e-4 and not torch.equal(got, old)
 
 
 @pytest.mark.parametrize("widths,fused", [((32, 64, 128, 128), True), ((32, 64, 128, 128), False)])
@@ -57,7 +57,7 @@ def test_encode_mean_matches_oracle(widths, fused):
     assert got.shape == ref.shape == (2, 4, 16, 24)
     e = rel_l2(got, ref)
     print(f"[vae encode {widths} fused={fused}] rel-L2 = {e:.3e}")
-    assert e < 3e-3
+    assert e < 1e-3
 
 
 def test_odd_latent_sizes_round_trip_shapes_and_parity():
@@ -67,10 +67,10 @@ def test_odd_latent_sizes_round_trip_shapes_and_parity():
     z = (torch.randn(2, 4, 9, 13, generator=torch.Generator().manual_seed(10)) * 1.5).half().float()
     got = m.decode(z.cuda())["sample"].float().cpu()
     ref = vae_ref.decode(sd, ocfg, z)
-    assert got.shape == ref.shape == (2, 3, 72, 104) and rel_l2(got, ref) < 3e-3
+    assert got.shape == ref.shape == (2, 3, 72, 104) and rel_l2(got, ref) < 1e-3
     x = ref.clamp(-1, 1).half().float()
     e = rel_l2(m.encode(x.cuda())["latent_dist"].mean.float().cpu(), vae_ref.encode_mean(sd, ocfg, x))
-    assert e < 3e-3
+    assert e < 1e-3
 
 
 def test_chunking_and_interface():
@@ -120,7 +120,7 @@ def test_encode_moments_and_sample_match_oracle():
     mom = vae_ref.encode_moments(sd, ocfg, x)
     e_mean, e_lv = rel_l2(d.mean.cpu(), mom[:, :4]), rel_l2(d.logvar.cpu(), mom[:, 4:].clamp(-30, 20))
     print(f"[vae moments] mean rel-L2 = {e_mean:.3e}  logvar rel-L2 = {e_lv:.3e}")
-    assert e_mean < 3e-3 and e_lv < 3e-3
+    assert e_mean < 1e-3 and e_lv < 1e-3
     assert torch.allclose(d.std, torch.exp(0.5 * d.logvar)) and torch.allclose(d.var, torch.exp(d.logvar))
     s1 = d.sample(torch.Generator().manual_seed(21))
     noise = torch.randn(d.mean.shape, generator=torch.Generator().manual_seed(21), dtype=d.mean.dtype)

@@ -4,7 +4,7 @@
 # (writes gpurun_out/<tag>/...; copy the summaries you want judged into profiles/).  The rocprofv3 passes run with ONE batch in flight
 # (--in-flight 1): per-kernel durations and counters are those of the roofline pass of the bench line, undisturbed by a second stream.
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 cd "$(dirname "$0")/.."

@@ -69,8 +69,9 @@ const char* icd_build_sha(void);
 #define ICD_GEMM_TUNE_NO_BIG     0x00200000   /* never take one                                                      */
 #define ICD_GEMM_TUNE_NO_LN_INLINE 0x00800000 /* ICD_GEMM_LN_COMPUTE: always take the separate statistics launch (A/B)        */
 #define ICD_GEMM_TUNE_BN256      0x00400000   /* big tiles: only the BN = 256 shapes                                 */
+#define ICD_GEMM_TUNE_PP_V1      0x10000000   /* ping-pong 256 x 256 tile, dense, no carry: its first schedule (reads 12 / 4 / 8 / 0 per phase, one vmcnt(6) per k-tile): A/B */
 #define ICD_GEMM_TUNE_NO_PP      0x20000000   /* never take the ping-pong 256 x 256 tile (gemm_pp.hip): A/B against the lockstep tiles */
-#define ICD_GEMM_TUNE_BIG_CFG(i) (((i) + 1) << 24)   /* force big-tile configuration i (0..5, see gemm_common.h)      */
+#define ICD_GEMM_TUNE_BIG_CFG(i) (((i) + 1) << 24)   /* force big-tile configuration i (0..6, see gemm_common.h)      */
 
 /* out = alpha * (A (*) W^T) + bias[n] + rowbias[m / rows_per_sample][n] + resid[m][n]
  * A is either a dense row-major [M, K] matrix (mode 0; Linear, 1x1 conv, attention bmm) or the implicit im2col

@@ -881,7 +881,10 @@ static int gemm_run(const icd_gemm_desc* d, void* stream, icd_gemm_plan_info* in
         for (int ci = 0; ci < NUM_BIG_TILES && base_ok; ++ci) {
             const BigTile& c = BIG_TILES[ci];
             if (forced >= 0 && ci != forced) continue;
-            if ((ci == PP_TILE || ci == PP320_TILE) && (!pp_operands_ok(k, d->mode == 1) || (d->flags & ICD_GEMM_TUNE_NO_PP))) continue;
+            // (the 192-row ping-pong tile serves the dense M = 8192-class layers; as a conv tile it measured 7 % behind the 256 x 320 one on
+            //  8192 x 1280 x 11520 / 17280 - more operand bytes per flop - and is taken for convs only when forced)
+            if (ci == PP192_TILE && d->mode == 1 && forced != ci) continue;
+            if ((ci == PP_TILE || ci == PP320_TILE || ci == PP192_TILE) && (!pp_operands_ok(k, d->mode == 1) || (d->flags & ICD_GEMM_TUNE_NO_PP))) continue;
             if (d->N % c.bn != 0 || (geglu && !c.geglu_ok) || ((d->flags & ICD_GEMM_TUNE_BN256) && c.bn != 256)) continue;
             const long long b0 = (long long)((d->M + c.bm - 1) / c.bm) * (d->N / c.bn);
             int smax = 1;

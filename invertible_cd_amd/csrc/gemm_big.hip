@@ -611,6 +611,7 @@ int launch_big(const GemmK& k, int cfg, hipStream_t st) {
     case 3: return ICD_BIG(4, 2, 1, 5);   // 128 x 320: 4 x 2 waves of 32 x 160
     case PP_TILE: return launch_pp(k, st);   // 256 x 256 with the ping-pong main loop (gemm_pp.hip)
     case PP320_TILE: return launch_pp320(k, st);   // 256 x 320 with it (gemm_pp320.hip)
+    case PP192_TILE: return launch_pp(k, st, 192); // 192 x 256 with it
     }
 #undef ICD_BIG
     if (cfg == 100)   // query projection + cross-attention in one launch (icd_gemm_desc.xattn_*): 256 x 256 = 256 queries x 4 heads

@@ -137,9 +137,10 @@ __device__ __forceinline__ u32x2 carry_of8(const float (&v)[8], const f16x8& o) 
 // chip (about 1.3 - 1.7 us depending on the box's clocks).  tk_full applies when >= 200 CUs are busy (chip-level
 // ceiling: the same block runs about 10 - 20 % slower), tk_part when <= 160.
 struct BigTile { int bm, bn; bool geglu_ok; double tk_part, tk_full, fixed; };
-constexpr int NUM_BIG_TILES = 6;
+constexpr int NUM_BIG_TILES = 7;
 constexpr int PP_TILE = 4;                       // index of the ping-pong 256 x 256 tile (gemm_pp.hip)
 constexpr int PP320_TILE = 5;                    //              ... 256 x 320 tile (gemm_pp320.hip)
+constexpr int PP192_TILE = 6;                    //              ... 192 x 256 tile (gemm_pp.hip, TM = 3)
 constexpr BigTile BIG_TILES[NUM_BIG_TILES] = {
     {256, 256, true, 1.00, 1.08, 9.5},
     {256, 320, false, 1.07, 1.30, 13.5},
@@ -149,6 +150,7 @@ constexpr BigTile BIG_TILES[NUM_BIG_TILES] = {
     {256, 320, false, 1.00, 1.21, 14.2},         // gemm_pp320.hip: k-tiles 3 - 7 % cheaper than the lockstep 256 x 320 tile, one more phase of fill and
                                                  // drain: slower below ~8 k-tiles (131072 x 320 x 320: 60.7 vs 55.3 us), faster from K = 640 on
                                                  // (32768 x 640 x 640: 37.6 vs 40.6; conv 131072 x 320 x 8640: 604 vs 640) - profiles/r06_tune_*.txt
+    {192, 256, true, 0.66, 0.72, 9.3},           // gemm_pp.hip TM = 3: the lockstep 192 x 256 tile x 0.95 (8192 x 1280 x 5120: 103.5 vs 108.1 us, x 1280: 33.5 vs 35.0)
 };
 // Round 6: 128 x 320 / 128 x 256 tiles with four waves and TWO co-resident blocks per CU on a 32-wide k-step (gemm_duo.hip) were built for the
 // short-K dense layers, measured and removed: 131072 x 320 x 320 58.1 us against 55.8 on the 256 x 320 tile, the K = 320 GEGLU projection
@@ -159,7 +161,7 @@ constexpr BigTile BIG_TILES[NUM_BIG_TILES] = {
 // two k-halves.  None is faster: under a full-chip launch every tile family delivers the same ~4 TFLOP/s per CU because the chip is at its
 // power limit (shader clock 1.3 - 1.7 GHz measured inside the main loop, 2.3 GHz when few CUs are busy).
 int launch_big(const GemmK& k, int cfg, hipStream_t st);     // cfg = index into BIG_TILES
-int launch_pp(const GemmK& k, hipStream_t st);               // gemm_pp.hip: the ping-pong 256 x 256 tile (BIG_TILES[PP_TILE])
+int launch_pp(const GemmK& k, hipStream_t st, int rows = 256);   // gemm_pp.hip: the ping-pong 256 x 256 / 192 x 256 tiles (BIG_TILES[PP_TILE / PP192_TILE])
 int launch_pp320(const GemmK& k, hipStream_t st);            // gemm_pp320.hip: the ping-pong 256 x 320 tile (BIG_TILES[PP320_TILE])
 bool pp_operands_ok(const GemmK& k, bool conv);              // operands addressable by its 31-bit buffer offsets
 

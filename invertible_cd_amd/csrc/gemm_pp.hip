@@ -12,9 +12,13 @@
 //     both wave rows, half h of W the columns wn * 64 + h * 32 + [0, 32) of the four wave columns - i.e. exactly what quadrant h of
 //     every wave reads.  Staging order per k-tile: W0, A0 (read in phase 0), W1 (phase 1), A1 (phase 2); phase P sends half-tile
 //     number P + 7 (two buffer_load ... lds of 1 KiB per wave), i.e. the slot whose last read was one (W0) or two phases ago.
-//   * the DMA queue is never drained inside the loop: one COUNTED wait per k-tile (vmcnt(6) in phase 3: all of k-tile t + 1 has landed,
-//     three half-tiles stay in flight across the barriers), taken before the phase's first barrier, read one phase later.
+//   * the DMA queue is never drained inside the loop.  Shipped schedule (V = 2): phase P reads half-tile P + 1 (8 / 4 / 8 / 4 ds_read_b128: phase 3
+//     fetches W0 of the NEXT k-tile into the register set W1 has left, the two sets swap roles every k-tile), sends half-tile P + 7 and takes a
+//     rolling COUNTED wait - vmcnt(10): half-tile P + 2 has landed, five stay in flight across the barriers - before the phase's first
+//     barrier; what a wait covers is read one phase later.  (V = 1, ICD_GEMM_TUNE_PP_V1: reads 12 / 4 / 8 / 0, one vmcnt(6) per k-tile; within 0.5 %.)
 //   * reads of a slot are retired (lgkmcnt(0)) BEFORE the phase's first barrier: the other group restages that slot right after it.
+//   * 2180 shader cycles per k-tile at 8192^3 against a floor of 2048 (64 MFMAs of 32 cycles per SIMD); the lockstep tile: 2873
+//     (profiles/r06_pp_timeline.txt).
 // Both operands come through buffer descriptors (32-bit per-lane offsets computed once, the k offset in a scalar register): no
 // per-k-tile pointer arithmetic on the VALU.  LDS image, swizzle, accumulator layout and epilogue are those of gemm_big.hip.
 #include <type_traits>
@@ -25,7 +29,7 @@ using namespace icd_gemm_detail;
 
 namespace {
 
-constexpr int PP_BM = 256, PP_BN = 256;
+constexpr int PP_BN = 256;
 constexpr int PP_HALF = 128 * 128;               // bytes of one half-tile (128 rows x 64 halfs)
 constexpr int PP_BUF = 4 * PP_HALF;              // one k-tile: W0 | A0 | W1 | A1
 constexpr int PP_SMEM = 2 * PP_BUF;
@@ -34,8 +38,14 @@ constexpr int PP_SMEM = 2 * PP_BUF;
 #define PP_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 #define PP_FENCE() __builtin_amdgcn_sched_barrier(0)
 
-template <int MODE, bool CARRY, int V = 2, bool LNS = false>
+// TM = 4: 256 x 256 (wave tile 128 x 64).  TM = 3 (round 6): 192 x 256, wave tile 96 x 64 - chip fill for the M = 8192-class layers (43 x 5 = 215
+// tiles where 256-row tiles make 160): A half 0 = the first 64 rows of both wave rows (two 32-row MFMA tiles), A half 1 = their last 32 rows
+// (8 KiB: ONE DMA instruction per wave), phases of 8 / 8 / 4 / 4 MFMAs; rolling wait vmcnt(8) in phase 0, vmcnt(9) otherwise.
+template <int MODE, bool CARRY, int V = 2, bool LNS = false, int TM = 4>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmK p) {
+    static_assert(TM == 4 || (TM == 3 && V == 2), "256 or 192 rows");
+    constexpr int PP_BM = TM * 64;
+    constexpr int NA1 = TM == 4 ? 2 : 1;          // DMA instructions per wave for A half 1 / MFMA row tiles of A half 1
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, wv = tid >> 6, l = tid & 63;
     const int wm = wv >> 2, wn = wv & 3;
@@ -59,7 +69,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmK p) {
     // per chunk the lane keeps the byte offset of its row's tap-(0,0) pixel and the complement of a 9-bit tap-validity mask.
     unsigned voff[4][2];
     unsigned a_off[2][2], a_nmsk[2][2];
-    int a_pix[2][2];
+    int a_pix[2][2], a_lc[2][2];             // (a_lc: the lane's logical 16-B chunk of that row: conv only)
     const int Cin = p.C0 + p.C1;
     const int ntaps = p.ksize * p.ksize, pad = (p.flags & ICD_GEMM_PAD_HI) ? 0 : p.ksize >> 1;
     const int ktaps = (int)(p.tapmap >> 60);
@@ -73,13 +83,22 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmK p) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int n = n0 + (r >> 5) * 64 + h * 32 + (r & 31);
-                const int m = m0 + (r >> 6) * 128 + h * 64 + (r & 63);
                 voff[2 * h][j] = n < p.Nw ? (unsigned)(n * p.ldw + lc * 8) * 2u : 0x80000000u;
+                // A half 0: 64 rows of each wave row; half 1: the remaining 64 (TM = 4) or 32 (TM = 3: rows wv * 8 + lrow, instruction j = 0 only)
+                int m, lca = lc;
+                bool live = true;
+                if (h == 0 || TM == 4) m = m0 + (r >> 6) * (TM * 32) + h * 64 + (r & 63);
+                else {
+                    const int r1 = wv * 8 + lrow;
+                    lca = pchunk ^ ((r1 >> 1) & 7);
+                    m = m0 + (r1 >> 5) * (TM * 32) + 64 + (r1 & 31);
+                    live = j == 0;
+                }
                 if constexpr (MODE == 0) {
-                    voff[2 * h + 1][j] = m < p.M ? (unsigned)(m * p.lda + lc * 8) * 2u : 0x80000000u;
+                    voff[2 * h + 1][j] = (live && m < p.M) ? (unsigned)(m * p.lda + lca * 8) * 2u : 0x80000000u;
                 } else {
-                    voff[2 * h + 1][j] = 0x80000000u; a_pix[h][j] = 0; a_nmsk[h][j] = 0x1ff; a_off[h][j] = 0;
-                    if (m < p.M) {
+                    voff[2 * h + 1][j] = 0x80000000u; a_pix[h][j] = 0; a_nmsk[h][j] = 0x1ff; a_off[h][j] = 0; a_lc[h][j] = lca;
+                    if (live && m < p.M) {
                         const int hw = p.Hout * p.Wout;
                         const int b = m / hw, rem = m - b * hw;
                         const int y = rem / p.Wout, x = rem - y * p.Wout;
@@ -111,14 +130,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmK p) {
     if constexpr (MODE == 1) { const int ch = kt_begin / ktaps; u_tap = kt_begin - ch * ktaps; u_c = ch * BK; }
     auto set_source = [&](bool first) {
         const int Cs = first ? p.C0 : p.C1;
-        const int lrow = l >> 3, pchunk = l & 7;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int r = (wv * 2 + j) * 8 + lrow;
-            const int lc = pchunk ^ ((r >> 1) & 7);
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int h = 0; h < 2; ++h) a_off[h][j] = ((unsigned)a_pix[h][j] * (unsigned)Cs + (unsigned)(lc * 8)) * 2u;
-        }
+            for (int h = 0; h < 2; ++h) a_off[h][j] = ((unsigned)a_pix[h][j] * (unsigned)Cs + (unsigned)(a_lc[h][j] * 8)) * 2u;
         u_first = first;
     };
     auto conv_advance = [&]() {                  // offsets of k-tile (u_tap, u_c) -> voff[A slots], w_soff; then step to the next k-tile
@@ -158,32 +173,35 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmK p) {
         const int soff = MODE == 1 ? ((SLOT & 1) ? 0 : w_soff) : (k_begin + kt * BK) * 2;
         unsigned char* dst = smem + BUF * PP_BUF + SLOT * PP_HALF + wave_base;
 #if defined(__HIP_DEVICE_COMPILE__)
+        constexpr bool TWO = SLOT != 3 || NA1 == 2;       // (A half 1 of the 192-row tile is 64 rows: one instruction per wave)
+        unsigned char* dst1 = SLOT == 3 && NA1 == 1 ? smem + BUF * PP_BUF + SLOT * PP_HALF + (wave_base >> 1) : dst;
         if constexpr (MODE == 1 && (SLOT & 1)) {
             const auto rs = __builtin_amdgcn_make_buffer_rsrc(
                 reinterpret_cast<half_t*>(((unsigned long long)(unsigned)src_hi << 32) | (unsigned long long)(unsigned)src_lo), 0, (unsigned)src_bytes, 0x00020000);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)dst, 16, voff[SLOT][0], 0, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(dst + 1024), 16, voff[SLOT][1], 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)dst1, 16, voff[SLOT][0], 0, 0, 0);
+            if constexpr (TWO) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(dst + 1024), 16, voff[SLOT][1], 0, 0, 0);
         } else {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds((SLOT & 1) ? rsA : rsW, (__attribute__((address_space(3))) void*)dst, 16, voff[SLOT][0], soff, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds((SLOT & 1) ? rsA : rsW, (__attribute__((address_space(3))) void*)(dst + 1024), 16, voff[SLOT][1], soff, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds((SLOT & 1) ? rsA : rsW, (__attribute__((address_space(3))) void*)dst1, 16, voff[SLOT][0], soff, 0, 0);
+            if constexpr (TWO) __builtin_amdgcn_raw_ptr_buffer_load_lds((SLOT & 1) ? rsA : rsW, (__attribute__((address_space(3))) void*)(dst + 1024), 16, voff[SLOT][1], soff, 0, 0);
         }
 #endif
     };
 
     // ---- fragment addresses (byte offset inside a half-tile, per k sub-step) ----
-    int rd_a[4], rd_w[4];
+    int rd_a[4], rd_a1[4], rd_w[4];
     {
         const int x = (lr >> 1) & 7;
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) {
             const int off = ((s4 * 2 + lh) ^ x) << 4;
             rd_a[s4] = (wm * 64 + lr) * 128 + off;
+            rd_a1[s4] = TM == 4 ? rd_a[s4] : (wm * 32 + lr) * 128 + off;          // A half 1 of the 192-row tile: 32 rows per wave row
             rd_w[s4] = (wn * 32 + lr) * 128 + off;
         }
     }
-    f32x16 acc[4][2];
+    f32x16 acc[TM][2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -193,9 +211,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmK p) {
     // its rows; here the sums are taken at the head of the load section that follows the A half's matrix sections (the fragments are
     // still in registers, the wave has nothing else to issue while its partner holds the matrix pipe)
     const bool stat_on = LNS && MODE == 0 && p.ln_stats_w != nullptr;
-    float st_s[4], st_q[4];
+    float st_s[TM], st_q[TM];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { st_s[i] = 0.f; st_q[i] = 0.f; }
+    for (int i = 0; i < TM; ++i) { st_s[i] = 0.f; st_q[i] = 0.f; }
     auto stats_of = [&](auto ha_tag) {
         constexpr int HA = decltype(ha_tag)::value;
         if constexpr (LNS) {
@@ -208,7 +226,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmK p) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
 #pragma unroll
-                        for (int ii = 0; ii < 2; ++ii) {
+                        for (int ii = 0; ii < (HA == 0 ? 2 : NA1); ++ii) {
                             const h2 v = {af[ii][s4][2 * e], af[ii][s4][2 * e + 1]};
                             st_s[2 * HA + ii] = __builtin_amdgcn_fdot2(v, one, st_s[2 * HA + ii], false);
                             st_q[2 * HA + ii] = __builtin_amdgcn_fdot2(v, v, st_q[2 * HA + ii], false);
@@ -228,8 +246,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmK p) {
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
-            for (int ii = 0; ii < 2; ++ii)
-                af[ii][s4] = *reinterpret_cast<const f16x8*>(smem + BUF * PP_BUF + (2 * H + 1) * PP_HALF + rd_a[s4] + ii * 4096);
+            for (int ii = 0; ii < (H == 0 ? 2 : NA1); ++ii)
+                af[ii][s4] = *reinterpret_cast<const f16x8*>(smem + BUF * PP_BUF + (2 * H + 1) * PP_HALF + (H == 0 ? rd_a[s4] : rd_a1[s4]) + ii * 4096);
     };
     // W half H of buffer BUF -> register set R
     auto read_w = [&](auto buf_tag, auto h_tag, auto r_tag) {
@@ -244,7 +262,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmK p) {
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
-            for (int ii = 0; ii < 2; ++ii)
+            for (int ii = 0; ii < (HA == 0 ? 2 : NA1); ++ii)
                 acc[2 * HA + ii][HB] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[R][s4], af[ii][s4], acc[2 * HA + ii][HB], 0, 0, 0);
     };
     auto matrix_section = [&](auto ha_tag, auto hb_tag, auto r_tag) {
@@ -316,9 +334,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmK p) {
     stage(I0{}, I0{}, 0); stage(I0{}, I1{}, 0); stage(I0{}, I2{}, 0); stage(I0{}, I3{}, 0);
     if (nk > 1) {
         stage(I1{}, I0{}, 1); stage(I1{}, I1{}, 1); stage(I1{}, I2{}, 1);
-        PP_WAIT_VM(10);                          // W0, A0 of k-tile 0
+        if constexpr (TM == 4) PP_WAIT_VM(10);   // W0, A0 of k-tile 0 have landed (14 instructions sent)
+        else PP_WAIT_VM(9);                      // (13 sent: A half 1 is one instruction)
     } else {
-        PP_WAIT_VM(4);
+        if constexpr (TM == 4) PP_WAIT_VM(4);
+        else PP_WAIT_VM(3);
     }
     PP_FENCE();
     __builtin_amdgcn_s_barrier();
@@ -328,11 +348,19 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmK p) {
     if (wm == 1) __builtin_amdgcn_s_barrier();   // group 1 runs one barrier behind
     PP_FENCE();
     auto tail_wait = [&](int rem) {              // rem half-tiles may stay in flight (the last phases of the block)
-        if (rem >= 4) PP_WAIT_VM(8);
-        else if (rem == 3) PP_WAIT_VM(6);
-        else if (rem == 2) PP_WAIT_VM(4);
-        else if (rem == 1) PP_WAIT_VM(2);
-        else PP_WAIT_VM(0);
+        if constexpr (TM == 4) {
+            if (rem >= 4) PP_WAIT_VM(8);
+            else if (rem == 3) PP_WAIT_VM(6);
+            else if (rem == 2) PP_WAIT_VM(4);
+            else if (rem == 1) PP_WAIT_VM(2);
+            else PP_WAIT_VM(0);
+        } else {                                 // the newest half-tiles of a block are A1 (1 instruction), W1, A0, W0 (2 each)
+            if (rem >= 4) PP_WAIT_VM(7);
+            else if (rem == 3) PP_WAIT_VM(5);
+            else if (rem == 2) PP_WAIT_VM(3);
+            else if (rem == 1) PP_WAIT_VM(1);
+            else PP_WAIT_VM(0);
+        }
     };
     auto phase = [&](auto buf_tag, auto p_tag, int t) {
         constexpr int BUF = decltype(buf_tag)::value, P = decltype(p_tag)::value;
@@ -351,7 +379,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmK p) {
             if constexpr (P == 1) stage(Bt{}, I0{}, t + 2);
             if constexpr (P == 2) stage(Bt{}, I1{}, t + 2);
             if constexpr (P == 3) stage(Bt{}, I2{}, t + 2);
-            PP_WAIT_VM(10);
+            // half-tiles P + 3 .. P + 7 may stay in flight: 10 instructions (TM = 4); TM = 3: 8 when that window starts at an A half 1, else 9
+            if constexpr (TM == 4) PP_WAIT_VM(10);
+            else if constexpr (P == 0) PP_WAIT_VM(8);
+            else PP_WAIT_VM(9);
         } else {
             tail_wait(nseq - 3 - gp);
         }
@@ -385,16 +416,16 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmK p) {
             float* parts = table + 2 * PP_BM;        // [4][BM][2]
             __syncthreads();
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < TM; ++i) {
                 const float s_ = st_s[i] + __shfl_xor(st_s[i], 32), q_ = st_q[i] + __shfl_xor(st_q[i], 32);
-                if (lh == 0) *reinterpret_cast<f32x2*>(parts + 2 * (wn * PP_BM + (wm * 4 + i) * 32 + lr)) = (f32x2){s_, q_};
+                if (lh == 0) *reinterpret_cast<f32x2*>(parts + 2 * (wn * PP_BM + (wm * TM + i) * 32 + lr)) = (f32x2){s_, q_};
             }
             __syncthreads();
             if (wn == 0 && lh == 0) {
                 const float inv_k = 1.f / (float)p.K;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int row = (wm * 4 + i) * 32 + lr;
+                for (int i = 0; i < TM; ++i) {
+                    const int row = (wm * TM + i) * 32 + lr;
                     float s_ = 0.f, q_ = 0.f;
 #pragma unroll
                     for (int w = 0; w < 4; ++w) {
@@ -421,21 +452,21 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmK p) {
             ln_lds = table;
         }
     }
-    wave_epilogue<4, 2, true, CARRY>(p, acc, smem, wv, wm, wn, l, m0, n0, split, tl, ln_lds);
+    wave_epilogue<TM, 2, true, CARRY>(p, acc, smem, wv, wm, wn, l, m0, n0, split, tl, ln_lds);
     if (tl) {
         __syncthreads();
         if (tid == 0) tl[3] = __builtin_amdgcn_s_memrealtime();
     }
 }
 
-template <int MODE, bool CARRY, int V = 2, bool LNS = false>
+template <int MODE, bool CARRY, int V = 2, bool LNS = false, int TM = 4>
 int launch_pp_one(const GemmK& k, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<MODE, CARRY, V, LNS>), hipFuncAttributeMaxDynamicSharedMemorySize, PP_SMEM);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<MODE, CARRY, V, LNS, TM>), hipFuncAttributeMaxDynamicSharedMemorySize, PP_SMEM);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_pp_kernel<MODE, CARRY, V, LNS>), dim3(k.nbm * k.nbn, k.ksplit, 1), dim3(512), PP_SMEM, st, k);
+    hipLaunchKernelGGL((gemm_pp_kernel<MODE, CARRY, V, LNS, TM>), dim3(k.nbm * k.nbn, k.ksplit, 1), dim3(512), PP_SMEM, st, k);
     ICD_CHECK_LAUNCH("icd_gemm(ping-pong tile)");
     return ICD_OK;
 }
@@ -454,11 +485,16 @@ bool pp_operands_ok(const GemmK& k, bool conv) {
     return a_bytes < (1LL << 31) - 4096 && w_bytes < (1LL << 31) - 4096 && k.lda >= 0 && k.ldw >= 0;
 }
 
-int launch_pp(const GemmK& k, hipStream_t st) {
+int launch_pp(const GemmK& k, hipStream_t st, int rows) {
     const bool carry = (k.out_c || k.resid_c) && k.ksplit == 1;
     const bool conv = k.ksize > 0 && k.Hout > 0;
+    if (rows == 192) {
+        if (conv) return carry ? launch_pp_one<1, true, 2, false, 3>(k, st) : launch_pp_one<1, false, 2, false, 3>(k, st);
+        if (k.ln_stats_w) return launch_pp_one<0, false, 2, true, 3>(k, st);
+        return carry ? launch_pp_one<0, true, 2, false, 3>(k, st) : launch_pp_one<0, false, 2, false, 3>(k, st);
+    }
     if (conv) return carry ? launch_pp_one<1, true>(k, st) : launch_pp_one<1, false>(k, st);
-    if (k.flags & 0x10000000) return launch_pp_one<0, false, 1>(k, st);      // A/B: the first schedule (no carry variant)
+    if ((k.flags & ICD_GEMM_TUNE_PP_V1) && !carry && !k.ln_stats_w) return launch_pp_one<0, false, 1>(k, st);      // A/B: the first schedule
     if (k.ln_stats_w) return launch_pp_one<0, false, 2, true>(k, st);        // (the planner never combines inline statistics with a carry)
     return carry ? launch_pp_one<0, true>(k, st) : launch_pp_one<0, false>(k, st);
 }

@@ -111,7 +111,7 @@ def test_ping_pong_tiles_keep_their_main_loops_clean():
     pipeline are in the loop (never vmcnt(0) on the steady-state path of the 256 x 256 tile), and - the trap the conv variant fell into
     on its first build - no WATERFALL loop around a buffer_load: a descriptor select hipcc cannot prove wave-uniform turns every LDS-DMA
     instruction into a v_readfirstlane / s_and_saveexec loop of its own (4 per k-tile, +15 % on every conv)."""
-    for src, name, n_kernels, spill_cap in (("gemm_pp.hip", "gemm_pp_kernel", 6, 0), ("gemm_pp320.hip", "gemm_pp320_kernel", 5, 40)):
+    for src, name, n_kernels, spill_cap in (("gemm_pp.hip", "gemm_pp_kernel", 11, 0), ("gemm_pp320.hip", "gemm_pp320_kernel", 5, 40)):
         ks = _descriptors(src)
         asm = _descriptors(src, main_loops=True)
         tiles = {n: v for n, v in ks.items() if name in n}
@@ -128,4 +128,4 @@ def test_ping_pong_tiles_keep_their_main_loops_clean():
             i1 = next(i for i in range(i0, len(lines)) if lines[i].startswith("\ts_endpgm"))
             body = "\n".join(lines[i0:i1])
             assert "Inner Loop Header: Depth=2" not in body, f"{n}: a loop inside the k-loop (waterfall around a buffer_load?)"
-            assert body.count("v_mfma_f32_32x32x16_f16") >= 64
+            assert body.count("v_mfma_f32_32x32x16_f16") >= 48

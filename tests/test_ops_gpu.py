@@ -100,34 +100,37 @@ PP_TILE_FLAG = 5 << 24                               # ICD_GEMM_TUNE_BIG_CFG(4):
 PP320_TILE_FLAG = 6 << 24                            # ICD_GEMM_TUNE_BIG_CFG(5): the ping-pong 256 x 320 tile (gemm_pp320.hip)
 
 
-@pytest.mark.parametrize("tile", [256, 320])
+@pytest.mark.parametrize("tile", ["256x256", "256x320", "192x256"])
 @pytest.mark.parametrize("M,nn,K", [(512, 1, 64), (300, 2, 128), (1000, 4, 1344), (1024, 4, 320), (256, 1, 4096), (2048, 8, 1280), (777, 1, 192)])
 def test_gemm_ping_pong_tile(M, nn, K, tile):
     """The ping-pong ("8-phase") tiles forced on small and ragged shapes: 1, 2, 3, odd and even k-tile counts (prologue / tail of the
-    counted-vmcnt pipelines), ragged M, split-K where the planner splits, bias + residual, GEGLU (256 x 256), plain."""
+    counted-vmcnt pipelines), ragged M, split-K where the planner splits, bias + residual, GEGLU (256-wide tiles), plain."""
     ops = _ops()
-    N = nn * tile
-    flag, lockstep = (PP_TILE_FLAG, 1 << 24) if tile == 256 else (PP320_TILE_FLAG, 2 << 24)
+    bm, bn = (int(x) for x in tile.split("x"))
+    N = nn * bn
+    flag, lockstep = {"256x256": (PP_TILE_FLAG, 1 << 24), "256x320": (PP320_TILE_FLAG, 2 << 24), "192x256": (7 << 24, 3 << 24)}[tile]
     a, w = r16(M, K, seed=661), r16(N, K, seed=662, scale=K ** -0.5)
     bias = torch.randn(N, generator=torch.Generator().manual_seed(663))
     res = r16(M, N, seed=664)
     ref = a.float() @ w.float().t()
-    assert _lib_plan(ops, M, N, K, flag).tile_n == tile
+    info = _lib_plan(ops, M, N, K, flag)
+    assert (info.tile_m, info.tile_n) == (bm, bn)
     for _ in range(3):                                # a race in the staging pipeline would come and go between runs
         out = ops.gemm(a.cuda(), w.cuda(), bias=bias.cuda(), resid=res.cuda(), debug_flags=flag)
         assert rel_l2(out, ref + bias + res.float()) < TOL
     plain = ops.gemm(a.cuda(), w.cuda(), debug_flags=flag)
     assert rel_l2(plain, ref) < TOL
     # bit-identical to the lockstep tile of the same shape: same k order, same accumulator layout, same epilogue
+    # (K <= 1344 or one tile column... the two plans split K alike: same tile grid)
     assert torch.equal(plain, ops.gemm(a.cuda(), w.cuda(), debug_flags=lockstep))
-    if tile == 256:
+    if bn == 256:
         perm = ops.geglu_perm(N // 2)
         outg = ops.gemm(a.cuda(), w[perm].contiguous().cuda(), bias=bias[perm].contiguous().cuda(), geglu=True, debug_flags=flag)
         val, gate = (ref + bias).chunk(2, dim=-1)
         assert rel_l2(outg, val * F.gelu(gate)) < TOL
 
 
-@pytest.mark.parametrize("cfg_i", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("cfg_i", [0, 1, 2, 3, 4, 5, 6])
 def test_gemm_every_big_tile_configuration(cfg_i):
     """Each gemm_big.hip configuration forced in turn (ICD_GEMM_TUNE_BIG_CFG): dense with bias + residual on a ragged M, the
     transposed (V^T) epilogue and a 3x3 conv with time bias."""
@@ -160,7 +163,8 @@ def test_gemm_every_big_tile_configuration(cfg_i):
                                                (1000, 1280, 1280, 4 << 24, False), (2048, 320, 320, 0x100000, False),
                                                (1000, 1280, 2560, (2 << 24) | 0x800000, False), (1000, 1280, 2560, 5 << 24, False),
                                                (1000, 1280, 2560, 5 << 24, True), (700, 320, 1280, 5 << 24, False),
-                                               (1000, 1280, 2560, 6 << 24, False), (700, 320, 1280, 6 << 24, False), (2048, 320, 320, 6 << 24, False)])
+                                               (1000, 1280, 2560, 6 << 24, False), (700, 320, 1280, 6 << 24, False), (2048, 320, 320, 6 << 24, False),
+                                               (1000, 1280, 2560, 7 << 24, False), (1000, 1280, 2560, 7 << 24, True), (700, 320, 1280, 7 << 24, False)])
 def test_gemm_computes_the_layernorm_statistics_it_applies(M, C, N, flags, geglu):
     """ICD_GEMM_LN_COMPUTE: the GEMM behind a LayerNorm computes (mean, rstd) of its A rows itself - the big tiles from the MFMA
     operand fragments of their main loop (v_dot2 sums in the waves of tile column 0, an LDS table feeds the epilogue, n-tile 0
@@ -198,7 +202,7 @@ def test_gemm_computes_the_layernorm_statistics_it_applies(M, C, N, flags, geglu
 
 @pytest.mark.parametrize("ratio", [50.0, 3.0, 0.0])
 @pytest.mark.parametrize("M,C,N,flags", [(1024, 640, 1280, 0x100000), (2048, 320, 320, 0x100000), (512, 1280, 1280, 3 << 24), (512, 1280, 1280, 5 << 24),
-                                         (512, 1280, 1280, 6 << 24)])
+                                         (512, 1280, 1280, 6 << 24), (512, 1280, 1280, 7 << 24)])
 def test_in_loop_layernorm_statistics_survive_a_large_row_offset(M, C, N, flags, ratio):
     """ICD_GEMM_LN_COMPUTE on the big tiles sums x and x^2 of each row from the MFMA operand fragments (one pass).  E[x^2] - mean^2
     cancels when a row's offset dominates its spread: at |mean| / sigma = 50 the one-pass variance alone is off by ~2.5e-3.  Rows with

@@ -33,14 +33,14 @@ d.a0, d.w, d.out, d.bias = x.data_ptr(), w.data_ptr(), out.data_ptr(), b.data_pt
 d.resid = res.data_ptr() if res is not None else None
 d.M, d.N, d.K, d.Nw, d.lda, d.ldw, d.ldo, d.ldr = M, N, K, N, K, K, out.stride(0), N
 d.mode, d.batch, d.zdiv, d.alpha = 0, 1, 1, 1.0
-d.flags = (((a.cfg + 1) << 24) if a.cfg < 4 else {4: 0x80000 | 0x200000, 5: 0x40000 | 0x200000, 6: 5 << 24, 7: (5 << 24) | 0x10000000}[a.cfg]) | (1 if a.geglu else 0)
-# cfg 4: 256x128 three-stage tile, 5: 128x128 (two blocks per CU), 6: the ping-pong 256x256 tile (gemm_pp.hip), 7: its first schedule
+d.flags = (((a.cfg + 1) << 24) if a.cfg < 4 else {4: 0x80000 | 0x200000, 5: 0x40000 | 0x200000, 6: 5 << 24, 7: (5 << 24) | 0x10000000, 8: 7 << 24}[a.cfg]) | (1 if a.geglu else 0)
+# cfg 4: 256x128 three-stage tile, 5: 128x128 (two blocks per CU), 6: the ping-pong 256x256 tile (gemm_pp.hip), 7: its first schedule, 8: the ping-pong 192x256 tile
 d.tune_group_m = a.gm
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 for _ in range(20):
     _lib.check(lib.icd_gemm(C.byref(d), st))
 torch.cuda.synchronize()
-tiles = {0: (256, 256), 1: (256, 320), 2: (192, 256), 3: (128, 320), 4: (256, 128), 5: (128, 128), 6: (256, 256), 7: (256, 256)}[a.cfg]
+tiles = {0: (256, 256), 1: (256, 320), 2: (192, 256), 3: (128, 320), 4: (256, 128), 5: (128, 128), 6: (256, 256), 7: (256, 256), 8: (192, 256)}[a.cfg]
 nblk = ((M + tiles[0] - 1) // tiles[0]) * ((N + tiles[1] - 1) // tiles[1])
 buf = torch.zeros((nblk, 8), dtype=torch.int64, device="cuda")
 d.debug_timeline = buf.data_ptr()

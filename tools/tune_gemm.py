@@ -47,7 +47,7 @@ for fam, M, N, K, aux, ms, fl in recs:
     e = agg.setdefault((fam, M, N, K, aux), [0, 0.0])
     e[0] += 1; e[1] += ms
 
-CONFIGS = [("plan", 0), ("b256x256", 1 << 24), ("b256x320", 2 << 24), ("b192x256", 3 << 24), ("b128x320", 4 << 24), ("pp256x256", 5 << 24), ("pp256x320", 6 << 24),
+CONFIGS = [("plan", 0), ("b256x256", 1 << 24), ("b256x320", 2 << 24), ("b192x256", 3 << 24), ("b128x320", 4 << 24), ("pp256x256", 5 << 24), ("pp256x320", 6 << 24), ("pp192x256", 7 << 24),
            ("t128x128", 0x40000 | 0x200000), ("t256x128", 0x80000 | 0x200000)]      # + ICD_GEMM_TUNE_NO_BIG
 lib = _lib.load()
 g = torch.Generator(device="cuda").manual_seed(0)

@@ -904,7 +904,12 @@ static int gemm_run(const icd_gemm_desc* d, void* stream, icd_gemm_plan_info* in
                 const int kps = (nk_total + sx - 1) / sx;
                 double cost = rounds * (kps * tk + c.fixed);
                 if (sx > 1) cost += (double)(sx + 1) * d->M * d->N * 4.0 / 3.5e12 / 1.5e-6 + 4.0;   // fp32 partials + reduce launch
-                if (cost < best) { best = cost; cfg = ci; s = sx; best_fill = (double)bt / (double)(((bt + 255) / 256) * 256); }
+                // (round 6: a candidate that would leave more than 55 % of its last round empty is no candidate - before, the cheapest tile was
+                //  picked first and the launch sent to the 128-wide kernels when THAT one filled badly, even with a well-filling tile at hand:
+                //  2048 x 2560 x 1280 lost its 128 x 320 tile to the 128 x 128 kernel the day a cheaper 192 x 256 entry appeared)
+                const double fill = (double)bt / (double)(((bt + 255) / 256) * 256);
+                if (fill < 0.45 && forced < 0 && !(d->flags & ICD_GEMM_TUNE_FORCE_BIG)) continue;
+                if (cost < best) { best = cost; cfg = ci; s = sx; best_fill = fill; }
             }
         }
         if (cfg >= 0 && (best_fill >= 0.45 || forced >= 0 || (d->flags & ICD_GEMM_TUNE_FORCE_BIG))) {

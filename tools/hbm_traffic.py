@@ -30,7 +30,7 @@ def family(k):
         return "xattn_fused"
     if re.search(r"gemm_big_kernel<\d, \d, \d, \d, \d, true", k):        # 256 x 256 host of the fused query-projection + attention
         return "xattn_fused"
-    m = re.search(r"gemm(?:_big)?_kernel<(\d)", k)
+    m = re.search(r"gemm(?:_big|_pp320|_pp)?_kernel<(\d)", k)
     if m:
         return "gemm_dense" if m.group(1) == "0" else "gemm_conv"
     for pat, f in (("splitk_reduce", "splitk_reduce"), ("attn_probs", "softmax"), ("attn_fused", "attn_fused"), ("attn_cross", "attn_fused"),

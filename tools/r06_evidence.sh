@@ -18,3 +18,13 @@ done; done > $OUT/r06_in_flight.txt 2>&1
 python -m pytest tests -m gpu -q -s --durations=15 2>&1 | grep -v '^$' > $OUT/r06_parity.txt
 tail -30 $OUT/r06_parity.txt
 cat $OUT/r06_in_flight.txt $OUT/r06_precision_gap.txt
+# the whole round's GEMM work against the lockstep tiles of rounds 1 - 5, two batches in flight, alternating, same box
+B="--steps 10 --warmup 3 --no-cpu-baseline --no-vae --no-ref-batching --no-sdxl --no-edit --no-live-traffic"
+for r in 1 2; do for arch in sd15 sdxl; do for t in 0 0x20000000; do
+python bench.py --arch $arch $B --gemm-tune $t 2>/dev/null | python -c "
+import sys, json
+d = json.loads(sys.stdin.read()); kf = d.get('kernel_families', {})
+print('$arch gemm_tune=$t round $r: value', d['value'], 'one_batch', d.get('value_one_batch_at_a_time'), {k: round(v['ms'], 2) for k, v in kf.items()})"
+done; done; done > $OUT/r06_pp_bench_ab.txt 2>&1
+python tools/vs_library.py 2>/dev/null | grep -v amdgpu > $OUT/r06_vs_library.txt
+cat $OUT/r06_pp_bench_ab.txt $OUT/r06_vs_library.txt

@@ -34,7 +34,7 @@ def main(path):
     # roll-up into the families bench.py's in-process profiler reports ("roofline.kernel" / "kernel_families")
     fam = {}
     for n, a in agg.items():
-        m = re.search(r"gemm(?:_big)?_kernel<(\d)", n)
+        m = re.search(r"gemm(?:_big|_pp320|_pp)?_kernel<(\d)", n)
         mx = re.search(r"gemm_kernel<\d, (?:false|true), \d, \d, true", n) or re.search(r"gemm_big_kernel<\d, \d, \d, \d, \d, true", n)
         if mx:
             f = "xattn_fused"

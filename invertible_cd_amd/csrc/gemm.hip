@@ -876,7 +876,8 @@ static int gemm_run(const icd_gemm_desc* d, void* stream, icd_gemm_plan_info* in
         // Cost model in units of "one k-tile of a 256x256 block" (calibrated with tools/gemm_bench.py, same-box A/B):
         // a block owns its CU, so a launch costs rounds x (k-tiles x tk + fixed), fixed = prologue + exposed epilogue.
         int cfg = -1, s = 1;
-        double best = 1e30, best_fill = 0.0;
+        double best = 1e30, best_fill = 0.0, best_ok = 1e30, fill_ok = 0.0;
+        int cfg_ok = -1;
         const int forced = ((d->flags >> 24) & 15) - 1;          // ICD_GEMM_TUNE_BIG_CFG(i)
         for (int ci = 0; ci < NUM_BIG_TILES && base_ok; ++ci) {
             const BigTile& c = BIG_TILES[ci];
@@ -904,14 +905,16 @@ static int gemm_run(const icd_gemm_desc* d, void* stream, icd_gemm_plan_info* in
                 const int kps = (nk_total + sx - 1) / sx;
                 double cost = rounds * (kps * tk + c.fixed);
                 if (sx > 1) cost += (double)(sx + 1) * d->M * d->N * 4.0 / 3.5e12 / 1.5e-6 + 4.0;   // fp32 partials + reduce launch
-                // (round 6: a candidate that would leave more than 55 % of its last round empty is no candidate - before, the cheapest tile was
-                //  picked first and the launch sent to the 128-wide kernels when THAT one filled badly, even with a well-filling tile at hand:
-                //  2048 x 2560 x 1280 lost its 128 x 320 tile to the 128 x 128 kernel the day a cheaper 192 x 256 entry appeared)
+                // (round 6: the cheapest candidate is picked as before and the launch goes to the 128-wide kernels when it fills its last round
+                //  below 45 % - UNLESS an un-split candidate fills well: 2048 x 2560 x 1280 lost its 128 x 320 tile (128 blocks) to the 128 x 128
+                //  kernel the day a cheaper-looking 192 x 256 entry (110 blocks) appeared.  Split-K candidates are not rescued this way: 2048 x 1280
+                //  x 1280 on 128 x 320 split 2 measured 26.2 us against 17.9 on the 128 x 128 kernel.)
                 const double fill = (double)bt / (double)(((bt + 255) / 256) * 256);
-                if (fill < 0.45 && forced < 0 && !(d->flags & ICD_GEMM_TUNE_FORCE_BIG)) continue;
+                if (fill >= 0.45 && sx == 1 && cost < best_ok) { best_ok = cost; cfg_ok = ci; fill_ok = fill; }
                 if (cost < best) { best = cost; cfg = ci; s = sx; best_fill = fill; }
             }
         }
+        if (cfg >= 0 && best_fill < 0.45 && forced < 0 && !(d->flags & ICD_GEMM_TUNE_FORCE_BIG) && cfg_ok >= 0) { cfg = cfg_ok; s = 1; best_fill = fill_ok; }
         if (cfg >= 0 && (best_fill >= 0.45 || forced >= 0 || (d->flags & ICD_GEMM_TUNE_FORCE_BIG))) {
             const BigTile& c = BIG_TILES[cfg];
             k.nbm = (d->M + c.bm - 1) / c.bm; k.nbn = d->N / c.bn;

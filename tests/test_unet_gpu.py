@@ -370,6 +370,44 @@ def test_precision_policy_selects_the_level_the_samplers_ask_for():
         m.set_precision("exact")
 
 
+def test_gemm_tune_option_switches_the_tile_family_not_the_result():
+    """ICD_UNET_OPT_GEMM_TUNE (round 6): ICD_GEMM_TUNE_NO_PP sends every launch of the handle to the lockstep tiles of rounds 1 - 5 - the
+    same-process A/B switch of bench.py --gemm-tune / tools/unet_ab.py.  Full-width SD1.5, B = 4 at 64 x 64: the planner records show the
+    ping-pong kernels' shapes moving to other tiles or staying put, and eps moves by what two valid tile plans of one evaluation differ by
+    (a tile with another column count changes which launches take their LayerNorm statistics from their own main loop, a split-K plan
+    regroups a sum: fp16-level noise, 0.8e-3 here - the distance test_full_size_sd15_properties allows between two plans of a sample)."""
+    from invertible_cd_amd import _lib
+    synthetic, unet, uc, _ = _mods()
+    cfg = uc.SD15
+    m = unet.UNet2DConditionModel(cfg, synthetic.synthetic_state_dict(cfg, seed=2, device="cuda", dtype=torch.float16)).set_precision("fast")
+    inp = synthetic.synthetic_inputs(cfg, 4, 64, 64, seed=2, device="cuda")
+    kw = dict(encoder_hidden_states=inp["context"].half(), timestep_cond=torch.randn(4, 512, device="cuda").half())
+    x = inp["latents"].half()
+
+    def run():
+        _lib.profile_enable(True)
+        try:
+            eps = m(x, 519, **kw).sample
+            torch.cuda.synchronize()
+            return eps, [p for p in _lib.profile_plans() if p["family"] in ("gemm_dense", "gemm_conv")]
+        finally:
+            _lib.profile_enable(False)
+
+    run()                                                     # (fills the context-projection cache: two launches the later passes skip)
+    e_pp, p_pp = run()
+    m.set_option("gemm_tune", _lib.ICD_GEMM_TUNE_NO_PP)
+    e_ls, p_ls = run()
+    m.set_option("gemm_tune", 0)
+    e_back, _ = run()
+    assert torch.equal(e_back, e_pp) and len(p_pp) == len(p_ls)
+    moved = sum(1 for a, b in zip(p_pp, p_ls) if a["tile"] != b["tile"])
+    d = rel_l2(e_ls, e_pp)
+    print(f"[gemm_tune] {len(p_pp)} GEMM launches, {moved} on another tile shape without the ping-pong family; eps distance {d:.3e}")
+    assert torch.isfinite(e_ls).all() and 0 < d < 2e-3 and moved > 0
+    with pytest.raises(RuntimeError):
+        m.set_option("gemm_tune", 1)                          # only planner bits are accepted
+
+
 def test_eight_pixel_latents_take_the_3x3_upsampler_at_the_one_pixel_level():
     """latents of 2^(levels - 1) pixels put the lowest level at 1 x 1; the phase-form upsampler (out_remap_w >= 2) cannot map a
     one-pixel-wide level, the executor takes the 3 x 3 form there - every precision level still matches the oracle."""

@@ -1088,3 +1088,12 @@ def test_flash_attention_ring_is_bit_identical_to_a_fully_fenced_build():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "attn_ring_check.py")], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "cases bit-identical" in r.stdout and "DIFF" not in r.stdout
+
+
+def test_ping_pong_tiles_race_screen():
+    """tools/pp_stress.py: every ping-pong tile (dense and conv) launched repeatedly beside a second stream's launches and compared bit for bit
+    with the lockstep tile - a fragment read before its DMA landed or a slot restaged under a reader would show up as rare mismatches."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "pp_stress.py"), "12"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "RACE SCREEN CLEAN" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

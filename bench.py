@@ -292,8 +292,13 @@ def live_traffic(arch, batch, family, timeout_s=240, leg="all"):
     exec(compile(src, "hbm_traffic_head", "exec"), ns)          # family() and collect(): one source of truth with the offline tool
     tmp = tempfile.mkdtemp(prefix="icd_pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp")
-    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR", "TORCHELASTIC_RUN_ID"):
-        env.pop(k, None)
+    # the child is a single-process run of its own: nothing of the parent's launcher may reach it.  (Under torch.distributed.run the
+    # variable TORCHELASTIC_USE_AGENT_STORE makes env:// rendezvous a CLIENT of the agent's store - a child that inherits it waits for
+    # a server nobody runs until this function's timeout kills it: 970 s of timeouts on a default run, measured.)
+    for k in list(env):
+        if k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR", "GROUP_RANK", "ROLE_RANK", "ROLE_NAME", "LOCAL_WORLD_SIZE",
+                 "GROUP_WORLD_SIZE", "ROLE_WORLD_SIZE", "TORCH_NCCL_ASYNC_ERROR_HANDLING") or k.startswith("TORCHELASTIC_"):
+            env.pop(k)
     child = [sys.executable, os.path.abspath(__file__), "--arch", arch, "--batch", str(batch), "--steps", "1", "--warmup", "1", "--in-flight", "1",
              "--no-cpu-baseline", "--no-vae", "--no-ref-batching", "--no-profile", "--no-sdxl", "--no-live-traffic"]
     child += ["--leg", "edit", "--in-flight-edit", "1"] if leg == "edit" else ["--no-edit"]
@@ -728,6 +733,12 @@ def run_edit(a, wl, arch, batch, steps, warmup, device, world, rank):
 
 def main():
     a = parse()
+    if os.environ.get("ICD_BENCH_WATCHDOG"):            # debugging aid: dump every thread's stack to stderr every N seconds (a hang names itself)
+        import atexit
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["ICD_BENCH_WATCHDOG"]), repeat=True, file=sys.stderr)
+        t_start = time.time()
+        atexit.register(lambda: print(f"[bench watchdog] interpreter exit after {time.time() - t_start:.1f} s", file=sys.stderr, flush=True))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:

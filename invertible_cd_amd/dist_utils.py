@@ -35,6 +35,10 @@ def init(backend=None, timeout_s=None):
     driver stack) is set only when the variable is absent.  The collectives time out after ICD_DIST_TIMEOUT_S seconds (default
     600) instead of hanging a node when a rank died."""
     import datetime
+    if 'MASTER_ADDR' not in os.environ and 'MASTER_PORT' not in os.environ:
+        # no launcher's rendezvous to join: this process hosts its own store.  A stray TORCHELASTIC_USE_AGENT_STORE (a process started
+        # FROM a torchrun worker inherits it) would make env:// a client of a store nobody runs, and the call would sit out its timeout.
+        os.environ.pop('TORCHELASTIC_USE_AGENT_STORE', None)
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('RANK', '0')
     os.environ.setdefault('LOCAL_RANK', '0')

@@ -68,6 +68,22 @@ def test_single_process_defaults(golden_dir):
     assert i.tolist() == [0, 1, 2, 3, 4, 5] and x[:, 0].tolist() == [3.0, 1.0, 2.0, 0.0, 5.0, 4.0]
 
 
+def test_single_process_init_ignores_a_stray_agent_store_flag():
+    """A process started FROM a torchrun worker (bench.py's counter passes are) inherits TORCHELASTIC_USE_AGENT_STORE: env:// rendezvous
+    would then be a client of a store nobody runs and sit out its timeout (measured: 970 s of timeouts on a default bench run under
+    torchrun).  dist_utils.init hosts its own store whenever no launcher gave it an address."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("MASTER_ADDR", "MASTER_PORT", "RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env.update(TORCHELASTIC_USE_AGENT_STORE="True", PYTHONPATH=root)
+    code = ("import torch.distributed as dist\nfrom invertible_cd_amd import dist_utils\n"
+            "dist_utils.init(backend='gloo', timeout_s=20)\nassert dist.get_world_size() == 1\ndist.barrier()\n"
+            "dist.destroy_process_group()\nprint('ALONE_OK')")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "ALONE_OK" in r.stdout, r.stdout[-1000:] + r.stderr[-2000:]
+
+
 def _bench_worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world))
     import sys

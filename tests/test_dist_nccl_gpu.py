@@ -92,6 +92,24 @@ def test_bench_under_torchrun_at_one_gpu_reports_rccl():
     assert d["rccl"]["rccl_world_size"] == 1 and d["rccl"]["backend"] == "nccl" and d["rccl"]["all_gather_executed"] is True
 
 
+def test_bench_under_torchrun_runs_its_counter_passes_live():
+    """The same launch line with the live HBM-traffic passes ON: the rocprofv3 children bench.py starts from inside a torchrun worker must
+    not inherit the launcher's rendezvous (TORCHELASTIC_USE_AGENT_STORE made them wait for the agent's store until their time limit - the
+    line then fell back to the committed summary after minutes of waiting).  `traffic_source` says which one the line carries."""
+    import shutil
+    if not (shutil.which("rocprofv3") or os.path.exists("/opt/rocm/bin/rocprofv3")):
+        pytest.skip("rocprofv3 not installed")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1", "--batch", "4",
+           "--no-cpu-baseline", "--no-vae", "--no-ref-batching", "--no-sdxl", "--no-edit"]
+    r = subprocess.run(cmd, env=_env(), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.strip()][-1])
+    roof = d["roofline"]
+    assert str(roof.get("traffic_source", "")).startswith("live"), (roof.get("traffic_source"), roof.get("traffic_live_error"))
+    assert roof["traffic"] > 0 and roof["traffic_seconds"] < 100
+
+
 @needs2
 def test_world2_nccl_gather_of_uint8_images(tmp_path):
     w = tmp_path / "worker.py"

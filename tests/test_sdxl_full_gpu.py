@@ -211,7 +211,7 @@ def test_full_sdxl_forward_128x128_b2_on_the_benchmarked_tiles():
     # same tiles: < 0.6e-3 (last variant: an explicit residual option switches the policy of the handle off)
     r = _run_case(SDXL, B=2, H=128, W=128, t=699, seed=9, tol=1e-3,
                   variants={"xattn_everywhere": {"xattn_fusion": 1}, "accurate": {"xattn_fusion": 2, "residual": 3, "split_mask": 1023},
-                            "fast": {"residual": 2}}, check_plans=check)
+                            "fast": {"residual": 2}}, check_plans=check, cache_tag="sdxl_full_128x128_b2_eps")
     # (round 6: the default run follows the 'auto' policy, whose probe picks the level for these weights; the two levels are pinned explicitly)
     print(f"[sdxl B=2 128x128] fast level {r['fast'][0]:.3e} -> accurate level {r['accurate'][0]:.3e}; default (auto policy) {r[None][0]:.3e}")
     assert r["accurate"][0] < 0.6e-3 and r["accurate"][0] < 0.7 * r["fast"][0]
@@ -240,13 +240,15 @@ def test_full_width_sdxl_loops_64x64_b1_meet_1e3():
                            "time_ids": added["time_ids"].cuda()}
     _, out = X.sample_deterministic(pipe, ["x"] * B, latents=lat.cuda().half(), num_inference_steps=4, guidance_scale=7.0, is_sdxl=True,
                                     timesteps=[249, 499, 699, 999], compute_embeddings_fn=emb, return_latent=True)
-    ref = T._oracle_loop_xl(E, sd, cfg, lat.clone(), ctx, list(zip([999, 699, 499, 249], [699, 499, 249, 0])), [[7.0] * B] * 4, added)
+    ref = T._oracle_loop_xl(E, sd, cfg, lat.clone(), ctx, list(zip([999, 699, 499, 249], [699, 499, 249, 0])), [[7.0] * B] * 4, added,
+                            cache_tag="sdxl_full_64x64_b1_reverse")
     e4 = rel_l2(out, ref)
     print(f"[sdxl FULL width 64x64 B=1, 4-step reverse] rel-L2 = {e4:.3e}  (probe gap {u._auto_gap}, plain level {u._auto_plain})")
     assert e4 < 1e-3
     fwd, start = X.inverse_sample_deterministic(fpipe, lat.cuda().half(), ["x"] * B, num_inference_steps=3, timesteps=[19, 339, 699],
                                                 guidance_scale=0.0, is_sdxl=True, compute_embeddings_fn=emb, seed=3, return_start_latent=True)
-    ref_f = T._oracle_loop_xl(E, sd, cfg, start.float().cpu(), ctx, list(zip([19, 339, 699], [339, 699, 999])), [[0.0] * B] * 3, added)
+    ref_f = T._oracle_loop_xl(E, sd, cfg, start.float().cpu(), ctx, list(zip([19, 339, 699], [339, 699, 999])), [[0.0] * B] * 3, added,
+                              cache_tag="sdxl_full_64x64_b1_forward")
     e5 = rel_l2(fwd, ref_f)
     print(f"[sdxl FULL width 64x64 B=1, 3-step forward] rel-L2 = {e5:.3e}")
     assert e5 < 1e-3

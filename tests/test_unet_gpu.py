@@ -40,7 +40,8 @@ def _oracle_cfg(unet_ref, cfg):
     return o
 
 
-def _run_case(cfg, B, H, W, t, seed, tol, with_cond=True, n_ctx=77, f32_io=False, variants=None, check_plans=None, variant_tol=None):
+def _run_case(cfg, B, H, W, t, seed, tol, with_cond=True, n_ctx=77, f32_io=False, variants=None, check_plans=None, variant_tol=None,
+              cache_tag=None):
     """Product vs fp32 oracle vs the fp16-torch floor.  `variants`: {name: {option: value}} - further runs of the SAME handle under
     other per-handle options (UNet2DConditionModel.set_option), each compared with the oracle too; `check_plans(name, plans)` gets
     the planner records of every run (name None = defaults) so a case can assert the code path it claims to pin.  Returns
@@ -56,7 +57,12 @@ def _run_case(cfg, B, H, W, t, seed, tol, with_cond=True, n_ctx=77, f32_io=False
     added = None
     if cfg.addition_time_embed_dim:
         added = {"text_embeds": inp["text_embeds"].half().float(), "time_ids": inp["time_ids"]}
-    ref = unet_ref.unet_forward(sd, _oracle_cfg(unet_ref, cfg), lat, t, ctx, timestep_cond=cond, added_cond=added)
+    oracle = lambda: unet_ref.unet_forward(sd, _oracle_cfg(unet_ref, cfg), lat, t, ctx, timestep_cond=cond, added_cond=added)
+    if cache_tag is None:
+        ref = oracle()
+    else:                                            # full-width cases: a committed fixture keyed by everything the oracle's result depends on
+        import oracle_cache
+        ref = oracle_cache.lookup(cache_tag, sd, [cfg.name, lat, t, ctx, cond, added], oracle)
     model = unet.UNet2DConditionModel(cfg, sd)
     x = lat.cuda() if f32_io else lat.half().cuda()
     kw = dict(encoder_hidden_states=ctx.cuda(), timestep_cond=None if cond is None else cond.cuda(),

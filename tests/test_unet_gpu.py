@@ -199,7 +199,7 @@ def test_unet_full_sd15_b8_64x64_on_the_benchmarked_tiles_and_layernorm_statisti
 
     r = _run_case(uc.SD15, B=8, H=64, W=64, t=779, seed=8, tol=1e-3,
                   variants={"ln_pass": {"ln_inline_stats": 0}, "accurate": {"ln_inline_stats": 1, "residual": 3, "split_mask": 1023},
-                            "fast": {"residual": 2}}, check_plans=check)
+                            "fast": {"residual": 2}}, check_plans=check, cache_tag="sd15_full_64x64_b8_eps")
     # (round 6: the default run follows the 'auto' policy, whose probe picks the level for these weights; the two levels are pinned explicitly)
     print(f"[sd15 B=8 64x64] fast level {r['fast'][0]:.3e} -> accurate level {r['accurate'][0]:.3e}; default (auto policy) {r[None][0]:.3e}")
     assert r["accurate"][0] < 0.6e-3 and r["accurate"][0] < 0.7 * r["fast"][0]   # what the inversion / edit loops run, on the benchmarked tiles
